@@ -1,0 +1,289 @@
+"""CPU oracle for the BMCNet bilateral event-SR hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it, and only as the checker.  The product path (``bmcnet-esr_amd/``)
+never imports anything from ``oracle/`` and has no CPU fallback.
+
+It is a functional restatement (plain functions over a ``{state_dict key:
+tensor}`` mapping, PyTorch-CPU ops + autograd for the backward) of what the
+reference computes on the hot path; nothing here is copied from the reference.
+Each function cites the reference lines it follows (paths relative to the
+upstream repo root).
+
+Parity pin: the reference has no tests or golden vectors of its own
+(SURVEY.md section 4), so this oracle is pinned against outputs of the
+reference itself, generated in the build container by
+``tests/golden/make_golden.py`` (which imports the reference) and committed as
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every one of
+them.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+
+# --------------------------------------------------------------------------
+# event -> count image (dataloader/encodings.py:241-269, 290-305)
+# --------------------------------------------------------------------------
+def events_to_channels_np(xs, ys, ps, sensor_size=(180, 240)):
+    """Two-channel event count image, numpy restatement.
+
+    Follows dataloader/encodings.py:290-305 (events_to_channels) calling
+    dataloader/encodings.py:241-269 (events_to_image) twice, including the
+    side effects of the first call on the caller's ``xs``/``ys``:
+
+    * first call (positive channel): events outside the sensor get
+      x = y = 0 written back into the caller's arrays and their weight zeroed,
+      so they contribute nothing;
+    * second call (negative channel): the same events now sit at (0, 0), are
+      no longer masked, and every formerly-out-of-range *negative* event adds
+      p*p = 1 at row H-1 (the vertical flip of y = 0), column 0.
+
+    Returns (img[2,H,W] float32, xs_after, ys_after); inputs are not modified.
+    """
+    H, W = int(sensor_size[0]), int(sensor_size[1])
+    xs = np.array(xs, dtype=np.float32, copy=True)
+    ys = np.array(ys, dtype=np.float32, copy=True)
+    ps = np.asarray(ps, dtype=np.float32)
+    out = np.zeros((2, H, W), dtype=np.float32)
+    for ch in range(2):
+        wsel = np.where(ps > 0, ps, 0) if ch == 0 else np.where(ps < 0, ps, 0)
+        wgt = (ps * wsel).astype(np.float32)
+        oob = (xs >= W) | (xs < 0) | (ys >= H) | (ys < 0)
+        xs[oob] = 0
+        ys[oob] = 0
+        wgt = np.where(oob, np.float32(0), wgt)
+        xi = xs.astype(np.int64)          # truncation toward zero, like .long()
+        yi = H - ys.astype(np.int64) - 1  # vertical flip
+        np.add.at(out[ch], (yi, xi), wgt)
+    return out, xs, ys
+
+
+# --------------------------------------------------------------------------
+# building blocks (models/submodules.py)
+# --------------------------------------------------------------------------
+def conv(p: Params, name: str, x: torch.Tensor) -> torch.Tensor:
+    w = p[name + ".weight"]
+    return F.conv2d(x, w, p[name + ".bias"], stride=1, padding=w.shape[-1] // 2)
+
+
+def res_block(p: Params, name: str, x: torch.Tensor) -> torch.Tensor:
+    """x + conv2(relu(conv1(x))) -- models/submodules.py:31-35."""
+    return x + conv(p, name + ".conv2", torch.relu(conv(p, name + ".conv1", x)))
+
+
+def layer_norm_2d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-6):
+    """Per-pixel normalisation over channels, biased variance, eps inside the
+    sqrt -- models/submodules.py:127-140,157-166 (forward); autograd supplies
+    the backward that submodules.py:141-154 writes by hand."""
+    mu = x.mean(dim=1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=1, keepdim=True)
+    y = (x - mu) / torch.sqrt(var + eps)
+    return y * weight.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+
+
+def bie(p: Params, name: str, x_1, x_2, x_s):
+    """Bilateral information exchange -- models/submodules.py:58-77."""
+    b, c, h, w = x_1.shape
+    r1 = res_block(p, name + ".conv1", x_1)
+    r2 = res_block(p, name + ".conv2", x_2)
+
+    def centre(convf: str, other):
+        z = conv(p, name + "." + convf, torch.cat([x_s, other], dim=1))
+        z = layer_norm_2d(z, p[name + ".norm_s.weight"], p[name + ".norm_s.bias"])
+        return conv(p, name + ".clustering", z).reshape(b, c, h * w)
+
+    c1 = centre("convf1", x_2)
+    c2 = centre("convf2", x_1)
+    v1 = conv(p, name + ".v1", x_1).reshape(b, c, h * w)
+    v2 = conv(p, name + ".v2", x_2).reshape(b, c, h * w)
+    s = c ** -0.5
+    a1 = torch.softmax(torch.bmm(c1, v1.transpose(1, 2)) * s, dim=-1)
+    a2 = torch.softmax(torch.bmm(c2, v2.transpose(1, 2)) * s, dim=-1)
+    o1 = torch.bmm(a1, v1).reshape(b, c, h, w)
+    o2 = torch.bmm(a2, v2).reshape(b, c, h, w)
+    xs_new = conv(p, name + ".unclustering",
+                  torch.cat([c1.reshape(b, c, h, w), c2.reshape(b, c, h, w)], dim=1)) + x_s
+    return o1 + r2, o2 + r1, xs_new
+
+
+def pixel_unshuffle(x: torch.Tensor, r: int) -> torch.Tensor:
+    """[B,C,rH,rW] -> [B,C*r*r,H,W], channel = c*r*r + i*r + j --
+    models/submodules.py:80-92."""
+    b, c, hh, ww = x.shape
+    h, w = hh // r, ww // r
+    return x.reshape(b, c, h, r, w, r).permute(0, 1, 3, 5, 2, 4).reshape(b, c * r * r, h, w)
+
+
+def pixel_shuffle(x: torch.Tensor, r: int) -> torch.Tensor:
+    """Inverse of pixel_unshuffle (F.pixel_shuffle at models/BMCNet.py:119)."""
+    b, c, h, w = x.shape
+    co = c // (r * r)
+    return x.reshape(b, co, r, r, h, w).permute(0, 1, 4, 2, 5, 3).reshape(b, co, h * r, w * r)
+
+
+def bilinear_up(x: torch.Tensor, r: int) -> torch.Tensor:
+    """x r bilinear, align_corners=False (F.interpolate at models/BMCNet.py:119):
+    src = (dst + 0.5)/r - 0.5 clamped at 0, i0 = floor(src), i1 = min(i0+1, n-1)."""
+    def axis(n):
+        dst = torch.arange(n * r, dtype=torch.float32)
+        src = torch.clamp((dst + 0.5) / r - 0.5, min=0.0)
+        i0 = torch.floor(src).to(torch.int64)
+        i1 = torch.clamp(i0 + 1, max=n - 1)
+        lam = (src - i0.to(torch.float32)).to(x.dtype)
+        return i0, i1, lam
+    _, _, h, w = x.shape
+    y0, y1, ly = axis(h)
+    x0, x1, lx = axis(w)
+    rows = x[:, :, y0, :] * (1 - ly).view(1, 1, -1, 1) + x[:, :, y1, :] * ly.view(1, 1, -1, 1)
+    return rows[:, :, :, x0] * (1 - lx).view(1, 1, 1, -1) + rows[:, :, :, x1] * lx.view(1, 1, 1, -1)
+
+
+# --------------------------------------------------------------------------
+# BMCNet (models/BMCNet.py)
+# --------------------------------------------------------------------------
+def parallel_blk(p: Params, name: str, x_1, x_2, x_s, x_1_st, x_2_st, x_1_s_st, x_2_s_st):
+    """models/BMCNet.py:19-32."""
+    x_1 = res_block(p, name + ".conv1", x_1)
+    x_2 = res_block(p, name + ".conv2", x_2)
+    x_1_st = res_block(p, name + ".conv1_st", x_1_st)
+    x_2_st = res_block(p, name + ".conv2_st", x_2_st)
+    x_1, x_1_st, x_1_s_st = bie(p, name + ".lBIE", x_1, x_1_st, x_1_s_st)
+    x_2, x_2_st, x_2_s_st = bie(p, name + ".lBIE", x_2, x_2_st, x_2_s_st)
+    x_1, x_2, x_s = bie(p, name + ".gBIE", x_1, x_2, x_s)
+    return x_1, x_2, x_s, x_1_st, x_2_st, x_1_s_st, x_2_s_st
+
+
+def _n_blocks(p: Params, prefix: str) -> int:
+    idx = {int(k[len(prefix):].split(".")[0]) for k in p if k.startswith(prefix)}
+    return max(idx) + 1
+
+
+def bmcnet_backbone(p: Params, x1p, x1n, x2p, x2n, hp, hn, hs, o, scale: int):
+    """models/BMCNet.py:57-84."""
+    s2 = scale * scale
+    op, on = o[:, :s2], o[:, s2:]
+    relu = torch.relu
+    xp_st = relu(conv(p, "neuro.conv_fpst", torch.cat([x1p, x2p, hp, op], 1)))
+    xn_st = relu(conv(p, "neuro.conv_fnst", torch.cat([x1n, x2n, hn, on], 1)))
+    xp_s = relu(conv(p, "neuro.conv_fps", torch.cat([x2p, hp], 1)))
+    xn_s = relu(conv(p, "neuro.conv_fns", torch.cat([x2n, hn], 1)))
+    both = torch.cat([xp_st, xn_st], 1)
+    xs = relu(conv(p, "neuro.conv_fs", torch.cat([both, hs, o], 1)))
+    xs_p_st = relu(conv(p, "neuro.conv_fs", torch.cat([both, hp, o], 1)))
+    xs_n_st = relu(conv(p, "neuro.conv_fs", torch.cat([both, hn, o], 1)))
+    for i in range(_n_blocks(p, "neuro.para_reschunk.")):
+        xp_s, xn_s, xs, xp_st, xn_st, xs_p_st, xs_n_st = parallel_blk(
+            p, f"neuro.para_reschunk.{i}", xp_s, xn_s, xs, xp_st, xn_st, xs_p_st, xs_n_st)
+    x_h = relu(conv(p, "neuro.conv_hs", xs))
+    x_h_p = relu(conv(p, "neuro.conv_hp", xs_p_st))
+    x_h_n = relu(conv(p, "neuro.conv_hn", xs_n_st))
+    x_o = conv(p, "neuro.conv_o", torch.cat([xp_s, xn_s], 1))
+    return x_h, x_h_p, x_h_n, x_o
+
+
+def bmcnet_forward(p: Params, x, x_h, x_h_p, x_h_n, x_o, init: bool, scale: int = 4, repeat: int = 3):
+    """One recurrent window -- models/BMCNet.py:95-121.
+    x [B,2,T>=2,H,W]; x_o is [B,2*s*s,H,W] when init else the previous HR
+    prediction [B,2,sH,sW]."""
+    f1, f2 = x[:, :, 0], x[:, :, 1]
+    rep = lambda t: t.repeat(1, repeat, 1, 1)
+    x1p, x1n = rep(f1[:, 0:1]), rep(f1[:, 1:2])
+    x2p, x2n = rep(f2[:, 0:1]), rep(f2[:, 1:2])
+    if not init:
+        x_o = pixel_unshuffle(x_o, scale)
+    # NB models/BMCNet.py:115,118 passes (x_h, x_h_p, x_h_n) positionally into
+    # Backbone.forward(xs, hp, hn, hs, o) (models/BMCNet.py:57): the state the
+    # caller names x_h is consumed as hp, x_h_p as hn and x_h_n as hs.
+    x_h, x_h_p, x_h_n, o = bmcnet_backbone(p, x1p, x1n, x2p, x2n, x_h, x_h_p, x_h_n, x_o, scale)
+    pred = pixel_shuffle(o, scale) + bilinear_up(f2[:, :2], scale)
+    return x_h, x_h_p, x_h_n, pred
+
+
+# --------------------------------------------------------------------------
+# BMCNet_plain (models/BMCNet_plain.py)
+# --------------------------------------------------------------------------
+def plain_backbone(p: Params, x1, x2, h, o, scale: int):
+    """models/BMCNet_plain.py:19-33."""
+    s2 = scale * scale
+    relu = torch.relu
+    a = relu(conv(p, "neuro.conv_f1", torch.cat([x1, h, o[:, :s2]], 1)))
+    b = relu(conv(p, "neuro.conv_f2", torch.cat([x2, h, o[:, s2:]], 1)))
+    s = relu(conv(p, "neuro.conv_fs", torch.cat([x1, x2, h, o], 1)))
+    for i in range(_n_blocks(p, "neuro.para_reschunk.")):
+        a, b, s = bie(p, f"neuro.para_reschunk.{i}", a, b, s)
+    x_h = relu(conv(p, "neuro.conv_h", s))
+    x_o = conv(p, "neuro.conv_o", torch.cat([a, b], 1))
+    return x_h, x_o
+
+
+def plain_forward(p: Params, x, x_h, x_o, init: bool, scale: int = 4, repeat: int = 3):
+    """models/BMCNet_plain.py:44-68."""
+    f1, f2 = x[:, :, 0], x[:, :, 1]
+    rep = lambda t: t.repeat(1, repeat, 1, 1)
+    x1 = torch.cat([rep(f1[:, 0:1]), rep(f2[:, 0:1])], 1)
+    x2 = torch.cat([rep(f1[:, 1:2]), rep(f2[:, 1:2])], 1)
+    if not init:
+        x_o = pixel_unshuffle(x_o, scale)
+    x_h, o = plain_backbone(p, x1, x2, x_h, x_o, scale)
+    return x_h, pixel_shuffle(o, scale) + bilinear_up(f2[:, :2], scale)
+
+
+# --------------------------------------------------------------------------
+# training step (train.py:202-237) and optimiser (config/train_nfs.yml:28-34)
+# --------------------------------------------------------------------------
+def bptt_loss(p: Params, inp_windows: Sequence[torch.Tensor], gt_windows: Sequence[torch.Tensor],
+              n_c: int, scale: int = 4, plain: bool = False):
+    """Sum over windows of mean-squared error between the SR prediction and
+    the HR count image, recurrent state carried without detach --
+    train.py:205-234.  inp_windows[i] is [B,2(pol),T,H,W] (already transposed
+    as train.py:211 does), gt_windows[i] is [B,2,sH,sW]."""
+    B, _, _, H, W = inp_windows[0].shape
+    z = lambda c: torch.zeros(B, c, H, W, dtype=inp_windows[0].dtype)
+    h, hp, hn, pred = z(n_c), z(n_c), z(n_c), z(2 * scale * scale)
+    loss = 0.0
+    preds = []
+    for i, (x, gt) in enumerate(zip(inp_windows, gt_windows)):
+        if plain:
+            h, pred = plain_forward(p, x, h, pred, i == 0, scale)
+        else:
+            h, hp, hn, pred = bmcnet_forward(p, x, h, hp, hn, pred, i == 0, scale)
+        preds.append(pred)
+        loss = loss + F.mse_loss(pred, gt)
+    return loss, preds, (h, hp, hn)
+
+
+def adam_amsgrad_step(params, grads, state, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5):
+    """One torch.optim.Adam(amsgrad=True, weight_decay=wd) update written out
+    (the optimiser train.py:653 builds from config/train_nfs.yml:28-34).
+    state: dict with 'step' and per-parameter lists m, v, vmax; in-place."""
+    state["step"] += 1
+    t = state["step"]
+    b1, b2 = betas
+    bc1 = 1 - b1 ** t
+    bc2 = 1 - b2 ** t
+    for i, (w, g) in enumerate(zip(params, grads)):
+        g = g + weight_decay * w
+        state["m"][i] = b1 * state["m"][i] + (1 - b1) * g
+        state["v"][i] = b2 * state["v"][i] + (1 - b2) * g * g
+        state["vmax"][i] = torch.maximum(state["vmax"][i], state["v"][i])
+        denom = state["vmax"][i].sqrt() / math.sqrt(bc2) + eps
+        w -= (lr / bc1) * state["m"][i] / denom
+    return params
+
+
+def unique_params(p: Params):
+    """State-dict keys grouped by storage (shared modules register alias keys);
+    returns {canonical key: [all keys sharing that tensor]}."""
+    seen = {}
+    for k, v in p.items():
+        seen.setdefault(v.data_ptr(), []).append(k)
+    return {ks[0]: ks for ks in seen.values()}
