@@ -1,0 +1,92 @@
+"""ctypes binding of libbmc_hip.so (C ABI: include/bmc_hip.h).
+
+There is no CPU fallback: if the shared library is missing the import of this
+module raises, and every call checks the return code and raises RuntimeError
+with the library's message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- must come first: libbmc_hip.so has to bind to the HIP runtime torch already loaded
+              # (torch ships its own libamdhip64; two runtimes in one process do not share the device context)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libbmc_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build the HIP extension first "
+        "(python -c 'import __graft_entry__ as g; g.build()' or make -C bmcnet-esr_amd/csrc). "
+        "The BMCNet MI355X path has no CPU fallback.")
+
+_lib = C.CDLL(LIB_PATH)
+
+MAX_SRC = 6
+c_fp = C.c_void_p  # device pointers travel as integers
+
+
+class Src(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("batch_stride", C.c_longlong), ("pix_stride", C.c_int), ("nch", C.c_int),
+                ("batch_shift", C.c_int), ("batch_mod", C.c_int)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("nsrc", C.c_int), ("src", Src * MAX_SRC), ("wpacked", C.c_void_p), ("bias", C.c_void_p),
+                ("w_group_stride", C.c_longlong), ("bias_group_stride", C.c_int), ("batch_per_group", C.c_int),
+                ("out", C.c_void_p), ("out_batch_stride", C.c_longlong), ("out_pix_stride", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cout", C.c_int), ("Coutpad", C.c_int),
+                ("taps", C.c_int), ("relu", C.c_int), ("residual", Src), ("mask", Src), ("accumulate", C.c_int)]
+
+
+class PgemmArgs(C.Structure):
+    _fields_ = [("a", Src), ("nsrc", C.c_int), ("src", Src * MAX_SRC), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("taps", C.c_int), ("batch_per_group", C.c_int), ("slabs", C.c_void_p), ("nsplit", C.c_int)]
+
+
+def _sig(name, argtypes, restype=C.c_int):
+    fn = getattr(_lib, name)
+    fn.argtypes = argtypes
+    fn.restype = restype
+    return fn
+
+
+_ll, _i, _f, _p = C.c_longlong, C.c_int, C.c_float, C.c_void_p
+
+bmc_version = _sig("bmc_version", [])
+bmc_last_error = _sig("bmc_last_error", [], C.c_char_p)
+_events = _sig("bmc_events_to_channels", [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p])
+_pack_w = _sig("bmc_pack_weight", [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p])
+_pack_wt = _sig("bmc_pack_weight_t", [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p])
+_conv = _sig("bmc_conv", [C.POINTER(ConvArgs), _p])
+_pgemm = _sig("bmc_pgemm", [C.POINTER(PgemmArgs), _p])
+_red_w = _sig("bmc_pgemm_reduce_weight", [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p])
+_red_p = _sig("bmc_pgemm_reduce_plain", [_p, _i, _i, _i, _i, _f, _p, _p])
+_colsum = _sig("bmc_colsum", [_p, _ll, _i, _i, _p, _p, _i, _p])
+_relu_bwd = _sig("bmc_relu_bwd", [_p, _p, _p, _ll, _p])
+_ln_fwd = _sig("bmc_layernorm_fwd", [_p, _p, _p, _ll, _i, _f, _p, _p, _p])
+_ln_bwd = _sig("bmc_layernorm_bwd", [_p, _p, _p, _p, _ll, _i, _p, _p, _p, _p, _i, _p])
+_sm_fwd = _sig("bmc_softmax_fwd", [_p, _ll, _i, _p, _p])
+_sm_bwd = _sig("bmc_softmax_bwd", [_p, _p, _ll, _i, _f, _p, _p])
+_pack_in = _sig("bmc_pack_inputs", [_p, _ll, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _p, _p, _p])
+_unshuffle = _sig("bmc_unshuffle_to_nhwc", [_p, _i, _i, _i, _i, _i, _p, _p])
+_shuffle = _sig("bmc_shuffle_to_hr", [_p, _i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _ll, _p, _p])
+
+EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_pack_weight", "bmc_pack_weight_t", "bmc_conv",
+           "bmc_pgemm", "bmc_pgemm_reduce_weight", "bmc_pgemm_reduce_plain", "bmc_colsum", "bmc_relu_bwd",
+           "bmc_layernorm_fwd", "bmc_layernorm_bwd", "bmc_softmax_fwd", "bmc_softmax_bwd", "bmc_pack_inputs",
+           "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr"]
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {bmc_last_error().decode()}")
+
+
+def call(fn, what, *args):
+    check(fn(*args), what)
+
+
+def has_symbol(name: str) -> bool:
+    return hasattr(_lib, name)

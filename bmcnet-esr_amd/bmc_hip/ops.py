@@ -1,0 +1,567 @@
+"""torch.autograd.Function wrappers around the libbmc_hip.so kernels.
+
+Everything here works on fp32 NHWC tensors ([B,H,W,C], contiguous) living on
+an MI355X; there is no CPU path (a CPU tensor raises).  The reference computes
+the same quantities with ATen ops + autograd (models/submodules.py,
+models/BMCNet.py); each function cites what it stands in for.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import lib
+
+CK = 16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("bmc_hip: tensor is on %s -- the BMCNet MI355X path has no CPU fallback" % t.device)
+    if t.dtype != torch.float32:
+        raise RuntimeError("bmc_hip: fp32 tensors only (got %s)" % t.dtype)
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def coutpad(c):
+    return 32 if c <= 32 else round_up(c, 128)
+
+
+class View:
+    """Channel/batch window of an NHWC tensor used as a convolution operand.
+
+    Launch batch b reads batch ((b + shift) % mod) + b0 of `t`, channels
+    [c0, c0 + nch)."""
+    __slots__ = ("t", "c0", "nch", "shift", "mod", "b0")
+
+    def __init__(self, t, c0=0, nch=None, shift=0, mod=None, b0=0):
+        self.t = t
+        self.c0 = c0
+        self.nch = t.shape[3] - c0 if nch is None else nch
+        self.shift = shift
+        self.mod = mod
+        self.b0 = b0
+
+    def meta(self):
+        return (self.c0, self.nch, self.shift, self.mod, self.b0)
+
+
+def _src(t: torch.Tensor, c0, nch, shift, mod, b0, launch_b) -> lib.Src:
+    Bt, H, W, Ct = t.shape
+    s = lib.Src()
+    s.ptr = t.data_ptr() + 4 * (b0 * H * W * Ct + c0)
+    s.batch_stride = H * W * Ct
+    s.pix_stride = Ct
+    s.nch = nch
+    s.batch_shift = shift
+    s.batch_mod = mod if mod is not None else max(launch_b, 1) + shift
+    return s
+
+
+def _null_src() -> lib.Src:
+    s = lib.Src()
+    s.ptr = None
+    s.batch_mod = 1
+    return s
+
+
+# --------------------------------------------------------------------------
+# conv spec: how the reference's concatenated input channels map onto packed,
+# 16-channel-granular sources
+# --------------------------------------------------------------------------
+class ConvSpec:
+    """sources: list of per-source lists giving, for each physical channel of the
+    source window, the reference input-channel index it carries (or -1 = padding)."""
+
+    def __init__(self, sources: Sequence[Sequence[int]]):
+        self.nch = [len(s) for s in sources]
+        for n in self.nch:
+            assert n % CK == 0, "source channel windows must be multiples of 16"
+        flat = [c for s in sources for c in s]
+        self.kpad = len(flat)
+        self.kmap_host = flat
+        self.cin = max(flat) + 1
+        self._kmap = {}
+
+    def kmap(self, device):
+        k = self._kmap.get(device)
+        if k is None:
+            k = torch.tensor(self.kmap_host, dtype=torch.int32, device=device)
+            self._kmap[device] = k
+        return k
+
+    @staticmethod
+    def dense(*nchs):
+        """Sources carry the reference's channels in order, no padding."""
+        out, c = [], 0
+        for n in nchs:
+            out.append(list(range(c, c + n)))
+            c += n
+        return ConvSpec(out)
+
+
+_pack_cache = {}
+
+
+def _packed_weight(w4: torch.Tensor, spec: ConvSpec, cache_key):
+    """[G,Cout,Cin,taps] -> MFMA staging layout (bmc_pack_weight)."""
+    G, Cout, Cin, taps = w4.shape
+    key = None
+    if cache_key is not None:
+        key = (cache_key[0], id(spec), "f")
+        hit = _pack_cache.get(key)
+        if hit is not None and hit[0] == cache_key[1]:
+            return hit[1]
+    cp = coutpad(Cout)
+    out = torch.empty(G * spec.kpad * taps * cp, device=w4.device, dtype=torch.float32)
+    lib.call(lib._pack_w, "bmc_pack_weight", w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin, taps,
+             spec.kpad, cp, out.data_ptr(), _stream())
+    if key is not None:
+        _pack_cache[key] = (cache_key[1], out)
+    return out
+
+
+def _packed_weight_t(w4: torch.Tensor, spec: ConvSpec, src_index: int, cache_key):
+    G, Cout, Cin, taps = w4.shape
+    key = None
+    if cache_key is not None:
+        key = (cache_key[0], id(spec), "t", src_index)
+        hit = _pack_cache.get(key)
+        if hit is not None and hit[0] == cache_key[1]:
+            return hit[1]
+    k0 = sum(spec.nch[:src_index])
+    nk = spec.nch[src_index]
+    nkpad = coutpad(nk)
+    c16 = round_up(Cout, CK)
+    out = torch.empty(G * c16 * taps * nkpad, device=w4.device, dtype=torch.float32)
+    lib.call(lib._pack_wt, "bmc_pack_weight_t", w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin, taps,
+             k0, nk, nkpad, c16, out.data_ptr(), _stream())
+    if key is not None:
+        _pack_cache[key] = (cache_key[1], out)
+    return out
+
+
+def clear_pack_cache():
+    _pack_cache.clear()
+
+
+# --------------------------------------------------------------------------
+# raw launches
+# --------------------------------------------------------------------------
+def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stride, out_ptr, out_batch_stride,
+             out_pix_stride, B, H, W, Cout, taps, relu=False, residual: Optional[lib.Src] = None, bpg=None,
+             accumulate=False):
+    a = lib.ConvArgs()
+    a.nsrc = len(srcs)
+    for i, s in enumerate(srcs):
+        a.src[i] = s
+    a.wpacked = wpacked.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.w_group_stride = w_group_stride
+    a.bias_group_stride = bias_group_stride
+    a.batch_per_group = bpg if bpg else B
+    a.out = out_ptr
+    a.out_batch_stride = out_batch_stride
+    a.out_pix_stride = out_pix_stride
+    a.B, a.H, a.W = B, H, W
+    a.Cout, a.Coutpad = Cout, coutpad(Cout)
+    a.taps = taps
+    a.relu = int(relu)
+    a.residual = residual if residual is not None else _null_src()
+    a.mask = _null_src()
+    a.accumulate = int(accumulate)
+    lib.call(lib._conv, "bmc_conv", C.byref(a), _stream())
+
+
+def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, device):
+    """Returns (slabs, nsplit, G)."""
+    G = B // bpg
+    mpad, npad = round_up(M, 32), round_up(N, 32)
+    if taps == 9:
+        n_nblk = npad // 32
+        tiles = ((H + 3) // 4) * ((W + 15) // 16)
+    else:
+        n_nblk = (npad + 127) // 128
+        tiles = (H * W + 63) // 64
+    other = G * ((mpad + 127) // 128) * n_nblk
+    nsplit = max(1, min(bpg * tiles, 768 // max(other, 1)))
+    slabs = torch.empty(nsplit * G * taps * mpad * npad, device=device, dtype=torch.float32)
+    p = lib.PgemmArgs()
+    p.a = a_src
+    p.nsrc = len(srcs)
+    for i, s in enumerate(srcs):
+        p.src[i] = s
+    p.B, p.H, p.W, p.taps = B, H, W, taps
+    p.batch_per_group = bpg
+    p.slabs = slabs.data_ptr()
+    p.nsplit = nsplit
+    lib.call(lib._pgemm, "bmc_pgemm", C.byref(p), _stream())
+    return slabs, nsplit, G
+
+
+def relu_bwd(dy, y):
+    g = torch.empty_like(dy)
+    lib.call(lib._relu_bwd, "bmc_relu_bwd", dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), _stream())
+    return g
+
+
+def colsum(x2d_ptr, npix, pix_stride, Cn, device):
+    ws = torch.empty(2048 * Cn, device=device, dtype=torch.float32)
+    out = torch.empty(Cn, device=device, dtype=torch.float32)
+    lib.call(lib._colsum, "bmc_colsum", x2d_ptr, npix, pix_stride, Cn, ws.data_ptr(), out.data_ptr(), 0, _stream())
+    return out
+
+
+# --------------------------------------------------------------------------
+# convolution (3x3 / 1x1, multi-source, grouped weights)
+# --------------------------------------------------------------------------
+class ConvMeta:
+    __slots__ = ("spec", "views", "B", "relu", "G", "res", "cache", "taps")
+
+    def __init__(self, spec, views, B, relu, G, res, cache, taps):
+        self.spec, self.views, self.B, self.relu, self.G, self.res, self.cache, self.taps = \
+            spec, views, B, relu, G, res, cache, taps
+
+
+class ConvFn(torch.autograd.Function):
+    """y = epi(conv(cat(sources)) + bias [+ residual]) -- F.conv2d + torch.cat + F.relu + residual add of
+    models/submodules.py:31-35,63-64,75 and models/BMCNet.py:64-82; with G > 1 weights are per batch-group
+    (torch.bmm(softmax, v) of models/submodules.py:72-73 is the G = B, 1x1 case)."""
+
+    @staticmethod
+    def forward(ctx, meta: ConvMeta, weight, bias, res_t, *src_ts):
+        for t in src_ts:
+            _need_gpu(t)
+        t0 = src_ts[0]
+        _, H, W, _ = t0.shape
+        G, taps, B = meta.G, meta.taps, meta.B
+        w4 = weight.detach().reshape(G, -1, meta.spec.cin, taps)
+        Cout = w4.shape[1]
+        ck = (weight.data_ptr(), weight._version) if meta.cache else None
+        wp = _packed_weight(w4.contiguous(), meta.spec, ck)
+        out = torch.empty((B, H, W, Cout), device=t0.device, dtype=torch.float32)
+        srcs = [_src(t.detach(), *v, B) for t, v in zip(src_ts, meta.views)]
+        res = None
+        if res_t is not None:
+            res = _src(res_t.detach(), 0, Cout, meta.res[0], meta.res[1], 0, B)
+        cp = coutpad(Cout)
+        conv_raw(srcs, wp, meta.spec.kpad * taps * cp, bias.detach() if bias is not None else None, Cout,
+                 out.data_ptr(), H * W * Cout, Cout, B, H, W, Cout, taps, relu=meta.relu, residual=res,
+                 bpg=B // G)
+        ctx.meta = meta
+        ctx.has_bias = bias is not None
+        ctx.has_res = res_t is not None
+        ctx.save_for_backward(weight, out if meta.relu else None, *src_ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        meta = ctx.meta
+        weight, out, *src_ts = ctx.saved_tensors
+        G, taps, B, spec = meta.G, meta.taps, meta.B, meta.spec
+        dy = dy.contiguous()
+        g = relu_bwd(dy, out) if meta.relu else dy
+        _, H, W, Cout = g.shape
+        dev = g.device
+        w4 = weight.detach().reshape(G, Cout, spec.cin, taps).contiguous()
+        ck = (weight.data_ptr(), weight._version) if meta.cache else None
+        need = ctx.needs_input_grad
+        dw = db = dres = None
+        # ---- weight gradient: pixel-reduction GEMM  dW[co][k][tap] = sum_px g[px][co] * x[px+tap][k]
+        if need[1]:
+            srcs = [_src(t, *v, B) for t, v in zip(src_ts, meta.views)]
+            a_src = _src(g, 0, Cout, 0, None, 0, B)
+            slabs, nsplit, _ = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev)
+            dwf = torch.zeros(G * Cout * spec.cin * taps, device=dev, dtype=torch.float32)
+            lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, G, taps, Cout, spec.kpad,
+                     spec.kmap(dev).data_ptr(), spec.cin, dwf.data_ptr(), 0, _stream())
+            dw = dwf.view(weight.shape)
+        if ctx.has_bias and need[2]:
+            bpg = B // G
+            parts = [colsum(g.data_ptr() + 4 * gi * bpg * H * W * Cout, bpg * H * W, Cout, Cout, dev) for gi in range(G)]
+            db = parts[0] if G == 1 else torch.stack(parts)
+        if ctx.has_res and need[3]:
+            shift, mod = meta.res
+            dres = g
+            if mod is not None and mod < B:
+                dres = g.view(B // mod, mod, H, W, Cout).sum(0)
+            elif shift:
+                dres = torch.roll(g, shifts=shift, dims=0)
+        # ---- data gradients: same conv kernel, transposed + mirrored weights, one launch per source
+        dsrcs = []
+        for i, (t, v) in enumerate(zip(src_ts, meta.views)):
+            if not need[4 + i]:
+                dsrcs.append(None)
+                continue
+            c0, nch, shift, mod, b0 = v
+            Bt, _, _, Ct = t.shape
+            wt = _packed_weight_t(w4, spec, i, ck)
+            c16 = round_up(Cout, CK)
+            nkpad = coutpad(nch)
+            gs, nb, gshift, gmod = g, B, 0, None
+            post = None
+            if G > 1 and ((mod is not None and mod < B) or shift):
+                # grouped weights + remapped operand: launch over the full batch, fold the batch map afterwards
+                tmp = torch.empty((B, H, W, nch), device=dev, dtype=torch.float32)
+                conv_raw([_src(g, 0, Cout, 0, None, 0, B)], wt, c16 * taps * nkpad, None, 0, tmp.data_ptr(), H * W * nch,
+                         nch, B, H, W, nch, taps, bpg=B // G)
+                if mod is not None and mod < B:
+                    tmp = tmp.view(B // mod, mod, H, W, nch).sum(0)
+                    if shift:
+                        tmp = torch.roll(tmp, shifts=shift, dims=0)
+                elif shift:
+                    tmp = torch.roll(tmp, shifts=shift, dims=0)
+                nbt = tmp.shape[0]
+                if c0 == 0 and nch == Ct and b0 == 0 and nbt == Bt:
+                    dx = tmp
+                else:
+                    dx = torch.zeros_like(t)
+                    dx[b0:b0 + nbt, :, :, c0:c0 + nch] = tmp
+                dsrcs.append(dx)
+                continue
+            if mod is not None and mod < B:          # operand shared by several launch batches: sum first (linearity)
+                assert shift == 0
+                gs, nb = g.view(B // mod, mod, H, W, Cout).sum(0), mod
+            elif shift:                               # operand read with a batch rotation: rotate back
+                assert mod == B
+                gshift, gmod = (mod - shift) % mod, mod
+            full = (c0 == 0 and nch == Ct and b0 == 0 and nb == Bt)
+            dx = torch.empty_like(t) if full else torch.zeros_like(t)
+            gsrc = _src(gs, 0, Cout, gshift, gmod, 0, nb)
+            if Cout % CK:
+                raise RuntimeError("bmc_hip: conv output channels must be a multiple of 16 for the data gradient")
+            conv_raw([gsrc], wt, c16 * taps * nkpad, None, 0, dx.data_ptr() + 4 * (b0 * H * W * Ct + c0), H * W * Ct, Ct,
+                     nb, H, W, nch, taps, bpg=nb // G)
+            dsrcs.append(dx)
+        return (None, dw, db, dres, *dsrcs)
+
+
+def conv(views: Sequence[View], weight, bias, spec: ConvSpec, *, B=None, relu=False, residual=None, G=1,
+         cache=True, taps=None):
+    """views: operands (in packed-K order of `spec`); weight [Cout,Cin,kh,kw] (G == 1) or [G,Cout,Cin(,1,1)]."""
+    B = views[0].t.shape[0] if B is None else B
+    if taps is None:
+        taps = weight.shape[-1] * weight.shape[-2] if weight.dim() >= 4 else 1
+    res_t, res_meta = None, None
+    if residual is not None:
+        res_t, res_meta = residual.t, (residual.shift, residual.mod)
+    meta = ConvMeta(spec, [v.meta() for v in views], B, relu, G, res_meta, cache, taps)
+    return ConvFn.apply(meta, weight, bias, res_t, *[v.t for v in views])
+
+
+# --------------------------------------------------------------------------
+# LayerNorm2d (models/submodules.py:127-166)
+# --------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _need_gpu(x)
+        x = x.contiguous()
+        Cn = x.shape[-1]
+        npix = x.numel() // Cn
+        y = torch.empty_like(x)
+        stats = torch.empty(npix * 2, device=x.device, dtype=torch.float32)
+        lib.call(lib._ln_fwd, "bmc_layernorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), npix, Cn, eps,
+                 y.data_ptr(), stats.data_ptr(), _stream())
+        ctx.save_for_backward(x, stats, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        Cn = x.shape[-1]
+        npix = x.numel() // Cn
+        dx = torch.empty_like(x)
+        ws = torch.empty(2 * 1024 * Cn, device=x.device, dtype=torch.float32)
+        dg = torch.empty(Cn, device=x.device, dtype=torch.float32)
+        db = torch.empty(Cn, device=x.device, dtype=torch.float32)
+        lib.call(lib._ln_bwd, "bmc_layernorm_bwd", dy.data_ptr(), x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), npix,
+                 Cn, dx.data_ptr(), ws.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, _stream())
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-6):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+# --------------------------------------------------------------------------
+# channel Gram matrix + softmax (models/submodules.py:69-73)
+# --------------------------------------------------------------------------
+_ID_SPECS = {}
+
+
+def _dense_spec(n):
+    s = _ID_SPECS.get(n)
+    if s is None:
+        s = ConvSpec.dense(n)
+        _ID_SPECS[n] = s
+    return s
+
+
+class GramFn(torch.autograd.Function):
+    """att[b] = scale * sum_px c[b,px,:]^T v[b,px,:]  ([C,C] per sample) -- torch.bmm(center, v) * scale."""
+
+    @staticmethod
+    def forward(ctx, c, v, scale):
+        _need_gpu(c)
+        B, H, W, Cn = c.shape
+        a_src = _src(c.detach(), 0, Cn, 0, None, 0, B)
+        slabs, nsplit, G = pgemm_raw(a_src, [_src(v.detach(), 0, Cn, 0, None, 0, B)], B, H, W, 1, 1, Cn, Cn, c.device)
+        att = torch.empty((B, Cn, Cn), device=c.device, dtype=torch.float32)
+        lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, scale, att.data_ptr(),
+                 _stream())
+        ctx.save_for_backward(c, v)
+        ctx.scale = scale
+        return att
+
+    @staticmethod
+    def backward(ctx, datt):
+        c, v = ctx.saved_tensors
+        B, H, W, Cn = c.shape
+        spec = _dense_spec(Cn)
+        ds = (datt * ctx.scale).contiguous()
+        dc = dv = None
+        cp = coutpad(Cn)
+        if ctx.needs_input_grad[0]:   # dc[px,i] = sum_j ds[i,j] v[px,j]
+            wp = _packed_weight(ds.view(B, Cn, Cn, 1), spec, None)
+            dc = torch.empty_like(c)
+            conv_raw([_src(v, 0, Cn, 0, None, 0, B)], wp, spec.kpad * cp, None, 0, dc.data_ptr(), H * W * Cn, Cn, B, H, W,
+                     Cn, 1, bpg=1)
+        if ctx.needs_input_grad[1]:   # dv[px,j] = sum_i ds[i,j] c[px,i]
+            wp = _packed_weight(ds.transpose(1, 2).contiguous().view(B, Cn, Cn, 1), spec, None)
+            dv = torch.empty_like(v)
+            conv_raw([_src(c, 0, Cn, 0, None, 0, B)], wp, spec.kpad * cp, None, 0, dv.data_ptr(), H * W * Cn, Cn, B, H, W,
+                     Cn, 1, bpg=1)
+        return dc, dv, None
+
+
+def gram(c, v, scale):
+    return GramFn.apply(c, v, scale)
+
+
+class SoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):
+        _need_gpu(a)
+        a = a.contiguous()
+        p = torch.empty_like(a)
+        Cn = a.shape[-1]
+        lib.call(lib._sm_fwd, "bmc_softmax_fwd", a.data_ptr(), a.numel() // Cn, Cn, p.data_ptr(), _stream())
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        dp = dp.contiguous()
+        Cn = p.shape[-1]
+        da = torch.empty_like(p)
+        lib.call(lib._sm_bwd, "bmc_softmax_bwd", p.data_ptr(), dp.data_ptr(), p.numel() // Cn, Cn, 1.0, da.data_ptr(),
+                 _stream())
+        return da
+
+
+def softmax_rows(a):
+    return SoftmaxFn.apply(a)
+
+
+def attn_apply(p, v, residual: Optional[View] = None):
+    """out[b,px,i] = sum_j p[b,i,j] v[b,px,j] (+ residual) -- torch.bmm(softmax, v^T) of models/submodules.py:72-73
+    as a 1x1 convolution with one weight matrix per sample."""
+    B, _, _, Cn = v.shape
+    return conv([View(v)], p, None, _dense_spec(Cn), B=B, residual=residual, G=B, cache=False, taps=1)
+
+
+# --------------------------------------------------------------------------
+# window head / tail (models/BMCNet.py:106-119, models/submodules.py:80-92)
+# --------------------------------------------------------------------------
+def pack_inputs(x, repeat=3):
+    """x [B,2,T,H,W] (any strides) -> xin12 NHWC [2B,H,W,16]: batches [0,B) carry the positive-polarity frames
+    [f1,f1,f1,f2,f2,f2,0..], batches [B,2B) the negative ones; no gradient (network inputs)."""
+    _need_gpu(x)
+    B, _, _, H, W = x.shape
+    xin = torch.empty((2 * B, H, W, CK), device=x.device, dtype=torch.float32)
+    sb, sc, st, sy, sx = x.stride()
+    lib.call(lib._pack_in, "bmc_pack_inputs", x.data_ptr(), sb, sc, st, sy, sx, B, H, W, repeat, xin.data_ptr(),
+             xin.data_ptr() + 4 * B * H * W * CK, _stream())
+    return xin
+
+
+def _unshuffle(hr, r):
+    B, Cc, HH, WW = hr.shape
+    H, W = HH // r, WW // r
+    lr = torch.empty((B, H, W, Cc * r * r), device=hr.device, dtype=torch.float32)
+    lib.call(lib._unshuffle, "bmc_unshuffle_to_nhwc", hr.data_ptr(), B, Cc, H, W, r, lr.data_ptr(), _stream())
+    return lr
+
+
+def _shuffle(lr, r, base=None):
+    B, H, W, CC = lr.shape
+    Cc = CC // (r * r)
+    hr = torch.empty((B, Cc, H * r, W * r), device=lr.device, dtype=torch.float32)
+    if base is None:
+        lib.call(lib._shuffle, "bmc_shuffle_to_hr", lr.data_ptr(), B, Cc, H, W, r, None, 0, 0, 0, 0, hr.data_ptr(), _stream())
+    else:
+        sb, sc, sy, sx = base.stride()
+        lib.call(lib._shuffle, "bmc_shuffle_to_hr", lr.data_ptr(), B, Cc, H, W, r, base.data_ptr(), sb, sc, sy, sx,
+                 hr.data_ptr(), _stream())
+    return hr
+
+
+class UnshuffleFn(torch.autograd.Function):
+    """HR NCHW [B,C,rH,rW] -> LR NHWC [B,H,W,C r r] (PixelUnShuffle, models/submodules.py:80-92)."""
+
+    @staticmethod
+    def forward(ctx, hr, r):
+        _need_gpu(hr)
+        ctx.r = r
+        return _unshuffle(hr.contiguous(), r)
+
+    @staticmethod
+    def backward(ctx, dlr):
+        return _shuffle(dlr.contiguous(), ctx.r), None
+
+
+class HeadFn(torch.autograd.Function):
+    """pred = pixel_shuffle(x_o, r) + bilinear_up(base, r)  (models/BMCNet.py:119); base carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, xo, base, r):
+        _need_gpu(xo)
+        ctx.r = r
+        return _shuffle(xo.contiguous(), r, base)
+
+    @staticmethod
+    def backward(ctx, dpred):
+        return _unshuffle(dpred.contiguous(), ctx.r), None, None
+
+
+def pixel_unshuffle_nhwc(hr, r):
+    return UnshuffleFn.apply(hr, r)
+
+
+def head(xo, base, r):
+    return HeadFn.apply(xo, base, r)
+
+
+# --------------------------------------------------------------------------
+# event -> count image (dataloader/encodings.py:290-305)
+# --------------------------------------------------------------------------
+def events_to_channels_batched(xs, ys, ps, offsets, H, W, mutate=True):
+    """xs/ys/ps: fp32 device vectors; offsets: int64 device vector [nframes+1] -> [nframes,2,H,W]."""
+    _need_gpu(xs)
+    nframes = offsets.numel() - 1
+    out = torch.empty((nframes, 2, H, W), device=xs.device, dtype=torch.float32)
+    lib.call(lib._events, "bmc_events_to_channels", xs.data_ptr(), ys.data_ptr(), ps.data_ptr(), offsets.data_ptr(),
+             nframes, H, W, out.data_ptr(), int(mutate), _stream())
+    return out

@@ -1,0 +1,14 @@
+// Library-level entry points: version + last-error text.
+#include "bmc_common.h"
+
+static thread_local char g_err[512] = "";
+
+void bmc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int bmc_version(void) { return 100; }
+extern "C" const char* bmc_last_error(void) { return g_err; }

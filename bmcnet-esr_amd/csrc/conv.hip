@@ -1,0 +1,267 @@
+// Implicit-GEMM 3x3 / 1x1 convolution on the fp32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32), NHWC, multi-source (no torch.cat), fused
+// bias / residual / ReLU / ReLU-mask epilogue, optional per-group weights.
+//
+// One workgroup (4 waves) computes an 8x16-pixel x BN-channel output tile.
+// K = taps * sum(nch) is walked in steps of (one 16-channel chunk, one tap):
+//   * the (8+2)x(16+2) input halo of the chunk is staged once in LDS and re-read
+//     for all 9 taps (tap shift = constant LDS offset);
+//   * the [BN][16] weight slice of the step is streamed through a second LDS
+//     buffer; both are double-buffered, global loads for step s+1 are issued
+//     before the MFMAs of step s and written to LDS after them (one barrier/step).
+// MFMA operand mapping: A = pixels (rows), B = output channels (cols); lane
+// (i = l&31, h = l>>5) reads 4 consecutive k at offset 4h with one ds_read_b128 --
+// the k-order inside a chunk is permuted identically for A and B, which a dot
+// product does not care about.
+#include "bmc_common.h"
+
+namespace {
+
+constexpr int CK = BMC_CK;  // channels per chunk
+constexpr int RS = 20;      // LDS row stride in floats (16 + 4 pad: conflict-free ds_read_b128)
+constexpr int TH = 8, TW = 16;
+
+struct ConvK {
+    int nsrc;
+    SrcDev src[BMC_MAX_SRC];
+    const float* w;
+    const float* bias;
+    long long w_group_stride;
+    int bias_group_stride;
+    int batch_per_group;
+    float* out;
+    long long out_batch_stride;
+    int out_pix_stride;
+    int B, H, W, Cout, Coutpad;
+    int relu;
+    SrcDev residual;
+    SrcDev mask;
+    int accumulate;
+    int tiles_x, tiles_y, ntn, nchunks;
+};
+
+template <int TAPS, int BN>
+__global__ __launch_bounds__(256) void conv_kernel(const ConvK a) {
+    constexpr int P = TAPS == 9 ? 1 : 0;
+    constexpr int HWD = TW + 2 * P, HHT = TH + 2 * P, NHALO = HWD * HHT;
+    constexpr int MT = BN == 128 ? 2 : 1, NT = BN == 128 ? 2 : 1;
+    constexpr int NXLD = (NHALO * 4 + 255) / 256;
+    constexpr int NWLD = (BN * 4 + 255) / 256;
+    constexpr int XBUF = NHALO * RS, WBUF = BN * RS;
+    __shared__ __attribute__((aligned(16))) float lds[2 * XBUF + 2 * WBUF];
+    float* const Xb = lds;
+    float* const Wb = lds + 2 * XBUF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int nt = bid % a.ntn; bid /= a.ntn;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int b = bid / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int g = b / a.batch_per_group;
+    const float* const wbase = a.w + (long long)g * a.w_group_stride + (long long)nt * BN * CK;
+    const long long wstep = (long long)a.Coutpad * CK;
+
+    // ---- per-thread staging coordinates (fixed for the whole K loop)
+    int xpix[NXLD];
+    bool xok[NXLD];
+#pragma unroll
+    for (int n = 0; n < NXLD; ++n) {
+        const int e = tid + 256 * n, hp = e >> 2;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int y = y0 - P + hy, x = x0 - P + hx;
+        xok[n] = hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        xpix[n] = y * a.W + x;
+    }
+    const int q4 = (tid & 3) * 4;
+
+    f32x4 xr[NXLD], wr[NWLD];
+
+    // chunk -> (source, channel offset) walk
+    int s_idx = 0, c_in = 0;
+    auto cur_src = [&](int idx) -> SrcDev {
+        SrcDev S = a.src[0];
+        if (idx == 1) S = a.src[1];
+        if (idx == 2) S = a.src[2];
+        if (idx == 3) S = a.src[3];
+        if (idx == 4) S = a.src[4];
+        if (idx == 5) S = a.src[5];
+        return S;
+    };
+    auto load_x = [&]() {  // loads chunk (s_idx, c_in), then advances the walk
+        const SrcDev S = cur_src(s_idx);
+        const float* base = src_batch_ptr(S, b) + c_in + q4;
+#pragma unroll
+        for (int n = 0; n < NXLD; ++n) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (xok[n]) v = *reinterpret_cast<const f32x4*>(base + (long long)xpix[n] * S.pix_stride);
+            xr[n] = v;
+        }
+        c_in += CK;
+        if (c_in >= S.nch) { c_in = 0; ++s_idx; }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < NXLD; ++n) {
+            const int e = tid + 256 * n, hp = e >> 2;
+            if (hp < NHALO) *reinterpret_cast<f32x4*>(Xb + buf * XBUF + hp * RS + q4) = xr[n];
+        }
+    };
+    auto load_w = [&](int step) {
+        const float* p = wbase + (long long)step * wstep;
+#pragma unroll
+        for (int n = 0; n < NWLD; ++n) {
+            const int e = tid + 256 * n;
+            if (e < BN * 4) wr[n] = *reinterpret_cast<const f32x4*>(p + e * 4);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < NWLD; ++n) {
+            const int e = tid + 256 * n;
+            if (e < BN * 4) *reinterpret_cast<f32x4*>(Wb + buf * WBUF + (e >> 2) * RS + q4) = wr[n];
+        }
+    };
+
+    // ---- MFMA fragment addressing
+    const int rowbase = BN == 128 ? 4 * (wave >> 1) : 2 * wave;
+    const int cobase = BN == 128 ? 64 * (wave & 1) : 0;
+    int aoff[MT], boff[NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) aoff[t] = ((rowbase + 2 * t + (li >> 4)) * HWD + (li & 15)) * RS + 4 * lh;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) boff[u] = (cobase + 32 * u + li) * RS + 4 * lh;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int nsteps = a.nchunks * TAPS;
+
+    load_x();
+    load_w(0);
+    store_x(0);
+    store_w(0);
+    __syncthreads();
+
+    for (int c = 0; c < a.nchunks; ++c) {
+        const float* const xb = Xb + (c & 1) * XBUF;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int step = c * TAPS + tap;
+            const bool has_next = step + 1 < nsteps;
+            const bool next_x = (tap == TAPS - 1) && (c + 1 < a.nchunks);
+            if (has_next) load_w(step + 1);
+            if (next_x) load_x();
+            const float* const wb = Wb + (step & 1) * WBUF;
+            const int tapoff = TAPS == 9 ? ((tap / 3) * HWD + (tap % 3)) * RS : 0;
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
+                f32x4 af[MT], bf[NT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const f32x4*>(xb + aoff[t] + tapoff + 8 * kg);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) bf[u] = *reinterpret_cast<const f32x4*>(wb + boff[u] + 8 * kg);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u)
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][j], bf[u][j], acc[t][u], 0, 0, 0);
+            }
+            if (has_next) store_w((step + 1) & 1);
+            if (next_x) store_x((c + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue
+    const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
+    float* const outb = a.out + (long long)b * a.out_batch_stride;
+    const float* const resb = a.residual.ptr ? src_batch_ptr(a.residual, b) : nullptr;
+    const float* const maskb = a.mask.ptr ? src_batch_ptr(a.mask, b) : nullptr;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int co = nt * BN + cobase + 32 * u + li;
+        const bool cok = co < a.Cout;
+        const float bv = (biasg && cok) ? biasg[co] : 0.f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int irow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int y = y0 + rowbase + 2 * t + (irow >> 4), x = x0 + (irow & 15);
+                if (cok && y < a.H && x < a.W) {
+                    const long long pix = (long long)y * a.W + x;
+                    float v = acc[t][u][r] + bv;
+                    if (resb) v += resb[pix * a.residual.pix_stride + co];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (maskb) v = maskb[pix * a.mask.pix_stride + co] > 0.f ? v : 0.f;
+                    float* o = outb + pix * a.out_pix_stride + co;
+                    if (a.accumulate) v += *o;
+                    *o = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int bmc_conv(const bmc_conv_args_t* h, bmc_stream_t stream) {
+    BMC_CHECK_ARG(h != nullptr, "bmc_conv: null args");
+    BMC_CHECK_ARG(h->nsrc >= 1 && h->nsrc <= BMC_MAX_SRC, "bmc_conv: nsrc=%d out of range", h->nsrc);
+    BMC_CHECK_ARG(h->taps == 1 || h->taps == 9, "bmc_conv: taps must be 1 or 9 (got %d)", h->taps);
+    BMC_CHECK_ARG(h->B > 0 && h->H > 0 && h->W > 0, "bmc_conv: bad shape %dx%dx%d", h->B, h->H, h->W);
+    BMC_CHECK_ARG(h->Cout > 0 && h->Coutpad >= h->Cout && h->Coutpad % 32 == 0 &&
+                      (h->Coutpad == 32 || h->Coutpad % 128 == 0),
+                  "bmc_conv: Coutpad=%d must be 32 or a multiple of 128 and >= Cout=%d", h->Coutpad, h->Cout);
+    BMC_CHECK_ARG(h->wpacked && h->out, "bmc_conv: null weight/out pointer");
+    BMC_CHECK_ARG(h->batch_per_group >= 1, "bmc_conv: batch_per_group must be >= 1");
+    ConvK k;
+    k.nsrc = h->nsrc;
+    int ktot = 0;
+    for (int i = 0; i < BMC_MAX_SRC; ++i) {
+        if (i < h->nsrc) {
+            BMC_CHECK_ARG(h->src[i].ptr && h->src[i].nch > 0 && h->src[i].nch % CK == 0 && h->src[i].pix_stride % 4 == 0 &&
+                              ((uintptr_t)h->src[i].ptr & 15) == 0 && h->src[i].batch_stride % 4 == 0,
+                          "bmc_conv: source %d: nch=%d must be a multiple of 16, pointer/strides 16-byte aligned", i,
+                          h->src[i].nch);
+            k.src[i] = to_dev(h->src[i]);
+            ktot += h->src[i].nch;
+        } else {
+            k.src[i] = to_dev(h->src[0]);
+        }
+    }
+    k.w = h->wpacked; k.bias = h->bias;
+    k.w_group_stride = h->w_group_stride; k.bias_group_stride = h->bias_group_stride;
+    k.batch_per_group = h->batch_per_group;
+    k.out = h->out; k.out_batch_stride = h->out_batch_stride; k.out_pix_stride = h->out_pix_stride;
+    k.B = h->B; k.H = h->H; k.W = h->W; k.Cout = h->Cout; k.Coutpad = h->Coutpad;
+    k.relu = h->relu; k.residual = to_dev(h->residual); k.mask = to_dev(h->mask); k.accumulate = h->accumulate;
+    k.tiles_x = (h->W + TW - 1) / TW; k.tiles_y = (h->H + TH - 1) / TH;
+    const int BN = h->Coutpad == 32 ? 32 : 128;
+    k.ntn = h->Coutpad / BN;
+    k.nchunks = ktot / CK;
+    const long long nblk = (long long)h->B * k.tiles_x * k.tiles_y * k.ntn;
+    BMC_CHECK_ARG(nblk < (1ll << 31), "bmc_conv: grid too large");
+    dim3 grid((unsigned)nblk), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (h->taps == 9) {
+        if (BN == 128) hipLaunchKernelGGL((conv_kernel<9, 128>), grid, block, 0, st, k);
+        else hipLaunchKernelGGL((conv_kernel<9, 32>), grid, block, 0, st, k);
+    } else {
+        if (BN == 128) hipLaunchKernelGGL((conv_kernel<1, 128>), grid, block, 0, st, k);
+        else hipLaunchKernelGGL((conv_kernel<1, 32>), grid, block, 0, st, k);
+    }
+    BMC_CHECK_LAUNCH("bmc_conv");
+    return 0;
+}

@@ -1,0 +1,270 @@
+// Pixel-reduction GEMM on the fp32 matrix cores:
+//   C[g][tap][m][n] = sum_{b in group g} sum_{y,x} A[b,y,x,m] * cat(src)[b, y+dy, x+dx, n]
+// = the weight gradient of a 3x3 / 1x1 convolution (A = dY, src = the conv inputs),
+// and the channel Gram matrix center . v^T of the BIE block (and its backward).
+//
+// The reduction axis is the pixel axis, so both MFMA operands are read
+// "k-major" straight from NHWC tiles in LDS (lane i -> channel i: conflict-free
+// ds_read_b32).  A workgroup (4 waves) owns 128 rows (m) x NT*32 columns (n) x
+// TAPS taps of the output and loops over its share of pixel tiles, accumulating
+// in registers (TAPS*NT 32x32 tiles per wave); the 9 taps re-use one A fragment
+// and read the X halo tile at 9 constant LDS offsets.  Partial sums of the
+// `nsplit` pixel splits go to slabs and are summed by a second kernel in a fixed
+// order (deterministic, no float atomics).
+#include "bmc_common.h"
+
+namespace {
+
+constexpr int PT_H = 4, PT_W = 16, PT = PT_H * PT_W;  // 64-pixel tile
+constexpr int AS = 128;                                // LDS row stride of the A tile
+
+struct PgemmK {
+    SrcDev a;
+    int nsrc;
+    SrcDev src[BMC_MAX_SRC];
+    int B, H, W;
+    int batch_per_group;
+    float* slabs;
+    int nsplit;
+    int M, Mpad, N, Npad;
+    int n_nblk, n_mblk, G;
+    int tiles_x, tiles_y, tiles_per_img;
+};
+
+template <int TAPS, int NT>
+__global__ __launch_bounds__(256) void pgemm_kernel(const PgemmK a) {
+    constexpr int P = TAPS == 9 ? 1 : 0;
+    constexpr int HWD = PT_W + 2 * P, HHT = PT_H + 2 * P;
+    constexpr int NHALO = TAPS == 9 ? HWD * HHT : PT;
+    constexpr int NB = 32 * NT;  // columns per block
+    constexpr int XS = NB;       // LDS row stride of the X tile
+    __shared__ __attribute__((aligned(16))) float lds[PT * AS + NHALO * XS];
+    float* const At = lds;
+    float* const Xt = lds + PT * AS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int split = bid % a.nsplit; bid /= a.nsplit;
+    const int nb = bid % a.n_nblk; bid /= a.n_nblk;
+    const int mb = bid % a.n_mblk;
+    const int g = bid / a.n_mblk;
+    const int m0 = mb * 128, n0 = nb * NB;
+    const bool wave_active = m0 + 32 * wave < a.Mpad;
+
+    f32x16 acc[TAPS * NT];
+#pragma unroll
+    for (int t = 0; t < TAPS * NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int ntiles = a.batch_per_group * a.tiles_per_img;
+    for (int tile = split; tile < ntiles; tile += a.nsplit) {
+        const int bb = tile / a.tiles_per_img, tin = tile - bb * a.tiles_per_img;
+        const int b = g * a.batch_per_group + bb;
+        int y0 = 0, x0 = 0, p0 = 0;
+        if (TAPS == 9) { y0 = (tin / a.tiles_x) * PT_H; x0 = (tin % a.tiles_x) * PT_W; }
+        else p0 = tin * PT;
+        const int HWp = a.H * a.W;
+
+        // ---- stage A tile: [64 px][128 ch of this m-block], zero outside image / beyond M
+        {
+            const float* ab = src_batch_ptr(a.a, b);
+#pragma unroll
+            for (int n = 0; n < PT * 32 / 256; ++n) {
+                const int e = tid + 256 * n, p = e >> 5, c4 = (e & 31) * 4;
+                long long pix;
+                bool ok;
+                if (TAPS == 9) {
+                    const int y = y0 + (p >> 4), x = x0 + (p & 15);
+                    ok = y < a.H && x < a.W;
+                    pix = (long long)y * a.W + x;
+                } else {
+                    pix = p0 + p;
+                    ok = pix < HWp;
+                }
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok && m0 + c4 < a.M) v = *reinterpret_cast<const f32x4*>(ab + pix * a.a.pix_stride + m0 + c4);
+                *reinterpret_cast<f32x4*>(At + p * AS + c4) = v;
+            }
+        }
+        // ---- stage X tile: [NHALO px][NB ch], 16-channel chunks resolved to their source
+        {
+            constexpr int F4_PER_PX = NB / 4;
+            constexpr int NX = (NHALO * F4_PER_PX + 255) / 256;
+#pragma unroll
+            for (int n = 0; n < NX; ++n) {
+                const int e = tid + 256 * n, hp = e / F4_PER_PX, c4 = (e - hp * F4_PER_PX) * 4;
+                if (hp < NHALO) {
+                    long long pix;
+                    bool ok;
+                    if (TAPS == 9) {
+                        const int hy = hp / HWD, hx = hp - hy * HWD;
+                        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                        ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
+                        pix = (long long)y * a.W + x;
+                    } else {
+                        pix = p0 + hp;
+                        ok = pix < HWp;
+                    }
+                    // channel n0 + c4 -> source
+                    int ch = n0 + c4;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (ok && ch < a.N) {
+                        SrcDev S = a.src[0];
+#pragma unroll
+                        for (int si = 1; si < BMC_MAX_SRC; ++si)
+                            if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; }
+                        v = *reinterpret_cast<const f32x4*>(src_batch_ptr(S, b) + pix * S.pix_stride + ch);
+                    }
+                    *reinterpret_cast<f32x4*>(Xt + hp * XS + c4) = v;
+                }
+            }
+        }
+        __syncthreads();
+
+        if (wave_active) {
+            const float* const ap = At + lh * AS + 32 * wave + li;
+            const float* const xp = Xt + lh * XS + li;
+#pragma unroll
+            for (int q = 0; q < PT / 2; ++q) {
+                const float av = ap[2 * q * AS];
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) {
+                        int off;
+                        if (TAPS == 9) off = (((q >> 3) + tap / 3) * HWD + 2 * (q & 7) + tap % 3) * XS;
+                        else off = 2 * q * XS + 32 * u;
+                        acc[tap * NT + u] =
+                            __builtin_amdgcn_mfma_f32_32x32x2f32(av, xp[off], acc[tap * NT + u], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- write this split's partial tile: slabs[split][g][tap][Mpad][Npad]
+    if (wave_active) {
+        float* const sl = a.slabs + (((long long)split * a.G + g) * TAPS) * a.Mpad * a.Npad;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int n = n0 + 32 * u + li;
+                if (n < a.Npad) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        sl[((long long)tap * a.Mpad + m) * a.Npad + n] = acc[tap * NT + u][r];
+                    }
+                }
+            }
+    }
+}
+
+__global__ void reduce_weight_kernel(const float* slabs, int nsplit, int G, int taps, int M, int N, int Mpad, int Npad,
+                                     const int* kmap, int Cin, float* dw, int accumulate) {
+    const long long total = (long long)G * taps * M * N;
+    const long long slab = (long long)G * taps * Mpad * Npad;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int n = idx % N;
+        long long r = idx / N;
+        const int m = r % M; r /= M;
+        const int tap = r % taps;
+        const int g = r / taps;
+        const int ci = kmap ? kmap[n] : n;
+        if (ci < 0) continue;
+        const float* p = slabs + (((long long)g * taps + tap) * Mpad + m) * Npad + n;
+        float s = 0.f;
+        for (int i = 0; i < nsplit; ++i) s += p[i * slab];
+        float* o = dw + (((long long)g * M + m) * Cin + ci) * taps + tap;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+__global__ void reduce_plain_kernel(const float* slabs, int nsplit, int G, int M, int N, int Mpad, int Npad, float scale,
+                                    float* out) {
+    const long long total = (long long)G * M * N;
+    const long long slab = (long long)G * Mpad * Npad;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int n = idx % N;
+        long long r = idx / N;
+        const int m = r % M;
+        const int g = r / M;
+        const float* p = slabs + ((long long)g * Mpad + m) * Npad + n;
+        float s = 0.f;
+        for (int i = 0; i < nsplit; ++i) s += p[i * slab];
+        out[idx] = s * scale;
+    }
+}
+
+}  // namespace
+
+extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
+    BMC_CHECK_ARG(h != nullptr, "bmc_pgemm: null args");
+    BMC_CHECK_ARG(h->nsrc >= 1 && h->nsrc <= BMC_MAX_SRC, "bmc_pgemm: nsrc=%d out of range", h->nsrc);
+    BMC_CHECK_ARG(h->taps == 1 || h->taps == 9, "bmc_pgemm: taps must be 1 or 9");
+    BMC_CHECK_ARG(h->batch_per_group >= 1 && h->B % h->batch_per_group == 0, "bmc_pgemm: B %% batch_per_group != 0");
+    BMC_CHECK_ARG(h->nsplit >= 1 && h->slabs, "bmc_pgemm: nsplit/slabs");
+    BMC_CHECK_ARG(h->a.ptr && h->a.nch > 0 && h->a.nch % 4 == 0 && h->a.pix_stride % 4 == 0, "bmc_pgemm: bad A operand");
+    PgemmK k;
+    k.a = to_dev(h->a);
+    k.nsrc = h->nsrc;
+    int N = 0;
+    for (int i = 0; i < BMC_MAX_SRC; ++i) {
+        if (i < h->nsrc) {
+            BMC_CHECK_ARG(h->src[i].ptr && h->src[i].nch > 0 && h->src[i].nch % 4 == 0 && h->src[i].pix_stride % 4 == 0,
+                          "bmc_pgemm: bad source %d", i);
+            k.src[i] = to_dev(h->src[i]);
+            N += h->src[i].nch;
+        } else k.src[i] = to_dev(h->src[0]);
+    }
+    k.B = h->B; k.H = h->H; k.W = h->W; k.batch_per_group = h->batch_per_group;
+    k.slabs = h->slabs; k.nsplit = h->nsplit;
+    k.M = h->a.nch; k.Mpad = bmc_round_up(k.M, 32); k.N = N; k.Npad = bmc_round_up(N, 32);
+    k.G = h->B / h->batch_per_group;
+    k.n_mblk = (k.Mpad + 127) / 128;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->taps == 9) {
+        k.n_nblk = k.Npad / 32;
+        k.tiles_x = (h->W + PT_W - 1) / PT_W; k.tiles_y = (h->H + PT_H - 1) / PT_H;
+        k.tiles_per_img = k.tiles_x * k.tiles_y;
+        dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * k.nsplit));
+        hipLaunchKernelGGL((pgemm_kernel<9, 1>), grid, dim3(256), 0, st, k);
+    } else {
+        k.n_nblk = (k.Npad + 127) / 128;
+        k.tiles_x = k.tiles_y = 0;
+        k.tiles_per_img = (h->H * h->W + PT - 1) / PT;
+        dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * k.nsplit));
+        hipLaunchKernelGGL((pgemm_kernel<1, 4>), grid, dim3(256), 0, st, k);
+    }
+    BMC_CHECK_LAUNCH("bmc_pgemm");
+    return 0;
+}
+
+extern "C" int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, int taps, int M, int N, const int* kmap,
+                                       int Cin, float* dw, int accumulate, bmc_stream_t stream) {
+    BMC_CHECK_ARG(slabs && dw && nsplit >= 1, "bmc_pgemm_reduce_weight: bad args");
+    const long long total = (long long)G * taps * M * N;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(reduce_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, taps, M, N,
+                       bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, dw, accumulate);
+    BMC_CHECK_LAUNCH("bmc_pgemm_reduce_weight");
+    return 0;
+}
+
+extern "C" int bmc_pgemm_reduce_plain(const float* slabs, int nsplit, int G, int M, int N, float scale, float* out,
+                                      bmc_stream_t stream) {
+    BMC_CHECK_ARG(slabs && out && nsplit >= 1, "bmc_pgemm_reduce_plain: bad args");
+    const long long total = (long long)G * M * N;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(reduce_plain_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, M, N,
+                       bmc_round_up(M, 32), bmc_round_up(N, 32), scale, out);
+    BMC_CHECK_LAUNCH("bmc_pgemm_reduce_plain");
+    return 0;
+}

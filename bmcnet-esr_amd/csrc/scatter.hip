@@ -1,0 +1,46 @@
+// Event -> two-channel count image (dataloader/encodings.py:241-269, 290-305), many frames per launch.
+// Integer bin indices, +p*p contributions (exact integers for p = +-1) accumulated with
+// global_atomic_add_f32: the sum is order independent below 2^24, hence bit-exact.
+#include "bmc_common.h"
+
+namespace {
+
+__global__ void events_kernel(float* __restrict__ xs, float* __restrict__ ys, const float* __restrict__ ps,
+                              const long long* __restrict__ offsets, int H, int W, float* __restrict__ out, int mutate) {
+    const int f = blockIdx.y;
+    const long long e0 = offsets[f], e1 = offsets[f + 1];
+    float* const img = out + (long long)f * 2 * H * W;
+    for (long long e = e0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += (long long)gridDim.x * blockDim.x) {
+        float x = xs[e], y = ys[e];
+        const float p = ps[e];
+        // first events_to_image() call (positive channel): out-of-range events are zeroed IN PLACE
+        // (encodings.py:249-254) -- weight dropped, coordinates reset to (0, 0)
+        const bool oob = (x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f);
+        if (oob) {
+            x = 0.f; y = 0.f;
+            if (mutate) { xs[e] = 0.f; ys[e] = 0.f; }
+        }
+        const int xi = (int)x;            // .long(): truncation (encodings.py:260-263)
+        const int yi = H - (int)y - 1;    // vertical flip (encodings.py:265)
+        const float wpos = (!oob && p > 0.f) ? p * p : 0.f;  // ps * mask_pos, mask_pos = p where p >= 0
+        // second call (negative channel) sees the already-reset coordinates: nothing is masked any more,
+        // so a formerly out-of-range negative event counts at [H-1, 0]
+        const float wneg = p < 0.f ? p * p : 0.f;
+        if (wpos != 0.f) atomicAdd(img + (long long)yi * W + xi, wpos);
+        if (wneg != 0.f) atomicAdd(img + (long long)H * W + (long long)yi * W + xi, wneg);
+    }
+}
+
+}  // namespace
+
+extern "C" int bmc_events_to_channels(float* xs, float* ys, const float* ps, const long long* offsets, int nframes, int H,
+                                      int W, float* out, int mutate, bmc_stream_t s) {
+    BMC_CHECK_ARG(nframes >= 0 && H > 0 && W > 0 && out, "bmc_events_to_channels: bad shape");
+    hipStream_t st = (hipStream_t)s;
+    if (nframes == 0) return 0;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)nframes * 2 * H * W * sizeof(float), st);
+    if (e != hipSuccess) { bmc_set_error("bmc_events_to_channels: memset failed: %s", hipGetErrorString(e)); return -2; }
+    hipLaunchKernelGGL(events_kernel, dim3(64, nframes), dim3(256), 0, st, xs, ys, ps, offsets, H, W, out, mutate);
+    BMC_CHECK_LAUNCH("bmc_events_to_channels");
+    return 0;
+}

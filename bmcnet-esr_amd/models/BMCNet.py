@@ -1,0 +1,143 @@
+"""BMCNet on MI355X: same class names, constructor/forward signatures and
+state_dict keys as the reference (models/BMCNet.py), executed by the gfx950
+kernels of libbmc_hip.so.
+
+Execution differs from the reference on purpose (results do not):
+  * activations are NHWC fp32; no torch.cat ever materialises -- convolutions
+    read up to six channel-slices directly;
+  * the polarity twins that share weights (p / n branches, conv1 == conv2,
+    convf1 == convf2, the two lBIE calls) run as ONE launch over a doubled
+    batch; the three conv_fs calls run as one launch over a tripled batch;
+  * ReLU, bias and residual adds live in convolution epilogues.
+"""
+from .submodules import *  # noqa: F401,F403  (same star-import surface as the reference)
+from .submodules import BIE, PixelUnShuffle, ResidualBlock_noBN, initialize_weights, to_nchw, to_nhwc
+from bmc_hip import ops
+from bmc_hip.ops import ConvSpec, View
+
+
+class ParallelBlk(nn.Module):
+    """reference: models/BMCNet.py:3-32."""
+
+    def __init__(self, nf=64):
+        super().__init__()
+        self.conv1 = ResidualBlock_noBN(nf)
+        self.conv2 = self.conv1
+        self.conv1_st = ResidualBlock_noBN(nf)
+        self.conv2_st = self.conv1_st
+        self.lBIE = BIE(nf)   # local BIE
+        self.gBIE = BIE(nf)   # global BIE
+        initialize_weights([self.conv1, self.conv2, self.conv1_st, self.conv2_st], 0.1)
+
+    def forward_nhwc(self, x12, xs, xst12, xsst12):
+        """x12 = [x_1; x_2], xst12 = [x_1_st; x_2_st], xsst12 = [x_1_s_st; x_2_s_st] (batch-stacked twins)."""
+        x12 = self.conv1.forward_nhwc(x12)
+        xst12 = self.conv1_st.forward_nhwc(xst12)
+        x12, xst12, xsst12 = self.lBIE.forward_pair(x12, xst12, xsst12)
+        x12, xs = self.gBIE.forward_twin(x12, xs)
+        return x12, xs, xst12, xsst12
+
+    def forward(self, x_1, x_2, x_s, x_1_st, x_2_st, x_1_s_st, x_2_s_st):
+        B = x_1.shape[0]
+        st = lambda a, b: torch.cat([to_nhwc(a), to_nhwc(b)], 0)
+        x12, xs, xst12, xsst12 = self.forward_nhwc(st(x_1, x_2), to_nhwc(x_s), st(x_1_st, x_2_st),
+                                                   st(x_1_s_st, x_2_s_st))
+        n = to_nchw
+        return n(x12[:B]), n(x12[B:]), n(xs), n(xst12[:B]), n(xst12[B:]), n(xsst12[:B]), n(xsst12[B:])
+
+
+class Backbone(nn.Module):
+    """reference: models/BMCNet.py:35-84."""
+
+    def __init__(self, n_c, n_b, scale, repeat):
+        super().__init__()
+        pad = (1, 1)
+        s2 = scale ** 2
+        if s2 % 16 or n_c % 16 or 2 * repeat > 16:
+            raise NotImplementedError("bmc_hip BMCNet needs scale^2 and n_c to be multiples of 16 and repeat <= 8 "
+                                      "(scale=%d, n_c=%d, repeat=%d)" % (scale, n_c, repeat))
+        self.conv_fpst = nn.Conv2d(s2 + n_c + 2 * repeat, n_c, 3, 1, padding=pad)
+        self.conv_fnst = self.conv_fpst
+        self.conv_fps = nn.Conv2d(repeat + n_c, n_c, 3, 1, padding=pad)
+        self.conv_fns = self.conv_fps
+        self.conv_fs = nn.Conv2d(s2 * 2 + n_c * 3, n_c, 3, 1, padding=pad)
+        self.para_reschunk = nn.ModuleList([ParallelBlk(n_c)] * n_b)
+        self.scale = scale
+        self.conv_hs = nn.Conv2d(n_c, n_c, 3, 1, padding=pad)
+        self.conv_hp = nn.Conv2d(n_c, n_c, 3, 1, padding=pad)
+        self.conv_hn = nn.Conv2d(n_c, n_c, 3, 1, padding=pad)
+        self.conv_o = nn.Conv2d(n_c * 2, s2 * 2, 3, 1, padding=pad)
+        initialize_weights([self.conv_fpst, self.conv_fnst, self.conv_fps, self.conv_fns, self.conv_fs, self.conv_hs,
+                            self.conv_hp, self.conv_hn, self.conv_o], 0.1)
+        r = repeat
+        pad16 = lambda used: list(used) + [-1] * (16 - len(used))
+        rng = lambda a, n: list(range(a, a + n))
+        # packed-K layouts (reference concat orders: models/BMCNet.py:60-73,78-82)
+        self._sp_fpst = ConvSpec([pad16(rng(0, 2 * r)), rng(2 * r, n_c), rng(2 * r + n_c, s2)])
+        self._sp_fps = ConvSpec([pad16([-1] * r + rng(0, r)), rng(r, n_c)])
+        self._sp_fs = ConvSpec([rng(0, n_c), rng(n_c, n_c), rng(2 * n_c, n_c), rng(3 * n_c, s2), rng(3 * n_c + s2, s2)])
+        self._sp_h = ConvSpec.dense(n_c)
+        self._sp_o = ConvSpec.dense(n_c, n_c)
+        self.n_c = n_c
+
+    def forward_nhwc(self, xin12, h3, o12):
+        """xin12 [2B,H,W,16]: packed polarity inputs (p batch-half, n batch-half);
+        h3 [3B,H,W,n_c] = [hp; hn; hs]; o12 [2B,H,W,s^2] = [o[:, :s^2]; o[:, s^2:]] (channel halves batch-stacked).
+        Returns x_h, x_h_p, x_h_n, x_o (NHWC)."""
+        B = o12.shape[0] // 2
+        hpn = h3[:2 * B]
+        st12 = ops.conv([View(xin12), View(hpn), View(o12)], self.conv_fpst.weight, self.conv_fpst.bias, self._sp_fpst,
+                        relu=True)                                         # [xp_st; xn_st]
+        s12 = ops.conv([View(xin12), View(hpn)], self.conv_fps.weight, self.conv_fps.bias, self._sp_fps,
+                       relu=True)                                          # [xp_s; xn_s]
+        # conv_fs on cat[xp_st, xn_st, h*, o] for h* = hp, hn, hs: one launch over 3B
+        fs3 = ops.conv([View(st12, b0=0, mod=B), View(st12, b0=B, mod=B), View(h3), View(o12, b0=0, mod=B),
+                        View(o12, b0=B, mod=B)], self.conv_fs.weight, self.conv_fs.bias, self._sp_fs, B=3 * B,
+                       relu=True)                                          # [xs_p_st; xs_n_st; xs]
+        sst12, xs = fs3[:2 * B], fs3[2 * B:]
+        for layer in self.para_reschunk:
+            s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12)
+        x_h = ops.conv([View(xs)], self.conv_hs.weight, self.conv_hs.bias, self._sp_h, relu=True)
+        hw = torch.stack([self.conv_hp.weight, self.conv_hn.weight])
+        hb = torch.stack([self.conv_hp.bias, self.conv_hn.bias])
+        x_hpn = ops.conv([View(sst12)], hw, hb, self._sp_h, relu=True, G=2, cache=False)
+        x_o = ops.conv([View(s12, b0=0), View(s12, b0=B)], self.conv_o.weight, self.conv_o.bias, self._sp_o, B=B)
+        return x_h, x_hpn[:B], x_hpn[B:], x_o
+
+    def forward(self, xs, hp, hn, hs, o):
+        """NCHW interface of the reference (xs = [x1p, x1n, x2p, x2n], 3 repeated channels each)."""
+        x1p, x1n, x2p, x2n = xs
+        B, r = x1p.shape[0], x1p.shape[1]
+        s2 = self.scale ** 2
+        z = lambda a, b: torch.cat([to_nhwc(a), to_nhwc(b), a.new_zeros(B, a.shape[2], a.shape[3], 16 - 2 * r)], 3)
+        xin12 = torch.cat([z(x1p, x2p), z(x1n, x2n)], 0).contiguous()
+        h3 = torch.cat([to_nhwc(hp), to_nhwc(hn), to_nhwc(hs)], 0)
+        on = to_nhwc(o)
+        o12 = torch.cat([on[..., :s2], on[..., s2:]], 0).contiguous()
+        return tuple(to_nchw(t) for t in self.forward_nhwc(xin12, h3, o12))
+
+
+class BMCNet(nn.Module):
+    """reference: models/BMCNet.py:87-121."""
+
+    def __init__(self, scale, n_c, n_b, repeat=3):
+        super().__init__()
+        self.neuro = Backbone(n_c, n_b, scale, repeat=repeat)
+        self.scale = scale
+        self.down = PixelUnShuffle(scale)
+        self.repeat = repeat
+
+    def forward(self, x, x_h, x_h_p, x_h_n, x_o, init):
+        """x [B,2,T>=2,H,W]; x_h/x_h_p/x_h_n [B,n_c,H,W]; x_o [B,2*s*s,H,W] if init else the previous HR
+        prediction [B,2,sH,sW]; returns (x_h, x_h_p, x_h_n, prediction [B,2,sH,sW])."""
+        B = x.shape[0]
+        s2 = self.scale ** 2
+        xin12 = ops.pack_inputs(x, self.repeat)
+        on = to_nhwc(x_o) if init else ops.pixel_unshuffle_nhwc(x_o, self.scale)
+        o12 = torch.cat([on[..., :s2], on[..., s2:]], 0)
+        # the reference passes (x_h, x_h_p, x_h_n) positionally into Backbone.forward(xs, hp, hn, hs, o)
+        # (models/BMCNet.py:115,118 vs :57): x_h acts as hp, x_h_p as hn, x_h_n as hs.
+        h3 = torch.cat([to_nhwc(x_h), to_nhwc(x_h_p), to_nhwc(x_h_n)], 0)
+        n_h, n_hp, n_hn, o = self.neuro.forward_nhwc(xin12, h3, o12)
+        pred = ops.head(o, x[:, :, 1], self.scale)
+        return to_nchw(n_h), to_nchw(n_hp), to_nchw(n_hn), pred

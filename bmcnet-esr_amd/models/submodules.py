@@ -1,0 +1,176 @@
+"""MI355X-native building blocks with the reference's module names, constructor
+signatures and state_dict keys (reference: models/submodules.py).
+
+Parameters live in ordinary nn.Conv2d containers (so checkpoints of the
+reference load strictly, including the alias keys of shared modules), but every
+forward runs the hand-written gfx950 kernels of libbmc_hip.so through
+bmc_hip.ops on NHWC tensors.  The public ``forward`` methods keep the
+reference's NCHW interface; ``forward_nhwc`` is the internal fast path the
+models use.  There is no CPU path: CPU tensors raise.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from bmc_hip import ops
+from bmc_hip.ops import ConvSpec, View
+
+
+def to_nhwc(x):
+    """[B,C,H,W] -> contiguous [B,H,W,C]; free when x is already channels-last strided."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def to_nchw(x):
+    """[B,H,W,C] -> [B,C,H,W] view (channels-last strides, no copy)."""
+    return x.permute(0, 3, 1, 2)
+
+
+def _check_nf(nf):
+    if nf % 16:
+        raise NotImplementedError("bmc_hip kernels need channel counts that are multiples of 16 (got %d)" % nf)
+
+
+def make_layer(block, n_layers):
+    return nn.Sequential(*[block() for _ in range(n_layers)])
+
+
+class ResidualBlock_noBN(nn.Module):
+    """x + conv2(relu(conv1(x))), 3x3 (reference: models/submodules.py:17-35).
+    ReLU and the residual add are fused into the convolution epilogues."""
+
+    def __init__(self, nf=64):
+        super().__init__()
+        _check_nf(nf)
+        self.conv1 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.conv2 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        initialize_weights([self.conv1, self.conv2], 0.1)
+        self._spec = ConvSpec.dense(nf)
+
+    def forward_nhwc(self, x):
+        t = ops.conv([View(x)], self.conv1.weight, self.conv1.bias, self._spec, relu=True)
+        return ops.conv([View(t)], self.conv2.weight, self.conv2.bias, self._spec, residual=View(x))
+
+    def forward(self, x):
+        return to_nchw(self.forward_nhwc(to_nhwc(x)))
+
+
+class LayerNorm2d(nn.Module):
+    """Per-pixel LayerNorm over channels (reference: models/submodules.py:127-166)."""
+
+    def __init__(self, channels, eps=1e-6):
+        super().__init__()
+        self.register_parameter('weight', nn.Parameter(torch.ones(channels)))
+        self.register_parameter('bias', nn.Parameter(torch.zeros(channels)))
+        self.eps = eps
+
+    def forward_nhwc(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+    def forward(self, x):
+        return to_nchw(self.forward_nhwc(to_nhwc(x)))
+
+
+class BIE(nn.Module):
+    """Bilateral information exchange (reference: models/submodules.py:38-77).
+
+    Two execution shapes:
+      * forward_pair(first, second, xs): the three operands are separate tensors of equal batch;
+      * forward_twin(x12, xs): `first`/`second` are the two batch halves of one tensor -- every
+        weight-shared twin call (conv1/conv2, convf1/convf2) becomes ONE launch over the doubled batch,
+        v1/v2 run as a 2-group launch, and the crossed outputs are written by a residual read with a
+        batch rotation."""
+
+    def __init__(self, nf=64):
+        super().__init__()
+        _check_nf(nf)
+        self.conv1 = ResidualBlock_noBN(nf)
+        self.conv2 = self.conv1
+        self.convf1 = nn.Conv2d(nf * 2, nf, 1, 1, padding=0)
+        self.convf2 = self.convf1
+        self.scale = nf ** -0.5
+        self.norm_s = LayerNorm2d(nf)
+        self.clustering = nn.Conv2d(nf, nf, 1, 1, padding=0)
+        self.unclustering = nn.Conv2d(nf * 2, nf, 1, stride=1, padding=0)
+        self.v1 = nn.Conv2d(nf, nf, 1, stride=1, padding=0)
+        self.v2 = nn.Conv2d(nf, nf, 1, stride=1, padding=0)
+        initialize_weights([self.convf1, self.convf2, self.clustering, self.unclustering, self.v1, self.v2], 0.1)
+        self.nf = nf
+        self._s1 = ConvSpec.dense(nf)
+        self._s2 = ConvSpec.dense(nf, nf)
+
+    def _centre(self, views, B):
+        z = ops.conv(views, self.convf1.weight, self.convf1.bias, self._s2, B=B)
+        z = self.norm_s.forward_nhwc(z)
+        return ops.conv([View(z)], self.clustering.weight, self.clustering.bias, self._s1)
+
+    def forward_pair(self, first, second, xs):
+        B = first.shape[0]
+        r1 = self.conv1.forward_nhwc(first)
+        r2 = self.conv1.forward_nhwc(second)
+        c1 = self._centre([View(xs), View(second)], B)
+        c2 = self._centre([View(xs), View(first)], B)
+        v1 = ops.conv([View(first)], self.v1.weight, self.v1.bias, self._s1)
+        v2 = ops.conv([View(second)], self.v2.weight, self.v2.bias, self._s1)
+        p1 = ops.softmax_rows(ops.gram(c1, v1, self.scale))
+        p2 = ops.softmax_rows(ops.gram(c2, v2, self.scale))
+        o1 = ops.attn_apply(p1, v1, residual=View(r2))
+        o2 = ops.attn_apply(p2, v2, residual=View(r1))
+        xs_new = ops.conv([View(c1), View(c2)], self.unclustering.weight, self.unclustering.bias, self._s2,
+                          residual=View(xs))
+        return o1, o2, xs_new
+
+    def forward_twin(self, x12, xs):
+        B2 = x12.shape[0]
+        B = B2 // 2
+        r12 = self.conv1.forward_nhwc(x12)                                          # [r1; r2]
+        c12 = self._centre([View(xs, mod=B), View(x12, shift=B, mod=B2)], B2)       # [c1; c2]
+        vw = torch.stack([self.v1.weight, self.v2.weight])
+        vb = torch.stack([self.v1.bias, self.v2.bias])
+        v12 = ops.conv([View(x12)], vw, vb, self._s1, G=2, cache=False)             # [v1(first); v2(second)]
+        p12 = ops.softmax_rows(ops.gram(c12, v12, self.scale))
+        o12 = ops.attn_apply(p12, v12, residual=View(r12, shift=B, mod=B2))         # [o1 + r2; o2 + r1]
+        xs_new = ops.conv([View(c12, b0=0), View(c12, b0=B)], self.unclustering.weight, self.unclustering.bias,
+                          self._s2, B=B, residual=View(xs))
+        return o12, xs_new
+
+    def forward(self, x_1, x_2, x_s):
+        B = x_1.shape[0]
+        o12, xs_new = self.forward_twin(torch.cat([to_nhwc(x_1), to_nhwc(x_2)], 0), to_nhwc(x_s))
+        return to_nchw(o12[:B]), to_nchw(o12[B:]), to_nchw(xs_new)
+
+
+def pixel_unshuffle(input, upscale_factor):
+    """[B,C,rH,rW] -> [B,C*r*r,H,W] (reference: models/submodules.py:80-92); returned as a channels-last view."""
+    return to_nchw(ops.pixel_unshuffle_nhwc(input, upscale_factor))
+
+
+class PixelUnShuffle(nn.Module):
+    def __init__(self, upscale_factor):
+        super().__init__()
+        self.upscale_factor = upscale_factor
+
+    def forward(self, input):
+        return pixel_unshuffle(input, self.upscale_factor)
+
+    def extra_repr(self):
+        return 'upscale_factor={}'.format(self.upscale_factor)
+
+
+def initialize_weights(net_l, scale=0.1):
+    """Kaiming-normal (fan_in) x scale for conv/linear weights, zero biases, BN affine = (1, 0)
+    (reference: models/submodules.py:107-124)."""
+    if not isinstance(net_l, list):
+        net_l = [net_l]
+    for net in net_l:
+        for m in net.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                init.kaiming_normal_(m.weight, a=0, mode='fan_in')
+                m.weight.data *= scale
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, nn.BatchNorm2d):
+                init.constant_(m.weight, 1)
+                init.constant_(m.bias.data, 0.0)

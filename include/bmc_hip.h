@@ -1,0 +1,165 @@
+/*
+ * bmc_hip.h -- C ABI of libbmc_hip.so, the MI355X (gfx950) kernel library behind
+ * the BMCNet bilateral event-SR hot path.
+ *
+ * The reference (Lqm26/BMCNet-ESR) has no FFI: its hot path is a chain of ATen
+ * calls issued from Python.  Each entry point below replaces the
+ * ATen call sites cited next to it; the Python host side
+ * (bmcnet-esr_amd/bmc_hip) binds them with ctypes and wraps fwd/bwd pairs in
+ * torch.autograd.Function objects behind the reference's own nn.Module
+ * signatures.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every pointer is DEVICE memory unless a
+ *    parameter is documented as a host struct;
+ *  - activations are fp32 NHWC: element (b,y,x,c) of a tensor lives at
+ *    ptr[b*batch_stride + (y*W + x)*pix_stride + c];
+ *  - nothing allocates: workspaces are passed in;
+ *  - every launch goes to the hipStream_t given (pass torch's current stream);
+ *  - return 0 on success, <0 on error (bmc_last_error() has the text).
+ */
+#ifndef BMC_HIP_H
+#define BMC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bmc_stream_t; /* hipStream_t */
+
+#define BMC_MAX_SRC 6
+#define BMC_CK 16 /* channel granule: every source's nch is a multiple of 16 */
+
+/* A channel-slice of an NHWC tensor used as one operand of a multi-source
+ * convolution (what the reference builds with torch.cat, models/BMCNet.py:60-73,
+ * models/submodules.py:63-64,75).  Batch index b of the launch reads batch
+ * (b + batch_shift) % batch_mod of this tensor (shared / swapped operands of the
+ * weight-shared twin branches). */
+typedef struct bmc_src {
+    const float* ptr;
+    long long batch_stride; /* floats */
+    int pix_stride;         /* floats */
+    int nch;                /* channels consumed from ptr, multiple of 16 */
+    int batch_shift;
+    int batch_mod;          /* >= 1 */
+} bmc_src_t;
+
+/* ---- library ---- */
+int bmc_version(void);
+const char* bmc_last_error(void);
+
+/* ---- event -> count image: dataloader/encodings.py:241-269,290-305 -------
+ * events_to_channels() for `nframes` frames in one launch.  Frame f owns events
+ * [offsets[f], offsets[f+1]) of xs/ys/ps (fp32, as event_formatting() leaves
+ * them, dataloader/base_dataset.py:24-31) and writes out[f] = [2,H,W] fp32
+ * (zero-filled here).  Bit-exact with the reference including its quirk: an
+ * out-of-range event is dropped from channel 0, but its x,y are reset to 0 in
+ * place so a NEGATIVE one lands on [H-1,0] of channel 1.  If mutate != 0 xs/ys
+ * are updated in place as the reference does to its caller's tensors. */
+int bmc_events_to_channels(float* xs, float* ys, const float* ps, const long long* offsets,
+                           int nframes, int H, int W, float* out, int mutate, bmc_stream_t s);
+
+/* ---- weight packing ------------------------------------------------------
+ * Conv weights [G][Cout][Cin][taps] (taps = kh*kw = 1 or 9; nn.Conv2d layout)
+ * -> MFMA staging layout [G][Kpad/16][taps][Coutpad][16] where packed input
+ * channel k holds reference input channel kmap[k] (or zero when kmap[k] < 0).
+ * transpose != 0 builds the data-gradient operator instead: output channels =
+ * packed k (Kpad rounded up to Coutpad_t), reduction over Cout, taps mirrored. */
+int bmc_pack_weight(const float* w, const int* kmap, int G, int Cout, int Cin, int taps,
+                    int Kpad, int Coutpad, float* out, bmc_stream_t s);
+int bmc_pack_weight_t(const float* w, const int* kmap, int G, int Cout, int Cin, int taps,
+                      int k0, int nk, int nkpad, int Coutpad16, float* out, bmc_stream_t s);
+
+/* ---- implicit-GEMM convolution (fp32 MFMA) -------------------------------
+ * Replaces F.conv2d at models/submodules.py:25-26,33-34,44-53,63-67,75 and
+ * models/BMCNet.py:40-53,64-82 together with the torch.cat / relu / residual
+ * add around them, and torch.bmm(softmax, v) at models/submodules.py:72-73
+ * (a 1x1 convolution with per-sample weights).  Also the data gradient of all
+ * of these (same kernel, transposed weights).
+ *   out[b,y,x,co] = epi( sum_{tap,k} W[g][k][tap][co] * cat(src)[b, y+dy, x+dx, k] + bias[g][co] )
+ *   epi(v) = relu? max(v,0) : v, after adding residual[b,y,x,co] if given;
+ *   g = b / batch_per_group. */
+typedef struct bmc_conv_args {
+    int nsrc;
+    bmc_src_t src[BMC_MAX_SRC];
+    const float* wpacked;       /* from bmc_pack_weight */
+    const float* bias;          /* [G][Cout] or NULL */
+    long long w_group_stride;   /* floats between groups in wpacked */
+    int bias_group_stride;
+    int batch_per_group;        /* >= 1 */
+    float* out;
+    long long out_batch_stride;
+    int out_pix_stride;
+    int B, H, W;
+    int Cout, Coutpad;          /* Coutpad: multiple of 32 (of 128 when > 32) */
+    int taps;                   /* 1 or 9 */
+    int relu;
+    bmc_src_t residual;         /* ptr NULL -> none; nch ignored */
+    bmc_src_t mask;             /* ptr NULL -> none; out = mask > 0 ? v : 0 (ReLU backward) */
+    int accumulate;             /* out += v */
+} bmc_conv_args_t;
+int bmc_conv(const bmc_conv_args_t* host_args, bmc_stream_t s);
+
+/* ---- pixel-reduction GEMM: weight gradients and channel Gram matrices ----
+ *   C[g][tap][m][n] = sum_{b in group g} sum_{y,x} A[b,y,x,m] * cat(src)[b,y+dy,x+dx,n]
+ * Replaces the weight-gradient half of conv backward (ATen autograd) and
+ * torch.bmm(center, v) at models/submodules.py:69-70 (+ its backward).
+ * Split over pixels: partial sums go to `slabs`
+ * [nsplit][G][taps][Mpad][Npad] (Mpad/Npad = M/N rounded up to 32), which one of
+ * the reduce calls below then sums (deterministic order). */
+typedef struct bmc_pgemm_args {
+    bmc_src_t a;                /* nch = M */
+    int nsrc;
+    bmc_src_t src[BMC_MAX_SRC]; /* sum nch = N */
+    int B, H, W, taps;
+    int batch_per_group;
+    float* slabs;
+    int nsplit;
+} bmc_pgemm_args_t;
+int bmc_pgemm(const bmc_pgemm_args_t* host_args, bmc_stream_t s);
+/* slabs -> dW[Cout][Cin][taps] (nn.Conv2d layout) through kmap; beta 0/1 = overwrite/accumulate */
+int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, int taps, int M, int N, const int* kmap,
+                            int Cin, float* dw, int accumulate, bmc_stream_t s);
+/* slabs -> out[G][M][N] * scale */
+int bmc_pgemm_reduce_plain(const float* slabs, int nsplit, int G, int M, int N, float scale,
+                           float* out, bmc_stream_t s);
+
+/* ---- streaming kernels ---------------------------------------------------*/
+/* column sums over pixels (bias gradients): out[c] (+)= sum_p x[p*pix_stride + c]; ws >= 2048*C floats */
+int bmc_colsum(const float* x, long long npix, int pix_stride, int C, float* ws, float* out,
+               int accumulate, bmc_stream_t s);
+/* ReLU backward: g = y > 0 ? dy : 0 (F.relu at models/BMCNet.py:64-80, submodules.py:33) */
+int bmc_relu_bwd(const float* dy, const float* y, float* g, long long n, bmc_stream_t s);
+/* LayerNorm2d over channels per pixel: models/submodules.py:127-140 (fwd), :141-154 (bwd).
+ * stats = [npix][2] (mean, rstd).  bwd: gx, and dgamma/dbeta (+)= via ws (>= 2*1024*C floats). */
+int bmc_layernorm_fwd(const float* x, const float* gamma, const float* beta, long long npix, int C,
+                      float eps, float* y, float* stats, bmc_stream_t s);
+int bmc_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
+                      long long npix, int C, float* dx, float* ws, float* dgamma, float* dbeta,
+                      int accumulate, bmc_stream_t s);
+/* row softmax of [rows][C] (torch.softmax(att, -1), models/submodules.py:72-73) and its backward
+ * dA = P * (dP - rowsum(dP*P)) * scale_out */
+int bmc_softmax_fwd(const float* a, long long rows, int C, float* p, bmc_stream_t s);
+int bmc_softmax_bwd(const float* p, const float* dp, long long rows, int C, float scale_out,
+                    float* da, bmc_stream_t s);
+
+/* ---- head / tail of a recurrent window -----------------------------------
+ * bmc_pack_inputs: models/BMCNet.py:106-112 -- polarity split + x3 repeat of the
+ * two frames into two NHWC tensors of 16 channels each
+ * [f1,f1,f1,f2,f2,f2,0...] (p: polarity 0, n: polarity 1).  x is [B,2,T,H,W]
+ * with arbitrary element strides (sb,sc,st,sy,sx). */
+int bmc_pack_inputs(const float* x, long long sb, long long sc, long long st, long long sy, long long sx,
+                    int B, int H, int W, int repeat, float* xin_p, float* xin_n, bmc_stream_t s);
+/* HR NCHW [B,C,rH,rW] -> LR NHWC [B,H,W,C*r*r] (pixel_unshuffle, models/submodules.py:80-92;
+ * also the backward of the head).  */
+int bmc_unshuffle_to_nhwc(const float* hr, int B, int C, int H, int W, int r, float* lr, bmc_stream_t s);
+/* LR NHWC [B,H,W,C*r*r] -> HR NCHW [B,C,rH,rW] (+ bilinear x r of base[B,C,H,W] given with strides
+ * (sb,sc,sy,sx), align_corners=False) -- F.pixel_shuffle + F.interpolate + add, models/BMCNet.py:119;
+ * base NULL -> pure shuffle (backward of pixel_unshuffle). */
+int bmc_shuffle_to_hr(const float* lr, int B, int C, int H, int W, int r, const float* base,
+                      long long sb, long long sc, long long sy, long long sx, float* hr, bmc_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMC_HIP_H */

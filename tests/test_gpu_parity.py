@@ -1,0 +1,278 @@
+"""GPU parity tests (-m gpu): the HIP path (through the C ABI of libbmc_hip.so) against the CPU oracle on the
+same seeded inputs and against the committed golden vectors generated from the reference.
+
+Tolerances (fp32 everywhere; the MFMA f32 path is an exact fp32 fma chain, only summation order differs):
+  * event scatter: bit-exact;
+  * single kernels / layers: rel-L2 <= 2e-5;
+  * SR tensor of the full recurrent model: rel-L2 <= 1e-4 (the bar BASELINE.json states);
+  * parameter gradients of the full BPTT: rel-L2 <= 1e-3.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, np.float64)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+# ------------------------------------------------------------------ events
+@pytest.mark.parametrize("tag", ["tiny", "nfs_lr", "oob_float", "empty", "hot", "c2_lr"])
+def test_events_bit_exact(tag):
+    dev = _gpu()
+    from dataloader.encodings import events_to_channels
+    z = load("events.npz")
+    xs, ys, ps = (torch.tensor(z[f"{tag}/{k}"], device=dev) for k in ("xs", "ys", "ps"))
+    H, W = (int(v) for v in z[f"{tag}/size"])
+    img = events_to_channels(xs, ys, ps, (H, W))
+    assert np.array_equal(img.cpu().numpy(), z[f"{tag}/img"])
+    assert np.array_equal(xs.cpu().numpy(), z[f"{tag}/xs_after"])      # caller's tensors reset in place
+    assert np.array_equal(ys.cpu().numpy(), z[f"{tag}/ys_after"])
+
+
+def test_events_batched_vs_oracle_full_size():
+    """C2-size frames (LR 24 576 events, HR 393 216 events) in one batched launch vs the numpy oracle."""
+    dev = _gpu()
+    from dataloader.encodings import events_to_channels_batch
+    from oracle.bmc_oracle import events_to_channels_np
+    rng = np.random.default_rng(0)
+    H, W = 720, 960
+    ns = [393216, 0, 100000]
+    xs = np.concatenate([rng.uniform(-2, W + 2, n) for n in ns]).astype(np.float32)
+    ys = np.concatenate([rng.uniform(-2, H + 2, n) for n in ns]).astype(np.float32)
+    ps = np.concatenate([rng.choice([-1.0, 1.0], n) for n in ns]).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    out = events_to_channels_batch(torch.tensor(xs, device=dev), torch.tensor(ys, device=dev),
+                                   torch.tensor(ps, device=dev), torch.tensor(off, device=dev), (H, W)).cpu().numpy()
+    for f in range(3):
+        ref, _, _ = events_to_channels_np(xs[off[f]:off[f + 1]], ys[off[f]:off[f + 1]], ps[off[f]:off[f + 1]], (H, W))
+        assert np.array_equal(out[f], ref)
+    # size-independent property: total count = in-range events + out-of-range negative events
+    oob = (xs >= W) | (xs < 0) | (ys >= H) | (ys < 0)
+    assert out.sum() == float(np.sum(~oob | (ps < 0)))
+
+
+# ------------------------------------------------------------------ conv kernel vs F.conv2d
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,cins,cout,k,relu,res", [
+    (2, 9, 7, [16], 16, 3, False, False),
+    (1, 8, 16, [128], 128, 3, True, False),
+    (2, 13, 21, [16, 32, 16], 128, 3, True, False),
+    (3, 17, 33, [32], 32, 3, False, True),
+    (2, 10, 12, [128, 128], 128, 1, False, True),
+    (1, 20, 35, [48], 16, 1, True, False),
+    (1, 11, 18, [16, 128, 16, 16, 32], 128, 3, True, False),
+    (2, 5, 40, [256], 256, 3, False, False),
+])
+def test_conv_fwd_bwd_vs_torch(B, H, W, cins, cout, k, relu, res):
+    dev = _gpu()
+    from bmc_hip import ops
+    from bmc_hip.ops import ConvSpec, View
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(B, cout, H, W, generator=g) if res else None
+    go = torch.randn(B, cout, H, W, generator=g)
+    # oracle (CPU)
+    xs_c = [x.clone().requires_grad_() for x in xs]
+    w_c, b_c = w.clone().requires_grad_(), b.clone().requires_grad_()
+    r_c = r.clone().requires_grad_() if res else None
+    y = F.conv2d(torch.cat(xs_c, 1), w_c, b_c, padding=k // 2)
+    if res:
+        y = y + r_c
+    if relu:
+        y = torch.relu(y)
+    y.backward(go)
+    # HIP
+    xs_g = [_nhwc(x).to(dev).requires_grad_() for x in xs]
+    w_g, b_g = w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    r_g = _nhwc(r).to(dev).requires_grad_() if res else None
+    yg = ops.conv([View(x) for x in xs_g], w_g, b_g, ConvSpec.dense(*cins), relu=relu,
+                  residual=View(r_g) if res else None)
+    yg.backward(_nhwc(go).to(dev))
+    assert rel_l2(yg.permute(0, 3, 1, 2), y) < 2e-5
+    for xg, xc in zip(xs_g, xs_c):
+        assert rel_l2(xg.grad.permute(0, 3, 1, 2), xc.grad) < 2e-5
+    assert rel_l2(w_g.grad, w_c.grad) < 2e-5
+    assert rel_l2(b_g.grad, b_c.grad) < 2e-5
+    if res:
+        assert rel_l2(r_g.grad.permute(0, 3, 1, 2), r_c.grad) < 2e-5
+
+
+def test_conv_batch_views_and_groups():
+    """Operands shared across / rotated over the doubled batch, two weight groups (the twin-branch launches)."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from bmc_hip.ops import ConvSpec, View
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cn = 2, 9, 11, 16
+    x12 = torch.randn(2 * B, Cn, H, W, generator=g)
+    xs = torch.randn(B, Cn, H, W, generator=g)
+    w = torch.randn(2, Cn, 2 * Cn, 1, 1, generator=g) / (2 * Cn) ** 0.5
+    go = torch.randn(2 * B, Cn, H, W, generator=g)
+    x12c, xsc, wc = x12.clone().requires_grad_(), xs.clone().requires_grad_(), w.clone().requires_grad_()
+    swapped = torch.cat([x12c[B:], x12c[:B]], 0)
+    inp = torch.cat([torch.cat([xsc, xsc], 0), swapped], 1)
+    y = torch.cat([F.conv2d(inp[:B], wc[0]), F.conv2d(inp[B:], wc[1])], 0)
+    y.backward(go)
+    x12g, xsg, wg = _nhwc(x12).to(dev).requires_grad_(), _nhwc(xs).to(dev).requires_grad_(), w.to(dev).requires_grad_()
+    yg = ops.conv([View(xsg, mod=B), View(x12g, shift=B, mod=2 * B)], wg, None, ConvSpec.dense(Cn, Cn), B=2 * B, G=2,
+                  cache=False)
+    yg.backward(_nhwc(go).to(dev))
+    assert rel_l2(yg.permute(0, 3, 1, 2), y) < 2e-5
+    assert rel_l2(x12g.grad.permute(0, 3, 1, 2), x12c.grad) < 2e-5
+    assert rel_l2(xsg.grad.permute(0, 3, 1, 2), xsc.grad) < 2e-5
+    assert rel_l2(wg.grad, wc.grad) < 2e-5
+
+
+# ------------------------------------------------------------------ layers vs golden (reference outputs)
+def _sub(z, pre):
+    class V:
+        files = [k[len(pre):] for k in z.files if k.startswith(pre)]
+        def __getitem__(self, k): return z[pre + k]
+    return V()
+
+
+def _load_sd(module, z, prefix="sd/"):
+    sd = {k[len(prefix):]: torch.tensor(z[k]) for k in z.files if k.startswith(prefix)}
+    module.load_state_dict(sd, strict=True)
+
+
+def _check_grads(module, z, tol):
+    named = dict(module.named_parameters())
+    n = 0
+    for k in z.files:
+        if k.startswith("grad/"):
+            assert rel_l2(named[k[5:]].grad, z[k]) < tol, k
+            n += 1
+    return n
+
+
+def test_resblock_golden():
+    dev = _gpu()
+    from models.submodules import ResidualBlock_noBN
+    z = _sub(load("layers.npz"), "res/")
+    m = ResidualBlock_noBN(16); _load_sd(m, z); m.to(dev)
+    x = torch.tensor(z["x"], device=dev, requires_grad=True)
+    y = m(x)
+    assert rel_l2(y, z["y"]) < 2e-5
+    y.backward(torch.tensor(z["go"], device=dev))
+    assert rel_l2(x.grad, z["gx"]) < 2e-5
+    assert _check_grads(m, z, 2e-5) == 4
+
+
+def test_layernorm_golden():
+    dev = _gpu()
+    from models.submodules import LayerNorm2d
+    z = _sub(load("layers.npz"), "ln/")
+    m = LayerNorm2d(16); _load_sd(m, z); m.to(dev)
+    x = torch.tensor(z["x"], device=dev, requires_grad=True)
+    y = m(x)
+    assert rel_l2(y, z["y"]) < 2e-5
+    y.backward(torch.tensor(z["go"], device=dev))
+    assert rel_l2(x.grad, z["gx"]) < 2e-5
+    assert _check_grads(m, z, 2e-5) == 2
+
+
+def test_bie_golden():
+    dev = _gpu()
+    from models.submodules import BIE
+    z = _sub(load("layers.npz"), "bie/")
+    m = BIE(16); _load_sd(m, z); m.to(dev)
+    xs = [torch.tensor(z[f"x{i}"], device=dev, requires_grad=True) for i in range(3)]
+    ys = m(*xs)
+    for i in range(3):
+        assert rel_l2(ys[i], z[f"y{i}"]) < 2e-5, i
+    torch.autograd.backward(ys, [torch.tensor(z[f"go{i}"], device=dev) for i in range(3)])
+    for i in range(3):
+        assert rel_l2(xs[i].grad, z[f"gx{i}"]) < 5e-5, i
+    assert _check_grads(m, z, 5e-5) >= 14
+
+
+def test_parallel_blk_golden():
+    dev = _gpu()
+    from models.BMCNet import ParallelBlk
+    z = _sub(load("layers.npz"), "pblk/")
+    m = ParallelBlk(16); _load_sd(m, z); m.to(dev)
+    xs = [torch.tensor(z[f"x{i}"], device=dev, requires_grad=True) for i in range(7)]
+    ys = m(*xs)
+    for i in range(7):
+        assert rel_l2(ys[i], z[f"y{i}"]) < 2e-5, i
+    torch.autograd.backward(ys, [torch.tensor(z[f"go{i}"], device=dev) for i in range(7)])
+    for i in range(7):
+        assert rel_l2(xs[i].grad, z[f"gx{i}"]) < 5e-5, i
+    assert _check_grads(m, z, 5e-5) >= 30
+
+
+def test_shuffle_head_golden():
+    dev = _gpu()
+    from models.submodules import pixel_unshuffle
+    from bmc_hip import ops
+    z = load("layers.npz")
+    y = pixel_unshuffle(torch.tensor(z["unshuffle/x"], device=dev), 4)
+    assert np.array_equal(y.cpu().numpy(), z["unshuffle/y"])
+    xo = torch.tensor(z["head/xo"], device=dev).permute(0, 2, 3, 1).contiguous()
+    pred = ops.head(xo, torch.tensor(z["head/f2"], device=dev), 4)
+    assert np.abs(pred.cpu().numpy() - z["head/y"]).max() < 1e-6
+
+
+# ------------------------------------------------------------------ full recurrent models (BPTT) vs golden
+@pytest.mark.parametrize("tag,plain", [("bmcnet_nc16", False), ("plain_nc16", True), ("bmcnet_nc32", False)])
+def test_full_model_bptt_golden(tag, plain):
+    dev = _gpu()
+    from models.BMCNet import BMCNet
+    from models.BMCNet_plain import BMCNet_plain
+    z = load(tag + ".npz")
+    scale, n_c, n_b, B, H, W, nwin = (int(v) for v in z["meta"])
+    m = (BMCNet_plain if plain else BMCNet)(scale, n_c, n_b)
+    _load_sd(m, z); m.to(dev)
+    frames = torch.tensor(z["frames"]); gts = torch.tensor(z["gts"])
+    zz = lambda c: torch.zeros(B, c, H, W, device=dev)
+    h, hp, hn, pred = zz(n_c), zz(n_c), zz(n_c), zz(2 * scale * scale)
+    loss = 0
+    for i in range(nwin):
+        x = frames[:, i:i + 2].transpose(1, 2).to(dev)          # as train.py:211,221
+        if plain:
+            h, pred = m(x, h, pred, i == 0)
+        else:
+            h, hp, hn, pred = m(x, h, hp, hn, pred, i == 0)
+        assert rel_l2(pred, z[f"pred{i}"]) < 1e-4, i
+        loss = loss + F.mse_loss(pred, gts[:, i + 1].to(dev))
+    assert rel_l2(h, z["h"]) < 1e-4
+    if not plain:
+        assert rel_l2(hp, z["hp"]) < 1e-4 and rel_l2(hn, z["hn"]) < 1e-4
+    assert abs(loss.item() - float(z["loss"])) < 1e-4 * abs(float(z["loss"]))
+    loss.backward()
+    assert _check_grads(m, z, 1e-3) >= 20
+
+
+def test_cpu_tensor_fails_loudly():
+    _gpu()
+    from models.submodules import ResidualBlock_noBN
+    m = ResidualBlock_noBN(16)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 16, 4, 4))
