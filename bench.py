@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- LR-voxel-frames/sec of the x4 SR BMCNet training step on synthetic NFS-shaped event data.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one sequence batch (train.py:202-237 semantics): event->count scatter
+of the batch's LR and HR frames, 8 recurrent BMCNet windows forward (state carried without detach), summed MSE,
+one backward through all windows, gradient all-reduce (N > 1), Adam(amsgrad) step.  Workload at every N:
+BASELINE.json configs[1] per GPU (BMCNet x4, 180x240 -> 720x960, bs=4/GPU, fp32, SEQL=9, SEQN=2) -> weak scaling;
+configs[2] (bs=32 over 8 GPUs) is exactly the N=8 point.  Inputs (events) are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "bmcnet-esr_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+import torch.distributed as dist
+
+# algorithmic work (measured on the reference with torch.utils.flop_counter, 2 FLOP/MAC)
+FLOP_PER_LRPX_FWD_BWD = 118_121_472      # BMCNet(4,128,5) one window forward+backward
+PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(budget_hw=(90, 120)):
+    """CPU oracle (the PyTorch-CPU restatement of the reference path, oracle/bmc_oracle.py) timed on this host:
+    one BMCNet window forward+backward, B=1, on a bounded sample (a quarter-size LR frame), converted to
+    180x240 frame-equivalents per second.  Reported only; never the thing optimised."""
+    from models.BMCNet import BMCNet
+    from oracle import bmc_oracle as O
+    import torch.nn.functional as F
+    torch.manual_seed(3407)
+    scale, n_c, n_b = 4, 128, 5
+    H, W = budget_hw
+    m = BMCNet(scale, n_c, n_b)
+    params, seen = {}, {}
+    for k, v in m.state_dict().items():
+        params[k] = seen.setdefault(v.data_ptr(), v.clone().requires_grad_())
+    x = torch.poisson(torch.full((1, 2, 2, H, W), 0.284))
+    gt = torch.poisson(torch.full((1, 2, scale * H, scale * W), 0.284))
+    z = lambda c: torch.zeros(1, c, H, W)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        _, _, _, pred = O.bmcnet_forward(params, x, z(n_c), z(n_c), z(n_c), z(32), True, scale)
+        loss = F.mse_loss(pred, gt)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        for p in seen.values():
+            p.grad = None
+    t = min(times[1:])
+    frames = (H * W) / (180.0 * 240.0)
+    return {"value": round(frames / t, 5), "unit": "LR-voxel-frames/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "oracle/bmc_oracle.py BMCNet(4,128,5) 1 window fwd+bwd, B=1, LR %dx%d (%.2f of a 180x240 frame), "
+                      "1 warm-up + 2 timed (best), %.2fs each, scaled by pixel count" % (H, W, frames, t)}
+
+
+def dominant_kernel_roofline(dev, B, H, W, n_c, iters=10):
+    """The kernel that carries ~73% of the step's FLOPs: 3x3 conv n_c->n_c over the doubled twin batch (2B).
+    Timed live with events on the stream the kernels are launched on (torch's current stream)."""
+    from bmc_hip import ops
+    from bmc_hip.ops import ConvSpec, View
+    spec = ConvSpec.dense(n_c)
+    x = torch.randn(2 * B, H, W, n_c, device=dev)
+    w = torch.randn(n_c, n_c, 3, 3, device=dev) * 0.03
+    b = torch.zeros(n_c, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            ops.conv([View(x)], w, b, spec, relu=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.conv([View(x)], w, b, spec, relu=True)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * (2 * B * H * W) * n_c * (9 * n_c)
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_kernel<9,128> (3x3 %d->%d, NHWC, batch %d)" % (n_c, n_c, 2 * B),
+            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "avg_launch_ms": round(ms, 4), "flop_per_launch": flops}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="sequences per GPU")
+    ap.add_argument("--height", type=int, default=180)
+    ap.add_argument("--width", type=int, default=240)
+    ap.add_argument("--seql", type=int, default=9)
+    ap.add_argument("--n_c", type=int, default=128)
+    ap.add_argument("--n_b", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the BMCNet HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from models.BMCNet import BMCNet
+    from bmc_hip.parallel import GradAllReducer
+    from train_step import bptt_step, encode_sequence, synthetic_events
+
+    scale, n_c, n_b = 4, args.n_c, args.n_b
+    B, H, W, L = args.batch, args.height, args.width, args.seql
+    torch.manual_seed(3407)                                   # same init on every rank (reference default seed)
+    model = BMCNet(scale, n_c, n_b).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, amsgrad=True)   # config/train_nfs.yml:28-34
+    reducer = GradAllReducer(model, opt) if world > 1 else None
+    n_lr = int(round(0.5689 * H * W / 1024)) * 1024 if (H, W) != (180, 240) else 24576
+    ev = synthetic_events(B, L, H, W, scale, n_lr, dev, seed=3407 + rank)
+
+    def step():
+        inp, gt = encode_sequence(ev, B, L, H, W, scale)
+        return bptt_step(model, opt, inp, gt, n_c, scale)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    peak_mem = torch.cuda.max_memory_allocated(dev) / 2**30
+
+    if rank == 0:
+        windows = L - 1
+        frames_per_step = world * B * windows
+        value = frames_per_step * args.steps / dt
+        step_flops = FLOP_PER_LRPX_FWD_BWD * H * W * B * windows if (n_c, n_b) == (128, 5) else None
+        roof = dominant_kernel_roofline(dev, B, H, W, n_c)
+        if step_flops:
+            roof["step_achieved_tflops_per_gpu"] = round(step_flops * args.steps / dt / 1e12, 2)
+            roof["step_frac_of_peak"] = round(step_flops * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+        out = {
+            "metric": "LR-voxel-frames/sec x4 SR train step, NFS 180x240",
+            "value": round(value, 3), "unit": "LR-voxel-frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BMCNet x4 NFS %dx%d->%dx%d, bs=%d/GPU fp32, SEQL=%d SEQN=2 (%d windows BPTT), "
+                                   "event scatter + fwd + MSE + bwd + Adam(amsgrad)%s" %
+                                   (H, W, scale * H, scale * W, B, L, windows, " + RCCL grad all-reduce" if world > 1 else ""),
+                       "global_batch": world * B, "frames_per_step": frames_per_step,
+                       "parallelism": "dp%d" % world, "n_c": n_c, "n_b": n_b, "peak_mem_GiB": round(peak_mem, 1),
+                       "final_loss": round(float(loss), 6)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""Data-parallel gradient synchronisation for sequence-batch sharding: one process per GPU,
+torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests).
+
+The reference has only dead DDP scaffolding (train.py:62-83, myutils/utils.py:41-53 with a hard-coded
+world size of 1); what a working version of it needs is one sum-all-reduce of the 10.9 MB fp32 gradient
+per step.  Every parameter is shared across the 5 blocks and the 8 recurrent windows, so almost all
+gradients become final only at the very end of backward; buckets are therefore few and large: a gradient is
+copied into its flat bucket by a post-accumulate hook the moment autograd finalises it, a full bucket is
+all-reduced on a side stream while backward continues, and the optimizer's pre-step hook joins the side
+stream, averages and points .grad at the reduced buffer.  The training loop itself stays
+`loss.backward(); optimizer.step()` as in train.py:236-237.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class GradAllReducer:
+    def __init__(self, module: torch.nn.Module, optimizer: torch.optim.Optimizer | None = None, group=None,
+                 bucket_mb: float = 4.0):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.params = [p for p in module.parameters() if p.requires_grad]   # parameters() de-duplicates aliases
+        dev = self.params[0].device
+        # reverse registration order ~ order in which gradients finalise (heads first, input convs last)
+        order = list(reversed(self.params))
+        self.buckets = []
+        cur, cur_bytes = [], 0
+        for p in order:
+            cur.append(p)
+            cur_bytes += p.numel() * 4
+            if cur_bytes >= bucket_mb * (1 << 20):
+                self.buckets.append(cur); cur, cur_bytes = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.flat = [torch.zeros(sum(p.numel() for p in b), device=dev, dtype=torch.float32) for b in self.buckets]
+        self.slot = {}
+        for bi, b in enumerate(self.buckets):
+            off = 0
+            for p in b:
+                self.slot[p] = (bi, off)
+                off += p.numel()
+        self.pending = [len(b) for b in self.buckets]
+        self.works = [None] * len(self.buckets)
+        self.cuda = dev.type == "cuda"
+        self.side = torch.cuda.Stream(device=dev) if self.cuda else None
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        if optimizer is not None:
+            optimizer.register_step_pre_hook(lambda *_: self.finish())
+
+    # -- called by autograd once per parameter per backward, after all its uses have been accumulated
+    def _on_grad(self, p):
+        bi, off = self.slot[p]
+        self.flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        if self.world == 1:
+            return
+        if self.cuda:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self.works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Join outstanding all-reduces, average, and expose the result as .grad (views of the flat buckets).
+        Every rank runs the same graph, so which parameters received a gradient is the same on every rank."""
+        nb = len(self.buckets)
+        active = [self.pending[bi] != len(self.buckets[bi]) for bi in range(nb)]
+        for bi in range(nb):
+            if active[bi] and self.pending[bi] != 0:      # bucket holds parameters the loss did not reach
+                for p in self.buckets[bi]:
+                    if p.grad is None:
+                        o = self.slot[p][1]
+                        self.flat[bi][o:o + p.numel()].zero_()
+                self._launch(bi)
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.side)
+        for bi in range(nb):
+            if not active[bi]:
+                continue
+            if self.world > 1:
+                self.flat[bi].div_(self.world)
+            for p in self.buckets[bi]:
+                if p.grad is not None:
+                    o = self.slot[p][1]
+                    p.grad = self.flat[bi][o:o + p.numel()].view_as(p)
+        self.pending = [len(b) for b in self.buckets]
+        self.works = [None] * nb
+
+
+def reduce_tensor(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Mean of a scalar over ranks for logging (myutils/utils.py:41-53, with the real world size)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t.detach().clone()
+    r = t.detach().clone()
+    dist.all_reduce(r, op=dist.ReduceOp.SUM, group=group)
+    return r / dist.get_world_size(group)

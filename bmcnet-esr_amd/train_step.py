@@ -1,0 +1,63 @@
+"""One BPTT training step with the semantics of the reference's hot loop (train.py:202-237):
+zero_grad; for each sliding window: forward with the recurrent state carried WITHOUT detach, MSE against the HR
+count image of the window's second frame, losses summed; one backward over all windows; one optimizer step.
+
+Plus the synthetic NFS-shaped event generator used by bench.py / tests."""
+import torch
+import torch.nn.functional as F
+
+from bmc_hip import ops
+
+
+def synthetic_events(B, seql, H, W, scale, n_lr, device, seed=3407):
+    """Per sample and frame: n_lr LR events and scale^2*n_lr HR events, x~U{0..W-1}, y~U{0..H-1}, p=+-1.
+    Returns dict of flat fp32 vectors + int64 frame offsets (frame order: b-major, then time)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = {}
+    for tag, (h, w, n) in {"lr": (H, W, n_lr), "hr": (H * scale, W * scale, n_lr * scale * scale)}.items():
+        nf = B * seql
+        xs = torch.randint(0, w, (nf * n,), generator=g).to(torch.float32)
+        ys = torch.randint(0, h, (nf * n,), generator=g).to(torch.float32)
+        ps = (torch.randint(0, 2, (nf * n,), generator=g) * 2 - 1).to(torch.float32)
+        off = torch.arange(nf + 1, dtype=torch.int64) * n
+        out[tag] = tuple(t.to(device) for t in (xs, ys, ps, off))
+    return out
+
+
+def encode_sequence(ev, B, seql, H, W, scale):
+    """events -> inp_cnt [B,seql,2,H,W], gt_cnt [B,seql,2,sH,sW] on the GPU (two batched scatter launches);
+    what the reference's DataLoader workers do per frame with events_to_channels (dataloader/h5dataset.py:518-526)."""
+    xs, ys, ps, off = ev["lr"]
+    inp = ops.events_to_channels_batched(xs, ys, ps, off, H, W, mutate=False).view(B, seql, 2, H, W)
+    xs, ys, ps, off = ev["hr"]
+    gt = ops.events_to_channels_batched(xs, ys, ps, off, H * scale, W * scale, mutate=False).view(
+        B, seql, 2, H * scale, W * scale)
+    return inp, gt
+
+
+def bptt_step(model, optimizer, inp_cnt, gt_cnt, n_c, scale, seqn=2, plain=False, loss_fn=F.mse_loss):
+    """inp_cnt [B,L,2,H,W], gt_cnt [B,L,2,sH,sW] (device tensors).  Returns (loss, last mse)."""
+    B, L, _, H, W = inp_cnt.shape
+    dev = inp_cnt.device
+    optimizer.zero_grad()
+    loss = 0
+    init = True
+    z = lambda c: torch.zeros(B, c, H, W, device=dev)
+    for i in range(L - seqn + 1):
+        x = inp_cnt[:, i:i + seqn].transpose(1, 2)          # [B,2(pol),seqn,H,W]   (train.py:211)
+        gt = gt_cnt[:, i + 1]                                # (train.py:213)
+        if init:
+            if plain:
+                h, pred = model(x, z(n_c), z(2 * scale * scale), True)
+            else:
+                h, hp, hn, pred = model(x, z(n_c), z(n_c), z(n_c), z(2 * scale * scale), True)
+            init = False
+        elif plain:
+            h, pred = model(x, h, pred, False)
+        else:
+            h, hp, hn, pred = model(x, h, hp, hn, pred, False)
+        mse = loss_fn(pred, gt)
+        loss = loss + mse
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), mse.detach()
