@@ -44,12 +44,19 @@ __global__ void colsum_stage1(const float* __restrict__ x, long long npix, int p
         ws[(long long)blockIdx.x * C + threadIdx.x] = t;
     }
 }
+// one block per channel: 256 threads stride over the per-block partials, fixed-order tree in LDS
 __global__ void colsum_stage2(const float* __restrict__ ws, int nblk, int C, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += ws[(long long)b * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) s += ws[(long long)b * C + c];
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + red[0] : red[0];
 }
 
 // ------------------------------------------------------------------ LayerNorm2d
@@ -145,13 +152,22 @@ __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restr
         ws[((long long)blockIdx.x * 2 + 1) * C + c] = b;
     }
 }
+// grid = 2*C blocks (dgamma channels then dbeta channels), same fixed-order reduction as colsum_stage2
 __global__ void ln_bwd_finish(const float* __restrict__ ws, int nblk, int C, float* dgamma, float* dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float a = 0.f, b = 0.f;
-    for (int i = 0; i < nblk; ++i) { a += ws[((long long)i * 2) * C + c]; b += ws[((long long)i * 2 + 1) * C + c]; }
-    dgamma[c] = accumulate ? dgamma[c] + a : a;
-    dbeta[c] = accumulate ? dbeta[c] + b : b;
+    const int which = blockIdx.x / C, c = blockIdx.x % C;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += ws[((long long)i * 2 + which) * C + c];
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float* o = which ? dbeta : dgamma;
+        o[c] = accumulate ? o[c] + red[0] : red[0];
+    }
 }
 
 // ------------------------------------------------------------------ row softmax (one wave per row)
@@ -317,7 +333,7 @@ extern "C" int bmc_colsum(const float* x, long long npix, int pix_stride, int C,
     const int npl = threads / C;
     const int nblk = nblocks(npix, npl * 16);
     hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(threads), 0, (hipStream_t)s, x, npix, pix_stride, C, ws);
-    hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)s, ws, nblk, C, out, accumulate);
+    hipLaunchKernelGGL(colsum_stage2, dim3(C), dim3(256), 0, (hipStream_t)s, ws, nblk, C, out, accumulate);
     BMC_CHECK_LAUNCH("bmc_colsum");
     return 0;
 }
@@ -348,7 +364,7 @@ extern "C" int bmc_layernorm_bwd(const float* dy, const float* x, const float* s
     if (nb > 1024) nb = 1024;
     dim3 grid(nb);
     LN_DISPATCH(ln_bwd_kernel, dy, x, stats, gamma, npix, dx, ws);
-    hipLaunchKernelGGL(ln_bwd_finish, dim3((C + 255) / 256), dim3(256), 0, st, ws, nb, C, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(ln_bwd_finish, dim3(2 * C), dim3(256), 0, st, ws, nb, C, dgamma, dbeta, accumulate);
     BMC_CHECK_LAUNCH("bmc_layernorm_bwd");
     return 0;
 }
