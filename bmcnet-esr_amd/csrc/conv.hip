@@ -15,6 +15,14 @@
 // product does not care about.
 #include "bmc_common.h"
 
+#ifdef BMC_DIAG
+// diagnostic build only (libbmc_hip_diag.so, tools/): per-block cycle / wall stamps; never in the product library
+__device__ unsigned long long* g_diag_buf = nullptr;
+extern "C" int bmc_diag_set_buffer(unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 
 constexpr int CK = BMC_CK;  // channels per chunk
@@ -54,6 +62,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvK a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+#ifdef BMC_DIAG
+    const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     int bid = blockIdx.x;
     const int nt = bid % a.ntn; bid /= a.ntn;
@@ -145,11 +156,38 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvK a) {
 
     const int nsteps = a.nchunks * TAPS;
 
+    // Software pipeline (one barrier per step, MFMA work queued on both sides of it):
+    //   top of step s : read fragments (s, k-half 1); write W(s+1) [and X(c+1) on the chunk's last tap] to LDS
+    //                   from registers loaded one step earlier; 16 MFMAs on fragments (s, k-half 0)
+    //   barrier
+    //   after barrier : read fragments (s+1, k-half 0); issue global loads for W(s+2) [/ next X];
+    //                   16 MFMAs on fragments (s, k-half 1) -- they cover the LDS latency of the reads just issued
+    f32x4 af0[MT], bf0[NT], af1[MT], bf1[NT];
+    auto read_frags = [&](const float* xb, const float* wb, int tapoff, int kg, f32x4 (&af)[MT], f32x4 (&bf)[NT]) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const f32x4*>(xb + aoff[t] + tapoff + 8 * kg);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) bf[u] = *reinterpret_cast<const f32x4*>(wb + boff[u] + 8 * kg);
+    };
+    auto mfma16 = [&](const f32x4 (&af)[MT], const f32x4 (&bf)[NT]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][j], bf[u][j], acc[t][u], 0, 0, 0);
+    };
+    auto tap_off = [](int tap) { return TAPS == 9 ? ((tap / 3) * HWD + (tap % 3)) * RS : 0; };
+
     load_x();
     load_w(0);
     store_x(0);
     store_w(0);
+    if (nsteps > 1) load_w(1);
+    if (TAPS == 1 && a.nchunks > 1) load_x();
     __syncthreads();
+    read_frags(Xb, Wb, 0, 0, af0, bf0);
 
     for (int c = 0; c < a.nchunks; ++c) {
         const float* const xb = Xb + (c & 1) * XBUF;
@@ -157,29 +195,25 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvK a) {
         for (int tap = 0; tap < TAPS; ++tap) {
             const int step = c * TAPS + tap;
             const bool has_next = step + 1 < nsteps;
-            const bool next_x = (tap == TAPS - 1) && (c + 1 < a.nchunks);
-            if (has_next) load_w(step + 1);
-            if (next_x) load_x();
+            const bool last_tap = tap == TAPS - 1;
+            const bool store_next_x = last_tap && (c + 1 < a.nchunks);
             const float* const wb = Wb + (step & 1) * WBUF;
-            const int tapoff = TAPS == 9 ? ((tap / 3) * HWD + (tap % 3)) * RS : 0;
-#pragma unroll
-            for (int kg = 0; kg < 2; ++kg) {
-                f32x4 af[MT], bf[NT];
-#pragma unroll
-                for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const f32x4*>(xb + aoff[t] + tapoff + 8 * kg);
-#pragma unroll
-                for (int u = 0; u < NT; ++u) bf[u] = *reinterpret_cast<const f32x4*>(wb + boff[u] + 8 * kg);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u)
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][j], bf[u][j], acc[t][u], 0, 0, 0);
-            }
+            read_frags(xb, wb, tap_off(tap), 1, af1, bf1);
             if (has_next) store_w((step + 1) & 1);
-            if (next_x) store_x((c + 1) & 1);
+            if (store_next_x) store_x((c + 1) & 1);
+            mfma16(af0, bf0);
             __syncthreads();
+            if (has_next) {
+                const float* const xbn = last_tap ? Xb + ((c + 1) & 1) * XBUF : xb;
+                read_frags(xbn, Wb + ((step + 1) & 1) * WBUF, tap_off(last_tap ? 0 : tap + 1), 0, af0, bf0);
+            }
+            if (step + 2 < nsteps) load_w(step + 2);
+            {   // X of the next chunk is written at the top of that chunk's... this chunk's last tap: load it one step ahead
+                const int tap1 = last_tap ? 0 : tap + 1;                   // tap of step+1
+                const int c1 = last_tap ? c + 1 : c;                       // chunk of step+1
+                if (tap1 == TAPS - 1 && c1 + 1 < a.nchunks && has_next) load_x();
+            }
+            mfma16(af1, bf1);
         }
     }
 
@@ -212,6 +246,12 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvK a) {
             }
         }
     }
+#ifdef BMC_DIAG
+    if (g_diag_buf && tid == 0) {
+        unsigned long long* d = g_diag_buf + (unsigned long long)blockIdx.x * 4;
+        d[0] = diag_c0; d[1] = __builtin_amdgcn_s_memtime(); d[2] = diag_r0; d[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 }  // namespace
