@@ -193,7 +193,7 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
         n_nblk = (npad + 127) // 128
         tiles = (H * W + 63) // 64
     other = G * ((mpad + 127) // 128) * n_nblk
-    nsplit = max(1, min(bpg * tiles, 768 // max(other, 1)))
+    nsplit = max(1, min(bpg * tiles, 512 // max(other, 1)))   # 2 resident workgroups per CU
     slabs = torch.empty(nsplit * G * taps * mpad * npad, device=device, dtype=torch.float32)
     p = lib.PgemmArgs()
     p.a = a_src

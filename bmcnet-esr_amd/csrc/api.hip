@@ -12,3 +12,14 @@ void bmc_set_error(const char* fmt, ...) {
 
 extern "C" int bmc_version(void) { return 100; }
 extern "C" const char* bmc_last_error(void) { return g_err; }
+
+int bmc_num_cus(void) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}

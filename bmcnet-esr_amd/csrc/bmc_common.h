@@ -28,6 +28,7 @@ void bmc_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int bmc_round_up(int v, int m) { return (v + m - 1) / m * m; }
+int bmc_num_cus(void);  // multiprocessor count of the current device (cached)
 
 // Device view of bmc_src_t (same fields; kept POD so it can sit in kernel args).
 struct SrcDev {

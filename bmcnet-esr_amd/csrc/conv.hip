@@ -45,74 +45,89 @@ struct ConvK {
     SrcDev residual;
     SrcDev mask;
     int accumulate;
-    int tiles_x, tiles_y, ntn, nchunks;
+    int tiles_x, tiles_y, ntn, nchunks, ntiles;
 };
 
 template <int TAPS, int BN>
-__global__ __launch_bounds__(256) void conv_kernel(const ConvK a) {
+__global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const ConvK a) {
     constexpr int P = TAPS == 9 ? 1 : 0;
     constexpr int HWD = TW + 2 * P, HHT = TH + 2 * P, NHALO = HWD * HHT;
     constexpr int MT = BN == 128 ? 2 : 1, NT = BN == 128 ? 2 : 1;
     constexpr int NXLD = (NHALO * 4 + 255) / 256;
     constexpr int NWLD = (BN * 4 + 255) / 256;
     constexpr int XBUF = NHALO * RS, WBUF = BN * RS;
-    __shared__ __attribute__((aligned(16))) float lds[2 * XBUF + 2 * WBUF];
+    __shared__ __attribute__((aligned(16))) float lds[2 * XBUF + 2 * WBUF + BMC_MAX_SRC * 8];
     float* const Xb = lds;
     float* const Wb = lds + 2 * XBUF;
+    SrcDev* const tab = reinterpret_cast<SrcDev*>(lds + 2 * XBUF + 2 * WBUF);   // source table (runtime-indexed)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < BMC_MAX_SRC; ++i)
+        if (tid == i) tab[i] = a.src[i];
+    __syncthreads();
 #ifdef BMC_DIAG
     const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-
-    int bid = blockIdx.x;
-    const int nt = bid % a.ntn; bid /= a.ntn;
-    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y;
-    const int b = bid / a.tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
-    const int g = b / a.batch_per_group;
-    const float* const wbase = a.w + (long long)g * a.w_group_stride + (long long)nt * BN * CK;
+    // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ... ; the load pipeline runs ahead of the
+    // MFMA pipeline across tile boundaries, so only the very first tile of a workgroup pays load latency.
+    const int ntiles = a.ntiles;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nsteps = a.nchunks * TAPS;
+    const int total_steps = my_tiles * nsteps, total_chunks = my_tiles * a.nchunks;
     const long long wstep = (long long)a.Coutpad * CK;
 
-    // ---- per-thread staging coordinates (fixed for the whole K loop)
-    int xpix[NXLD];
-    bool xok[NXLD];
-#pragma unroll
-    for (int n = 0; n < NXLD; ++n) {
-        const int e = tid + 256 * n, hp = e >> 2;
-        const int hy = hp / HWD, hx = hp - hy * HWD;
-        const int y = y0 - P + hy, x = x0 - P + hx;
-        xok[n] = hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W;
-        xpix[n] = y * a.W + x;
-    }
+    auto decode = [&](int tile, int& b, int& y0, int& x0, int& nt) {
+        nt = tile % a.ntn; tile /= a.ntn;
+        x0 = (tile % a.tiles_x) * TW; tile /= a.tiles_x;
+        y0 = (tile % a.tiles_y) * TH;
+        b = tile / a.tiles_y;
+    };
     const int q4 = (tid & 3) * 4;
 
-    f32x4 xr[NXLD], wr[NWLD];
-
-    // chunk -> (source, channel offset) walk
-    int s_idx = 0, c_in = 0;
-    auto cur_src = [&](int idx) -> SrcDev {
-        SrcDev S = a.src[0];
-        if (idx == 1) S = a.src[1];
-        if (idx == 2) S = a.src[2];
-        if (idx == 3) S = a.src[3];
-        if (idx == 4) S = a.src[4];
-        if (idx == 5) S = a.src[5];
-        return S;
+    // ---- X loader: walks (tile, chunk) in consumption order
+    int xl_tile = blockIdx.x, xl_chunk = 0, xl_b = 0, s_idx = 0, c_in = 0;
+    const float* sbase = nullptr;   // current source: batch base pointer, pixel stride, channel count
+    int spix = 0, snch = 0;
+    auto src_select = [&]() {
+        const SrcDev S = tab[s_idx];
+        sbase = src_batch_ptr(S, xl_b); spix = S.pix_stride; snch = S.nch;
     };
-    auto load_x = [&]() {  // loads chunk (s_idx, c_in), then advances the walk
-        const SrcDev S = cur_src(s_idx);
-        const float* base = src_batch_ptr(S, b) + c_in + q4;
+    int xpix[NXLD];
+    bool xok[NXLD];
+    auto xl_setup = [&](int tile) {
+        int b, y0, x0, nt;
+        decode(tile, b, y0, x0, nt);
+        xl_b = b;
+#pragma unroll
+        for (int n = 0; n < NXLD; ++n) {
+            const int e = tid + 256 * n, hp = e >> 2;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int y = y0 - P + hy, x = x0 - P + hx;
+            xok[n] = hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            xpix[n] = y * a.W + x;
+        }
+        s_idx = 0; c_in = 0; xl_chunk = 0;
+        src_select();
+    };
+    f32x4 xr[NXLD], wr[NWLD];
+    auto load_x = [&]() {
+        const float* base = sbase + c_in + q4;
 #pragma unroll
         for (int n = 0; n < NXLD; ++n) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (xok[n]) v = *reinterpret_cast<const f32x4*>(base + (long long)xpix[n] * S.pix_stride);
+            if (xok[n]) v = *reinterpret_cast<const f32x4*>(base + (long long)xpix[n] * spix);
             xr[n] = v;
         }
         c_in += CK;
-        if (c_in >= S.nch) { c_in = 0; ++s_idx; }
+        if (++xl_chunk == a.nchunks) {
+            xl_tile += gridDim.x;
+            if (xl_tile < ntiles) xl_setup(xl_tile);
+        } else if (c_in >= snch) {
+            c_in = 0; ++s_idx;
+            src_select();
+        }
     };
     auto store_x = [&](int buf) {
 #pragma unroll
@@ -121,12 +136,25 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvK a) {
             if (hp < NHALO) *reinterpret_cast<f32x4*>(Xb + buf * XBUF + hp * RS + q4) = xr[n];
         }
     };
-    auto load_w = [&](int step) {
-        const float* p = wbase + (long long)step * wstep;
+    // ---- W loader: walks (tile, step)
+    int wl_tile = blockIdx.x, wl_step = 0;
+    const float* wl_base = nullptr;
+    auto wl_setup = [&](int tile) {
+        int b, y0, x0, nt;
+        decode(tile, b, y0, x0, nt);
+        wl_base = a.w + (long long)(b / a.batch_per_group) * a.w_group_stride + (long long)nt * BN * CK;
+        wl_step = 0;
+    };
+    auto load_w = [&]() {
+        const float* p = wl_base + (long long)wl_step * wstep;
 #pragma unroll
         for (int n = 0; n < NWLD; ++n) {
             const int e = tid + 256 * n;
             if (e < BN * 4) wr[n] = *reinterpret_cast<const f32x4*>(p + e * 4);
+        }
+        if (++wl_step == nsteps) {
+            wl_tile += gridDim.x;
+            if (wl_tile < ntiles) wl_setup(wl_tile);
         }
     };
     auto store_w = [&](int buf) {
@@ -147,18 +175,19 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvK a) {
     for (int u = 0; u < NT; ++u) boff[u] = (cobase + 32 * u + li) * RS + 4 * lh;
 
     f32x16 acc[MT][NT];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int u = 0; u < NT; ++u)
+            for (int u = 0; u < NT; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
-
-    const int nsteps = a.nchunks * TAPS;
+                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    };
+    zero_acc();
 
     // Software pipeline (one barrier per step, MFMA work queued on both sides of it):
-    //   top of step s : read fragments (s, k-half 1); write W(s+1) [and X(c+1) on the chunk's last tap] to LDS
-    //                   from registers loaded one step earlier; 16 MFMAs on fragments (s, k-half 0)
+    //   top of step s : read fragments (s, k-half 1); write W(s+1) [and the next chunk's X on a chunk's last tap] to
+    //                   LDS from registers loaded one step earlier; 16 MFMAs on fragments (s, k-half 0)
     //   barrier
     //   after barrier : read fragments (s+1, k-half 0); issue global loads for W(s+2) [/ next X];
     //                   16 MFMAs on fragments (s, k-half 1) -- they cover the LDS latency of the reads just issued
@@ -180,71 +209,79 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvK a) {
     };
     auto tap_off = [](int tap) { return TAPS == 9 ? ((tap / 3) * HWD + (tap % 3)) * RS : 0; };
 
+    xl_setup(xl_tile);
+    wl_setup(wl_tile);
     load_x();
-    load_w(0);
+    load_w();
     store_x(0);
     store_w(0);
-    if (nsteps > 1) load_w(1);
-    if (TAPS == 1 && a.nchunks > 1) load_x();
+    if (total_steps > 1) load_w();
+    if (TAPS == 1 && total_chunks > 1) load_x();
     __syncthreads();
     read_frags(Xb, Wb, 0, 0, af0, bf0);
 
-    for (int c = 0; c < a.nchunks; ++c) {
-        const float* const xb = Xb + (c & 1) * XBUF;
+    int gs = 0, gc = 0;   // global step / chunk counters of this workgroup (LDS buffer parity)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int c = 0; c < a.nchunks; ++c, ++gc) {
+            const float* const xb = Xb + (gc & 1) * XBUF;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int step = c * TAPS + tap;
-            const bool has_next = step + 1 < nsteps;
-            const bool last_tap = tap == TAPS - 1;
-            const bool store_next_x = last_tap && (c + 1 < a.nchunks);
-            const float* const wb = Wb + (step & 1) * WBUF;
-            read_frags(xb, wb, tap_off(tap), 1, af1, bf1);
-            if (has_next) store_w((step + 1) & 1);
-            if (store_next_x) store_x((c + 1) & 1);
-            mfma16(af0, bf0);
-            __syncthreads();
-            if (has_next) {
-                const float* const xbn = last_tap ? Xb + ((c + 1) & 1) * XBUF : xb;
-                read_frags(xbn, Wb + ((step + 1) & 1) * WBUF, tap_off(last_tap ? 0 : tap + 1), 0, af0, bf0);
+            for (int tap = 0; tap < TAPS; ++tap, ++gs) {
+                const bool has_next = gs + 1 < total_steps;
+                const bool last_tap = tap == TAPS - 1;
+                const bool store_next_x = last_tap && (gc + 1 < total_chunks);
+                const float* const wb = Wb + (gs & 1) * WBUF;
+                read_frags(xb, wb, tap_off(tap), 1, af1, bf1);
+                if (has_next) store_w((gs + 1) & 1);
+                if (store_next_x) store_x((gc + 1) & 1);
+                mfma16(af0, bf0);
+                __syncthreads();
+                if (has_next) {
+                    const float* const xbn = last_tap ? Xb + ((gc + 1) & 1) * XBUF : xb;
+                    read_frags(xbn, Wb + ((gs + 1) & 1) * WBUF, tap_off(last_tap ? 0 : tap + 1), 0, af0, bf0);
+                }
+                if (gs + 2 < total_steps) load_w();
+                {   // the X tile written at the top of a chunk's last tap is loaded one step ahead of that
+                    const int tap1 = last_tap ? 0 : tap + 1;
+                    const int gc1 = last_tap ? gc + 1 : gc;
+                    if (tap1 == TAPS - 1 && gc1 + 1 < total_chunks && has_next) load_x();
+                }
+                mfma16(af1, bf1);
             }
-            if (step + 2 < nsteps) load_w(step + 2);
-            {   // X of the next chunk is written at the top of that chunk's... this chunk's last tap: load it one step ahead
-                const int tap1 = last_tap ? 0 : tap + 1;                   // tap of step+1
-                const int c1 = last_tap ? c + 1 : c;                       // chunk of step+1
-                if (tap1 == TAPS - 1 && c1 + 1 < a.nchunks && has_next) load_x();
-            }
-            mfma16(af1, bf1);
         }
-    }
 
-    // ---- epilogue
-    const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
-    float* const outb = a.out + (long long)b * a.out_batch_stride;
-    const float* const resb = a.residual.ptr ? src_batch_ptr(a.residual, b) : nullptr;
-    const float* const maskb = a.mask.ptr ? src_batch_ptr(a.mask, b) : nullptr;
+        // ---- epilogue of this tile
+        int b, y0, x0, nt;
+        decode(tile, b, y0, x0, nt);
+        const int g = b / a.batch_per_group;
+        const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
+        float* const outb = a.out + (long long)b * a.out_batch_stride;
+        const float* const resb = a.residual.ptr ? src_batch_ptr(a.residual, b) : nullptr;
+        const float* const maskb = a.mask.ptr ? src_batch_ptr(a.mask, b) : nullptr;
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        const int co = nt * BN + cobase + 32 * u + li;
-        const bool cok = co < a.Cout;
-        const float bv = (biasg && cok) ? biasg[co] : 0.f;
+        for (int u = 0; u < NT; ++u) {
+            const int co = nt * BN + cobase + 32 * u + li;
+            const bool cok = co < a.Cout;
+            const float bv = (biasg && cok) ? biasg[co] : 0.f;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
+            for (int t = 0; t < MT; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int irow = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int y = y0 + rowbase + 2 * t + (irow >> 4), x = x0 + (irow & 15);
-                if (cok && y < a.H && x < a.W) {
-                    const long long pix = (long long)y * a.W + x;
-                    float v = acc[t][u][r] + bv;
-                    if (resb) v += resb[pix * a.residual.pix_stride + co];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (maskb) v = maskb[pix * a.mask.pix_stride + co] > 0.f ? v : 0.f;
-                    float* o = outb + pix * a.out_pix_stride + co;
-                    if (a.accumulate) v += *o;
-                    *o = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int irow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int y = y0 + rowbase + 2 * t + (irow >> 4), x = x0 + (irow & 15);
+                    if (cok && y < a.H && x < a.W) {
+                        const long long pix = (long long)y * a.W + x;
+                        float v = acc[t][u][r] + bv;
+                        if (resb) v += resb[pix * a.residual.pix_stride + co];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        if (maskb) v = maskb[pix * a.mask.pix_stride + co] > 0.f ? v : 0.f;
+                        float* o = outb + pix * a.out_pix_stride + co;
+                        if (a.accumulate) v += *o;
+                        *o = v;
+                    }
                 }
             }
         }
+        zero_acc();
     }
 #ifdef BMC_DIAG
     if (g_diag_buf && tid == 0) {
@@ -291,9 +328,11 @@ extern "C" int bmc_conv(const bmc_conv_args_t* h, bmc_stream_t stream) {
     const int BN = h->Coutpad == 32 ? 32 : 128;
     k.ntn = h->Coutpad / BN;
     k.nchunks = ktot / CK;
-    const long long nblk = (long long)h->B * k.tiles_x * k.tiles_y * k.ntn;
-    BMC_CHECK_ARG(nblk < (1ll << 31), "bmc_conv: grid too large");
-    dim3 grid((unsigned)nblk), block(256);
+    const long long ntiles = (long long)h->B * k.tiles_x * k.tiles_y * k.ntn;
+    BMC_CHECK_ARG(ntiles < (1ll << 31), "bmc_conv: too many tiles");
+    k.ntiles = (int)ntiles;
+    const int max_blocks = bmc_num_cus() * 3;   // 3 resident workgroups per CU (LDS 49 KB, 154 registers)
+    dim3 grid((unsigned)(ntiles < max_blocks ? ntiles : max_blocks)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (h->taps == 9) {
         if (BN == 128) hipLaunchKernelGGL((conv_kernel<9, 128>), grid, block, 0, st, k);

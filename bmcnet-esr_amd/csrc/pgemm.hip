@@ -32,7 +32,7 @@ struct PgemmK {
 };
 
 template <int TAPS, int NT>
-__global__ __launch_bounds__(256) void pgemm_kernel(const PgemmK a) {
+__global__ __launch_bounds__(256, 2) void pgemm_kernel(const PgemmK a) {
     constexpr int P = TAPS == 9 ? 1 : 0;
     constexpr int HWD = PT_W + 2 * P, HHT = PT_H + 2 * P;
     constexpr int NHALO = TAPS == 9 ? HWD * HHT : PT;
@@ -60,70 +60,86 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PgemmK a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int ntiles = a.batch_per_group * a.tiles_per_img;
-    for (int tile = split; tile < ntiles; tile += a.nsplit) {
+    const int HWp = a.H * a.W;
+    constexpr int NA = PT * 32 / 256;                       // float4 per thread for the A tile
+    constexpr int F4_PER_PX = NB / 4;
+    constexpr int NX = (NHALO * F4_PER_PX + 255) / 256;     // float4 per thread for the X tile
+    f32x4 ar[NA], xr[NX];
+
+    // global -> registers for one pixel tile (issued one tile ahead, under the MFMAs of the current tile)
+    auto gload = [&](int tile) {
         const int bb = tile / a.tiles_per_img, tin = tile - bb * a.tiles_per_img;
         const int b = g * a.batch_per_group + bb;
         int y0 = 0, x0 = 0, p0 = 0;
         if (TAPS == 9) { y0 = (tin / a.tiles_x) * PT_H; x0 = (tin % a.tiles_x) * PT_W; }
         else p0 = tin * PT;
-        const int HWp = a.H * a.W;
-
-        // ---- stage A tile: [64 px][128 ch of this m-block], zero outside image / beyond M
-        {
-            const float* ab = src_batch_ptr(a.a, b);
+        const float* ab = src_batch_ptr(a.a, b);
 #pragma unroll
-            for (int n = 0; n < PT * 32 / 256; ++n) {
-                const int e = tid + 256 * n, p = e >> 5, c4 = (e & 31) * 4;
+        for (int n = 0; n < NA; ++n) {
+            const int e = tid + 256 * n, p = e >> 5, c4 = (e & 31) * 4;
+            long long pix;
+            bool ok;
+            if (TAPS == 9) {
+                const int y = y0 + (p >> 4), x = x0 + (p & 15);
+                ok = y < a.H && x < a.W;
+                pix = (long long)y * a.W + x;
+            } else {
+                pix = p0 + p;
+                ok = pix < HWp;
+            }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok && m0 + c4 < a.M) v = *reinterpret_cast<const f32x4*>(ab + pix * a.a.pix_stride + m0 + c4);
+            ar[n] = v;
+        }
+#pragma unroll
+        for (int n = 0; n < NX; ++n) {
+            const int e = tid + 256 * n, hp = e / F4_PER_PX, c4 = (e - hp * F4_PER_PX) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (hp < NHALO) {
                 long long pix;
                 bool ok;
                 if (TAPS == 9) {
-                    const int y = y0 + (p >> 4), x = x0 + (p & 15);
-                    ok = y < a.H && x < a.W;
+                    const int hy = hp / HWD, hx = hp - hy * HWD;
+                    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                    ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
                     pix = (long long)y * a.W + x;
                 } else {
-                    pix = p0 + p;
+                    pix = p0 + hp;
                     ok = pix < HWp;
                 }
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok && m0 + c4 < a.M) v = *reinterpret_cast<const f32x4*>(ab + pix * a.a.pix_stride + m0 + c4);
-                *reinterpret_cast<f32x4*>(At + p * AS + c4) = v;
-            }
-        }
-        // ---- stage X tile: [NHALO px][NB ch], 16-channel chunks resolved to their source
-        {
-            constexpr int F4_PER_PX = NB / 4;
-            constexpr int NX = (NHALO * F4_PER_PX + 255) / 256;
+                int ch = n0 + c4;   // channel -> source
+                if (ok && ch < a.N) {
+                    SrcDev S = a.src[0];
 #pragma unroll
-            for (int n = 0; n < NX; ++n) {
-                const int e = tid + 256 * n, hp = e / F4_PER_PX, c4 = (e - hp * F4_PER_PX) * 4;
-                if (hp < NHALO) {
-                    long long pix;
-                    bool ok;
-                    if (TAPS == 9) {
-                        const int hy = hp / HWD, hx = hp - hy * HWD;
-                        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-                        ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
-                        pix = (long long)y * a.W + x;
-                    } else {
-                        pix = p0 + hp;
-                        ok = pix < HWp;
-                    }
-                    // channel n0 + c4 -> source
-                    int ch = n0 + c4;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (ok && ch < a.N) {
-                        SrcDev S = a.src[0];
-#pragma unroll
-                        for (int si = 1; si < BMC_MAX_SRC; ++si)
-                            if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; }
-                        v = *reinterpret_cast<const f32x4*>(src_batch_ptr(S, b) + pix * S.pix_stride + ch);
-                    }
-                    *reinterpret_cast<f32x4*>(Xt + hp * XS + c4) = v;
+                    for (int si = 1; si < BMC_MAX_SRC; ++si)
+                        if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; }
+                    v = *reinterpret_cast<const f32x4*>(src_batch_ptr(S, b) + pix * S.pix_stride + ch);
                 }
             }
+            xr[n] = v;
         }
-        __syncthreads();
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int n = 0; n < NA; ++n) {
+            const int e = tid + 256 * n, p = e >> 5, c4 = (e & 31) * 4;
+            *reinterpret_cast<f32x4*>(At + p * AS + c4) = ar[n];
+        }
+#pragma unroll
+        for (int n = 0; n < NX; ++n) {
+            const int e = tid + 256 * n, hp = e / F4_PER_PX, c4 = (e - hp * F4_PER_PX) * 4;
+            if (hp < NHALO) *reinterpret_cast<f32x4*>(Xt + hp * XS + c4) = xr[n];
+        }
+    };
 
+    if (split < ntiles) {
+        gload(split);
+        lstore();
+    }
+    __syncthreads();
+    for (int tile = split; tile < ntiles; tile += a.nsplit) {
+        const int next = tile + a.nsplit;
+        if (next < ntiles) gload(next);
         if (wave_active) {
             const float* const ap = At + lh * AS + 32 * wave + li;
             const float* const xp = Xt + lh * XS + li;
@@ -144,6 +160,10 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PgemmK a) {
             }
         }
         __syncthreads();
+        if (next < ntiles) {
+            lstore();
+            __syncthreads();
+        }
     }
 
     // ---- write this split's partial tile: slabs[split][g][tap][Mpad][Npad]

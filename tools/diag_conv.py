@@ -22,7 +22,7 @@ k = 3 if taps == 9 else 1
 x = torch.randn(B, H, W, Cn, device=dev)
 w = torch.randn(Cn, Cn, k, k, device=dev) * 0.03; b = torch.zeros(Cn, device=dev)
 spec = ConvSpec.dense(Cn)
-nblk = B * ((H + 7) // 8) * ((W + 15) // 16)
+nblk = min(B * ((H + 7) // 8) * ((W + 15) // 16), 768)
 buf = torch.zeros(nblk * 4, dtype=torch.int64, device=dev)
 diag.bmc_diag_set_buffer.argtypes = [ctypes.c_void_p]
 with torch.no_grad():
