@@ -90,6 +90,7 @@ class ConvSpec:
         self.kpad = len(flat)
         self.kmap_host = flat
         self.cin = max(flat) + 1
+        self.real_nch = [sum(1 for c in src if c >= 0) for src in sources]
         self._kmap = {}
 
     def kmap(self, device):
@@ -110,6 +111,25 @@ class ConvSpec:
 
 
 _pack_cache = {}
+
+# Optional in-situ kernel timing (bench.py): when PROFILE is a list, every conv / pgemm launch appends
+# (kernel kind, algorithmic FLOPs, start event, end event) recorded on the launch stream.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, kind, flops):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((kind, flops, e0, e1))
 
 
 def _packed_weight(w4: torch.Tensor, spec: ConvSpec, cache_key):
@@ -159,7 +179,7 @@ def clear_pack_cache():
 # --------------------------------------------------------------------------
 def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stride, out_ptr, out_batch_stride,
              out_pix_stride, B, H, W, Cout, taps, relu=False, residual: Optional[lib.Src] = None, bpg=None,
-             accumulate=False):
+             accumulate=False, flops=0.0):
     a = lib.ConvArgs()
     a.nsrc = len(srcs)
     for i, s in enumerate(srcs):
@@ -179,10 +199,12 @@ def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stri
     a.residual = residual if residual is not None else _null_src()
     a.mask = _null_src()
     a.accumulate = int(accumulate)
+    e0 = _prof_begin()
     lib.call(lib._conv, "bmc_conv", C.byref(a), _stream())
+    _prof_end(e0, "conv_kernel<%d,%d>" % (taps, 32 if a.Coutpad == 32 else 128), flops)
 
 
-def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, device):
+def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, device, flops=0.0):
     """Returns (slabs, nsplit, G)."""
     G = B // bpg
     mpad, npad = round_up(M, 32), round_up(N, 32)
@@ -204,7 +226,9 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
     p.batch_per_group = bpg
     p.slabs = slabs.data_ptr()
     p.nsplit = nsplit
+    e0 = _prof_begin()
     lib.call(lib._pgemm, "bmc_pgemm", C.byref(p), _stream())
+    _prof_end(e0, "pgemm_kernel<%d>" % taps, flops)
     return slabs, nsplit, G
 
 
@@ -256,7 +280,7 @@ class ConvFn(torch.autograd.Function):
         cp = coutpad(Cout)
         conv_raw(srcs, wp, meta.spec.kpad * taps * cp, bias.detach() if bias is not None else None, Cout,
                  out.data_ptr(), H * W * Cout, Cout, B, H, W, Cout, taps, relu=meta.relu, residual=res,
-                 bpg=B // G)
+                 bpg=B // G, flops=2.0 * B * H * W * Cout * taps * meta.spec.cin)
         ctx.meta = meta
         ctx.has_bias = bias is not None
         ctx.has_res = res_t is not None
@@ -280,7 +304,8 @@ class ConvFn(torch.autograd.Function):
         if need[1]:
             srcs = [_src(t, *v, B) for t, v in zip(src_ts, meta.views)]
             a_src = _src(g, 0, Cout, 0, None, 0, B)
-            slabs, nsplit, _ = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev)
+            slabs, nsplit, _ = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
+                                         flops=2.0 * B * H * W * Cout * taps * spec.cin)
             dwf = torch.zeros(G * Cout * spec.cin * taps, device=dev, dtype=torch.float32)
             lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, G, taps, Cout, spec.kpad,
                      spec.kmap(dev).data_ptr(), spec.cin, dwf.data_ptr(), 0, _stream())
@@ -313,7 +338,7 @@ class ConvFn(torch.autograd.Function):
                 # grouped weights + remapped operand: launch over the full batch, fold the batch map afterwards
                 tmp = torch.empty((B, H, W, nch), device=dev, dtype=torch.float32)
                 conv_raw([_src(g, 0, Cout, 0, None, 0, B)], wt, c16 * taps * nkpad, None, 0, tmp.data_ptr(), H * W * nch,
-                         nch, B, H, W, nch, taps, bpg=B // G)
+                         nch, B, H, W, nch, taps, bpg=B // G, flops=2.0 * B * H * W * spec.real_nch[i] * taps * Cout)
                 if mod is not None and mod < B:
                     tmp = tmp.view(B // mod, mod, H, W, nch).sum(0)
                     if shift:
@@ -340,7 +365,7 @@ class ConvFn(torch.autograd.Function):
             if Cout % CK:
                 raise RuntimeError("bmc_hip: conv output channels must be a multiple of 16 for the data gradient")
             conv_raw([gsrc], wt, c16 * taps * nkpad, None, 0, dx.data_ptr() + 4 * (b0 * H * W * Ct + c0), H * W * Ct, Ct,
-                     nb, H, W, nch, taps, bpg=nb // G)
+                     nb, H, W, nch, taps, bpg=nb // G, flops=2.0 * nb * H * W * spec.real_nch[i] * taps * Cout)
             dsrcs.append(dx)
         return (None, dw, db, dres, *dsrcs)
 
@@ -416,7 +441,8 @@ class GramFn(torch.autograd.Function):
         _need_gpu(c)
         B, H, W, Cn = c.shape
         a_src = _src(c.detach(), 0, Cn, 0, None, 0, B)
-        slabs, nsplit, G = pgemm_raw(a_src, [_src(v.detach(), 0, Cn, 0, None, 0, B)], B, H, W, 1, 1, Cn, Cn, c.device)
+        slabs, nsplit, G = pgemm_raw(a_src, [_src(v.detach(), 0, Cn, 0, None, 0, B)], B, H, W, 1, 1, Cn, Cn, c.device,
+                                     flops=2.0 * B * H * W * Cn * Cn)
         att = torch.empty((B, Cn, Cn), device=c.device, dtype=torch.float32)
         lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, scale, att.data_ptr(),
                  _stream())
@@ -436,12 +462,12 @@ class GramFn(torch.autograd.Function):
             wp = _packed_weight(ds.view(B, Cn, Cn, 1), spec, None)
             dc = torch.empty_like(c)
             conv_raw([_src(v, 0, Cn, 0, None, 0, B)], wp, spec.kpad * cp, None, 0, dc.data_ptr(), H * W * Cn, Cn, B, H, W,
-                     Cn, 1, bpg=1)
+                     Cn, 1, bpg=1, flops=2.0 * B * H * W * Cn * Cn)
         if ctx.needs_input_grad[1]:   # dv[px,j] = sum_i ds[i,j] c[px,i]
             wp = _packed_weight(ds.transpose(1, 2).contiguous().view(B, Cn, Cn, 1), spec, None)
             dv = torch.empty_like(v)
             conv_raw([_src(c, 0, Cn, 0, None, 0, B)], wp, spec.kpad * cp, None, 0, dv.data_ptr(), H * W * Cn, Cn, B, H, W,
-                     Cn, 1, bpg=1)
+                     Cn, 1, bpg=1, flops=2.0 * B * H * W * Cn * Cn)
         return dc, dv, None
 
 

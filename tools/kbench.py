@@ -12,7 +12,7 @@ from bmc_hip.ops import ConvSpec, View
 
 dev = torch.device("cuda:0")
 B, H, W, Cn = int(os.environ.get("KB_B", 8)), int(os.environ.get("KB_H", 180)), int(os.environ.get("KB_W", 240)), 128
-ITERS = int(os.environ.get("KB_ITERS", 10))
+ITERS = int(os.environ.get("KB_ITERS", 40))
 
 
 def timeit(fn, flops, name, iters=ITERS):
