@@ -81,9 +81,13 @@ def dominant_kernel_roofline(step_fn, iso):
         a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1)
     n, fl, ms = agg["conv_kernel<9,128>"]
     ach = fl / (ms * 1e-3) / 1e12
+    traffic = None      # HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), never computed here
+    tj = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+    if os.path.exists(tj):
+        traffic = json.load(open(tj))["conv_kernel<9,128>"]["hbm_bytes_per_launch"]
     out = {"bound": "mfma", "kernel": "conv_kernel<9,128> (3x3 implicit GEMM fwd + dgrad, all %d launches of one step)" % n,
            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
            "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n, "launches_per_step": n,
            "isolated_2B_128to128": iso,
            "other_kernels": {k: {"launches": v[0], "achieved_tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2),
