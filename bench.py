@@ -139,9 +139,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the BMCNet HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("BMC_FORCE_DIST"))      # BMC_FORCE_DIST: exercise RCCL with 1 rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from models.BMCNet import BMCNet
     from bmc_hip.parallel import GradAllReducer
@@ -152,7 +154,7 @@ def main():
     torch.manual_seed(3407)                                   # same init on every rank (reference default seed)
     model = BMCNet(scale, n_c, n_b).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, amsgrad=True)   # config/train_nfs.yml:28-34
-    reducer = GradAllReducer(model, opt) if world > 1 else None
+    reducer = GradAllReducer(model, opt) if use_dist else None
     n_lr = int(round(0.5689 * H * W / 1024)) * 1024 if (H, W) != (180, 240) else 24576
     ev = synthetic_events(B, L, H, W, scale, n_lr, dev, seed=3407 + rank)
 
@@ -163,18 +165,18 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -196,7 +198,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BMCNet x4 NFS %dx%d->%dx%d, bs=%d/GPU fp32, SEQL=%d SEQN=2 (%d windows BPTT), "
                                    "event scatter + fwd + MSE + bwd + Adam(amsgrad)%s" %
-                                   (H, W, scale * H, scale * W, B, L, windows, " + RCCL grad all-reduce" if world > 1 else ""),
+                                   (H, W, scale * H, scale * W, B, L, windows, " + RCCL grad all-reduce" if use_dist else ""),
                        "global_batch": world * B, "frames_per_step": frames_per_step,
                        "parallelism": "dp%d" % world, "n_c": n_c, "n_b": n_b, "peak_mem_GiB": round(peak_mem, 1),
                        "final_loss": round(float(loss), 6)},
@@ -205,7 +207,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -58,7 +58,7 @@ class GradAllReducer:
             self._launch(bi)
 
     def _launch(self, bi):
-        if self.world == 1:
+        if not dist.is_initialized():
             return
         if self.cuda:
             self.side.wait_stream(torch.cuda.current_stream())

@@ -276,3 +276,40 @@ def test_cpu_tensor_fails_loudly():
     m = ResidualBlock_noBN(16)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 16, 4, 4))
+
+
+def test_rccl_grad_allreducer_single_rank():
+    """The RCCL path (init_process_group('nccl'), bucketed async all-reduce on a side stream, optimizer pre-step
+    hook) on one GPU / one rank: gradients must equal those of the same step without the reducer."""
+    dev = _gpu()
+    import socket
+    import torch.distributed as dist
+    from models.BMCNet_plain import BMCNet_plain
+    from bmc_hip.parallel import GradAllReducer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(1)
+        m = BMCNet_plain(4, 16, 1).to(dev)
+        x = torch.poisson(torch.full((1, 2, 2, 8, 16), 0.3)).to(dev)
+        gt = torch.rand(1, 2, 32, 64, device=dev)
+        z = lambda c: torch.zeros(1, c, 8, 16, device=dev)
+
+        def grads(with_reducer):
+            opt = torch.optim.SGD(m.parameters(), lr=0.0)
+            red = GradAllReducer(m, opt, bucket_mb=0.01) if with_reducer else None
+            opt.zero_grad()
+            h, pred = m(x, z(16), z(32), True)
+            h, pred = m(x, h, pred, False)
+            F.mse_loss(pred, gt).backward()
+            opt.step()
+            out = [p.grad.clone() for p in m.parameters()]
+            if red is not None:
+                for hd in red._handles:
+                    hd.remove()
+            return out
+        g0, g1 = grads(False), grads(True)
+        for a, b in zip(g0, g1):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
