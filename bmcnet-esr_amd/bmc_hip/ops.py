@@ -179,7 +179,7 @@ def clear_pack_cache():
 # --------------------------------------------------------------------------
 def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stride, out_ptr, out_batch_stride,
              out_pix_stride, B, H, W, Cout, taps, relu=False, residual: Optional[lib.Src] = None, bpg=None,
-             accumulate=False, flops=0.0):
+             accumulate=False, flops=0.0, mask: Optional[lib.Src] = None):
     a = lib.ConvArgs()
     a.nsrc = len(srcs)
     for i, s in enumerate(srcs):
@@ -197,7 +197,7 @@ def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stri
     a.taps = taps
     a.relu = int(relu)
     a.residual = residual if residual is not None else _null_src()
-    a.mask = _null_src()
+    a.mask = mask if mask is not None else _null_src()
     a.accumulate = int(accumulate)
     e0 = _prof_begin()
     lib.call(lib._conv, "bmc_conv", C.byref(a), _stream())
@@ -381,6 +381,75 @@ def conv(views: Sequence[View], weight, bias, spec: ConvSpec, *, B=None, relu=Fa
         res_t, res_meta = residual.t, (residual.shift, residual.mod)
     meta = ConvMeta(spec, [v.meta() for v in views], B, relu, G, res_meta, cache, taps)
     return ConvFn.apply(meta, weight, bias, res_t, *[v.t for v in views])
+
+
+# --------------------------------------------------------------------------
+# fused residual block (models/submodules.py:17-35): both ReLU-backward and the skip-path gradient add live in
+# convolution epilogues, so the backward is exactly 2 data-gradient + 2 weight-gradient launches (+ bias sums)
+# --------------------------------------------------------------------------
+def _wgrad_plain(g, x, spec, weight_shape, taps):
+    B, H, W, Cout = g.shape
+    dev = g.device
+    slabs, nsplit, _ = pgemm_raw(_src(g, 0, Cout, 0, None, 0, B), [_src(x, 0, x.shape[3], 0, None, 0, B)], B, H, W, taps, B,
+                                 Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.cin)
+    dw = torch.zeros(Cout * spec.cin * taps, device=dev, dtype=torch.float32)
+    lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, 1, taps, Cout, spec.kpad,
+             spec.kmap(dev).data_ptr(), spec.cin, dw.data_ptr(), 0, _stream())
+    return dw.view(weight_shape)
+
+
+class ResBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, spec):
+        _need_gpu(x)
+        B, H, W, Cn = x.shape
+        taps = w1.shape[-1] * w1.shape[-2]
+        cp = coutpad(Cn)
+        xs = _src(x.detach(), 0, Cn, 0, None, 0, B)
+        wp1 = _packed_weight(w1.detach().reshape(1, Cn, Cn, taps), spec, (w1.data_ptr(), w1._version))
+        wp2 = _packed_weight(w2.detach().reshape(1, Cn, Cn, taps), spec, (w2.data_ptr(), w2._version))
+        fl = 2.0 * B * H * W * Cn * taps * Cn
+        t = torch.empty_like(x)
+        conv_raw([xs], wp1, spec.kpad * taps * cp, b1.detach(), Cn, t.data_ptr(), H * W * Cn, Cn, B, H, W, Cn, taps, relu=True,
+                 flops=fl)
+        y = torch.empty_like(x)
+        conv_raw([_src(t, 0, Cn, 0, None, 0, B)], wp2, spec.kpad * taps * cp, b2.detach(), Cn, y.data_ptr(), H * W * Cn, Cn, B, H,
+                 W, Cn, taps, residual=xs, flops=fl)
+        ctx.save_for_backward(x, t, w1, w2)
+        ctx.spec, ctx.taps = spec, taps
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, w1, w2 = ctx.saved_tensors
+        spec, taps = ctx.spec, ctx.taps
+        g = g.contiguous()
+        B, H, W, Cn = g.shape
+        dev = g.device
+        need = ctx.needs_input_grad
+        fl = 2.0 * B * H * W * Cn * taps * Cn
+        gs = _src(g, 0, Cn, 0, None, 0, B)
+        nkpad, c16 = coutpad(Cn), round_up(Cn, CK)
+        dw2 = _wgrad_plain(g, t, spec, w2.shape, taps) if need[3] else None
+        db2 = colsum(g.data_ptr(), B * H * W, Cn, Cn, dev) if need[4] else None
+        # d(pre-activation of conv1) = ReLU'(t) * conv2^T(g): mask epilogue
+        w2t = _packed_weight_t(w2.detach().reshape(1, Cn, Cn, taps), spec, 0, (w2.data_ptr(), w2._version))
+        dt = torch.empty_like(g)
+        conv_raw([gs], w2t, c16 * taps * nkpad, None, 0, dt.data_ptr(), H * W * Cn, Cn, B, H, W, Cn, taps,
+                 mask=_src(t, 0, Cn, 0, None, 0, B), flops=fl)
+        dw1 = _wgrad_plain(dt, x, spec, w1.shape, taps) if need[1] else None
+        db1 = colsum(dt.data_ptr(), B * H * W, Cn, Cn, dev) if need[2] else None
+        dx = None
+        if need[0]:   # dx = conv1^T(dt) + g (skip path): residual epilogue
+            w1t = _packed_weight_t(w1.detach().reshape(1, Cn, Cn, taps), spec, 0, (w1.data_ptr(), w1._version))
+            dx = torch.empty_like(g)
+            conv_raw([_src(dt, 0, Cn, 0, None, 0, B)], w1t, c16 * taps * nkpad, None, 0, dx.data_ptr(), H * W * Cn, Cn, B, H, W,
+                     Cn, taps, residual=gs, flops=fl)
+        return dx, dw1, db1, dw2, db2, None
+
+
+def res_block(x, w1, b1, w2, b2, spec):
+    return ResBlockFn.apply(x, w1, b1, w2, b2, spec)
 
 
 # --------------------------------------------------------------------------

@@ -185,41 +185,69 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const PgemmK a) {
     }
 }
 
+// Slab reductions: 32 outputs x 8 split-parts per 256-thread block (each part sums every 8th split, then a fixed
+// order LDS tree) -- deterministic, and short even when nsplit is in the hundreds.
+__device__ __forceinline__ float split_sum(const float* p, long long slab, int nsplit, float* red) {
+    const int part = threadIdx.x >> 5, ol = threadIdx.x & 31;
+    float s = 0.f;
+    if (p)
+        for (int i = part; i < nsplit; i += 8) s += p[i * slab];
+    red[part * 32 + ol] = s;
+    __syncthreads();
+    float t = 0.f;
+    if (part == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + ol];
+    }
+    __syncthreads();
+    return t;
+}
+
 __global__ void reduce_weight_kernel(const float* slabs, int nsplit, int G, int taps, int M, int N, int Mpad, int Npad,
                                      const int* kmap, int Cin, float* dw, int accumulate) {
+    __shared__ float red[256];
     const long long total = (long long)G * taps * M * N;
     const long long slab = (long long)G * taps * Mpad * Npad;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int n = idx % N;
-        long long r = idx / N;
-        const int m = r % M; r /= M;
-        const int tap = r % taps;
-        const int g = r / taps;
-        const int ci = kmap ? kmap[n] : n;
-        if (ci < 0) continue;
-        const float* p = slabs + (((long long)g * taps + tap) * Mpad + m) * Npad + n;
-        float s = 0.f;
-        for (int i = 0; i < nsplit; ++i) s += p[i * slab];
-        float* o = dw + (((long long)g * M + m) * Cin + ci) * taps + tap;
-        *o = accumulate ? *o + s : s;
+    const long long nchunk = (total + 31) / 32;
+    for (long long chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+        const long long idx = chunk * 32 + (threadIdx.x & 31);
+        const float* p = nullptr;
+        int m = 0, tap = 0, g = 0, ci = -1;
+        if (idx < total) {
+            const int n = idx % N;
+            long long r = idx / N;
+            m = r % M; r /= M;
+            tap = r % taps;
+            g = r / taps;
+            ci = kmap ? kmap[n] : n;
+            if (ci >= 0) p = slabs + (((long long)g * taps + tap) * Mpad + m) * Npad + n;
+        }
+        const float s = split_sum(p, slab, nsplit, red);
+        if (threadIdx.x < 32 && ci >= 0) {
+            float* o = dw + (((long long)g * M + m) * Cin + ci) * taps + tap;
+            *o = accumulate ? *o + s : s;
+        }
     }
 }
 
 __global__ void reduce_plain_kernel(const float* slabs, int nsplit, int G, int M, int N, int Mpad, int Npad, float scale,
                                     float* out) {
+    __shared__ float red[256];
     const long long total = (long long)G * M * N;
     const long long slab = (long long)G * Mpad * Npad;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int n = idx % N;
-        long long r = idx / N;
-        const int m = r % M;
-        const int g = r / M;
-        const float* p = slabs + ((long long)g * Mpad + m) * Npad + n;
-        float s = 0.f;
-        for (int i = 0; i < nsplit; ++i) s += p[i * slab];
-        out[idx] = s * scale;
+    const long long nchunk = (total + 31) / 32;
+    for (long long chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+        const long long idx = chunk * 32 + (threadIdx.x & 31);
+        const float* p = nullptr;
+        if (idx < total) {
+            const int n = idx % N;
+            long long r = idx / N;
+            const int m = r % M;
+            const int g = r / M;
+            p = slabs + ((long long)g * Mpad + m) * Npad + n;
+        }
+        const float s = split_sum(p, slab, nsplit, red);
+        if (threadIdx.x < 32 && idx < total) out[idx] = s * scale;
     }
 }
 
@@ -271,7 +299,7 @@ extern "C" int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, in
                                        int Cin, float* dw, int accumulate, bmc_stream_t stream) {
     BMC_CHECK_ARG(slabs && dw && nsplit >= 1, "bmc_pgemm_reduce_weight: bad args");
     const long long total = (long long)G * taps * M * N;
-    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    const int blocks = (int)((total + 31) / 32 > 8192 ? 8192 : (total + 31) / 32);
     hipLaunchKernelGGL(reduce_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, taps, M, N,
                        bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, dw, accumulate);
     BMC_CHECK_LAUNCH("bmc_pgemm_reduce_weight");
@@ -282,7 +310,7 @@ extern "C" int bmc_pgemm_reduce_plain(const float* slabs, int nsplit, int G, int
                                       bmc_stream_t stream) {
     BMC_CHECK_ARG(slabs && out && nsplit >= 1, "bmc_pgemm_reduce_plain: bad args");
     const long long total = (long long)G * M * N;
-    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    const int blocks = (int)((total + 31) / 32 > 8192 ? 8192 : (total + 31) / 32);
     hipLaunchKernelGGL(reduce_plain_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, M, N,
                        bmc_round_up(M, 32), bmc_round_up(N, 32), scale, out);
     BMC_CHECK_LAUNCH("bmc_pgemm_reduce_plain");
