@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--n_c", type=int, default=128)
     ap.add_argument("--n_b", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--recompute", action="store_true", help="per-window activation recompute (long sequences / big batches)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -160,7 +161,7 @@ def main():
 
     def step():
         inp, gt = encode_sequence(ev, B, L, H, W, scale)
-        return bptt_step(model, opt, inp, gt, n_c, scale)
+        return bptt_step(model, opt, inp, gt, n_c, scale, recompute=args.recompute)
 
     for _ in range(args.warmup):
         step()
@@ -197,8 +198,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BMCNet x4 NFS %dx%d->%dx%d, bs=%d/GPU fp32, SEQL=%d SEQN=2 (%d windows BPTT), "
-                                   "event scatter + fwd + MSE + bwd + Adam(amsgrad)%s" %
-                                   (H, W, scale * H, scale * W, B, L, windows, " + RCCL grad all-reduce" if use_dist else ""),
+                                   "event scatter + fwd + MSE + bwd + Adam(amsgrad)%s%s" %
+                                   (H, W, scale * H, scale * W, B, L, windows, " + RCCL grad all-reduce" if use_dist else "",
+                                    " [per-window recompute]" if args.recompute else ""),
                        "global_batch": world * B, "frames_per_step": frames_per_step,
                        "parallelism": "dp%d" % world, "n_c": n_c, "n_b": n_b, "peak_mem_GiB": round(peak_mem, 1),
                        "final_loss": round(float(loss), 6)},

@@ -35,8 +35,15 @@ def encode_sequence(ev, B, seql, H, W, scale):
     return inp, gt
 
 
-def bptt_step(model, optimizer, inp_cnt, gt_cnt, n_c, scale, seqn=2, plain=False, loss_fn=F.mse_loss):
-    """inp_cnt [B,L,2,H,W], gt_cnt [B,L,2,sH,sW] (device tensors).  Returns (loss, last mse)."""
+def bptt_step(model, optimizer, inp_cnt, gt_cnt, n_c, scale, seqn=2, plain=False, loss_fn=F.mse_loss, recompute=False):
+    """inp_cnt [B,L,2,H,W], gt_cnt [B,L,2,sH,sW] (device tensors).  Returns (loss, last mse).
+
+    recompute=True keeps only the recurrent state (h, hp, hn, prediction) of every window and re-runs a window's
+    forward inside backward (activation checkpointing per window): peak memory drops from
+    windows x (one window's activations) to one window's activations, at the price of one extra forward per
+    window.  Needed for long sequences / big batches (BASELINE configs[4]: T=16, 8 sequences per GPU); results
+    are bit-identical (same kernels, same order)."""
+    from torch.utils.checkpoint import checkpoint
     B, L, _, H, W = inp_cnt.shape
     dev = inp_cnt.device
     optimizer.zero_grad()
@@ -53,7 +60,9 @@ def bptt_step(model, optimizer, inp_cnt, gt_cnt, n_c, scale, seqn=2, plain=False
                 h, hp, hn, pred = model(x, z(n_c), z(n_c), z(n_c), z(2 * scale * scale), True)
             init = False
         elif plain:
-            h, pred = model(x, h, pred, False)
+            h, pred = checkpoint(model, x, h, pred, False, use_reentrant=False) if recompute else model(x, h, pred, False)
+        elif recompute:
+            h, hp, hn, pred = checkpoint(model, x, h, hp, hn, pred, False, use_reentrant=False)
         else:
             h, hp, hn, pred = model(x, h, hp, hn, pred, False)
         mse = loss_fn(pred, gt)

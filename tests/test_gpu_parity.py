@@ -313,3 +313,30 @@ def test_rccl_grad_allreducer_single_rank():
             assert torch.equal(a, b)
     finally:
         dist.destroy_process_group()
+
+
+def test_bptt_step_recompute_is_bit_identical():
+    """Per-window activation recompute (train_step.bptt_step(recompute=True)) must give the same loss and
+    gradients as the store-everything path, bit for bit."""
+    dev = _gpu()
+    from models.BMCNet import BMCNet
+    from train_step import bptt_step, encode_sequence, synthetic_events
+    torch.manual_seed(3)
+    B, L, H, W, scale, n_c = 1, 4, 12, 20, 4, 16
+    m = BMCNet(scale, n_c, 1).to(dev)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(4.0)
+    ev = synthetic_events(B, L, H, W, scale, 128, dev, seed=1)
+    inp, gt = encode_sequence(ev, B, L, H, W, scale)
+    assert inp.shape == (B, L, 2, H, W) and gt.shape == (B, L, 2, 4 * H, 4 * W)
+    assert float(inp.sum()) == B * L * 128 and float(gt.sum()) == B * L * 128 * 16      # every event counted once
+    res = []
+    for rc in (False, True):
+        opt = torch.optim.SGD(m.parameters(), lr=0.0)
+        loss, _ = bptt_step(m, opt, inp, gt, n_c, scale, recompute=rc)
+        res.append((loss.clone(), [p.grad.clone() for p in m.parameters() if p.grad is not None]))
+    assert torch.equal(res[0][0], res[1][0])
+    assert len(res[0][1]) == len(res[1][1]) > 20
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
