@@ -75,6 +75,9 @@ class Backbone(nn.Module):
         # packed-K layouts (reference concat orders: models/BMCNet.py:60-73,78-82)
         self._sp_fpst = ConvSpec([pad16(rng(0, 2 * r)), rng(2 * r, n_c), rng(2 * r + n_c, s2)])
         self._sp_fps = ConvSpec([pad16([-1] * r + rng(0, r)), rng(r, n_c)])
+        # conv_fs is applied three times to cat[xp_st, xn_st, h*, o] with only h* changing (models/BMCNet.py:70-73):
+        # the contribution of the shared 2*n_c + 2*s2 input channels is computed once (with the bias), the h* part per call
+        self._sp_fs_shared = ConvSpec([rng(0, n_c), rng(n_c, n_c), rng(2 * n_c, s2), rng(2 * n_c + s2, s2)])
         self._sp_fs = ConvSpec([rng(0, n_c), rng(n_c, n_c), rng(2 * n_c, n_c), rng(3 * n_c, s2), rng(3 * n_c + s2, s2)])
         self._sp_h = ConvSpec.dense(n_c)
         self._sp_o = ConvSpec.dense(n_c, n_c)
@@ -91,9 +94,13 @@ class Backbone(nn.Module):
         s12 = ops.conv([View(xin12), View(hpn)], self.conv_fps.weight, self.conv_fps.bias, self._sp_fps,
                        relu=True)                                          # [xp_s; xn_s]
         # conv_fs on cat[xp_st, xn_st, h*, o] for h* = hp, hn, hs: one launch over 3B
-        fs3 = ops.conv([View(st12, b0=0, mod=B), View(st12, b0=B, mod=B), View(h3), View(o12, b0=0, mod=B),
-                        View(o12, b0=B, mod=B)], self.conv_fs.weight, self.conv_fs.bias, self._sp_fs, B=3 * B,
-                       relu=True)                                          # [xs_p_st; xs_n_st; xs]
+        n_c = self.n_c
+        wfs = self.conv_fs.weight
+        w_shared = torch.cat([wfs[:, :2 * n_c], wfs[:, 3 * n_c:]], 1)      # input channels of xp_st, xn_st, o
+        shared = ops.conv([View(st12, b0=0), View(st12, b0=B), View(o12, b0=0), View(o12, b0=B)], w_shared,
+                          self.conv_fs.bias, self._sp_fs_shared, B=B, cache=False)
+        fs3 = ops.conv([View(h3)], wfs[:, 2 * n_c:3 * n_c].contiguous(), None, self._sp_h, B=3 * B, relu=True,
+                       residual=View(shared, mod=B), cache=False)          # [xs_p_st; xs_n_st; xs]
         sst12, xs = fs3[:2 * B], fs3[2 * B:]
         for layer in self.para_reschunk:
             s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12)
