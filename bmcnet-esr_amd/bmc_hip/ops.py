@@ -8,6 +8,7 @@ models/BMCNet.py); each function cites what it stands in for.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Optional, Sequence
 
 import torch
@@ -92,6 +93,7 @@ class ConvSpec:
         self.cin = max(flat) + 1
         self.real_nch = [sum(1 for c in src if c >= 0) for src in sources]
         self._kmap = {}
+        self._packs = {}
 
     def kmap(self, device):
         k = self._kmap.get(device)
@@ -110,7 +112,6 @@ class ConvSpec:
         return ConvSpec(out)
 
 
-_pack_cache = {}
 
 # Optional in-situ kernel timing (bench.py): when PROFILE is a list, every conv / pgemm launch appends
 # (kernel kind, algorithmic FLOPs, start event, end event) recorded on the launch stream.
@@ -132,32 +133,45 @@ def _prof_end(e0, kind, flops):
         PROFILE.append((kind, flops, e0, e1))
 
 
-def _packed_weight(w4: torch.Tensor, spec: ConvSpec, cache_key):
-    """[G,Cout,Cin,taps] -> MFMA staging layout (bmc_pack_weight)."""
+def _cache_get(spec: ConvSpec, kind, owner):
+    """Packed weights are cached on the ConvSpec, keyed by (kind, id(owner)) and validated by a weak reference to
+    the owning parameter plus its version counter (an address or id alone can be recycled by the allocator)."""
+    if owner is None:
+        return None
+    hit = spec._packs.get((kind, id(owner)))
+    if hit is not None and hit[0]() is owner and hit[1] == owner._version:
+        return hit[2]
+    return None
+
+
+def _cache_put(spec: ConvSpec, kind, owner, packed):
+    if owner is not None:
+        if len(spec._packs) > 64:       # stale entries of dead owners
+            for k in [k for k, v in spec._packs.items() if v[0]() is None]:
+                del spec._packs[k]
+        spec._packs[(kind, id(owner))] = (weakref.ref(owner), owner._version, packed)
+
+
+def _packed_weight(w4: torch.Tensor, spec: ConvSpec, owner):
+    """[G,Cout,Cin,taps] -> MFMA staging layout (bmc_pack_weight).  owner: the parameter tensor w4 was derived
+    from (cache key), or None for no caching."""
     G, Cout, Cin, taps = w4.shape
-    key = None
-    if cache_key is not None:
-        key = (cache_key[0], id(spec), "f")
-        hit = _pack_cache.get(key)
-        if hit is not None and hit[0] == cache_key[1]:
-            return hit[1]
+    hit = _cache_get(spec, "f", owner)
+    if hit is not None:
+        return hit
     cp = coutpad(Cout)
     out = torch.empty(G * spec.kpad * taps * cp, device=w4.device, dtype=torch.float32)
     lib.call(lib._pack_w, "bmc_pack_weight", w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin, taps,
              spec.kpad, cp, out.data_ptr(), _stream())
-    if key is not None:
-        _pack_cache[key] = (cache_key[1], out)
+    _cache_put(spec, "f", owner, out)
     return out
 
 
-def _packed_weight_t(w4: torch.Tensor, spec: ConvSpec, src_index: int, cache_key):
+def _packed_weight_t(w4: torch.Tensor, spec: ConvSpec, src_index: int, owner):
     G, Cout, Cin, taps = w4.shape
-    key = None
-    if cache_key is not None:
-        key = (cache_key[0], id(spec), "t", src_index)
-        hit = _pack_cache.get(key)
-        if hit is not None and hit[0] == cache_key[1]:
-            return hit[1]
+    hit = _cache_get(spec, ("t", src_index), owner)
+    if hit is not None:
+        return hit
     k0 = sum(spec.nch[:src_index])
     nk = spec.nch[src_index]
     nkpad = coutpad(nk)
@@ -165,13 +179,12 @@ def _packed_weight_t(w4: torch.Tensor, spec: ConvSpec, src_index: int, cache_key
     out = torch.empty(G * c16 * taps * nkpad, device=w4.device, dtype=torch.float32)
     lib.call(lib._pack_wt, "bmc_pack_weight_t", w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin, taps,
              k0, nk, nkpad, c16, out.data_ptr(), _stream())
-    if key is not None:
-        _pack_cache[key] = (cache_key[1], out)
+    _cache_put(spec, ("t", src_index), owner, out)
     return out
 
 
 def clear_pack_cache():
-    _pack_cache.clear()
+    pass    # caches live on the ConvSpec objects and die with them
 
 
 # --------------------------------------------------------------------------
@@ -280,7 +293,7 @@ class ConvFn(torch.autograd.Function):
         G, taps, B = meta.G, meta.taps, meta.B
         w4 = weight.detach().reshape(G, -1, meta.spec.cin, taps)
         Cout = w4.shape[1]
-        ck = (weight.data_ptr(), weight._version) if meta.cache else None
+        ck = weight if meta.cache else None
         wp = _packed_weight(w4.contiguous(), meta.spec, ck)
         out = torch.empty((B, H, W, Cout), device=t0.device, dtype=torch.float32)
         srcs = [_src(t.detach(), *v, B) for t, v in zip(src_ts, meta.views)]
@@ -292,6 +305,7 @@ class ConvFn(torch.autograd.Function):
                  out.data_ptr(), H * W * Cout, Cout, B, H, W, Cout, taps, relu=meta.relu, residual=res,
                  bpg=B // G, flops=2.0 * B * H * W * Cout * taps * meta.spec.cin)
         ctx.meta = meta
+        ctx.w_owner = ck            # identity of the parameter object (saved_tensors may hand back a new wrapper)
         ctx.has_bias = bias is not None
         ctx.has_res = res_t is not None
         ctx.save_for_backward(weight, out if meta.relu else None, *src_ts)
@@ -307,7 +321,7 @@ class ConvFn(torch.autograd.Function):
         _, H, W, Cout = g.shape
         dev = g.device
         w4 = weight.detach().reshape(G, Cout, spec.cin, taps).contiguous()
-        ck = (weight.data_ptr(), weight._version) if meta.cache else None
+        ck = ctx.w_owner
         need = ctx.needs_input_grad
         dw = db = dres = None
         # ---- weight gradient: pixel-reduction GEMM  dW[co][k][tap] = sum_px g[px][co] * x[px+tap][k]
@@ -427,8 +441,8 @@ class ResBlockFn(torch.autograd.Function):
         taps = w1.shape[-1] * w1.shape[-2]
         cp = coutpad(Cn)
         xs = _src(x.detach(), 0, Cn, 0, None, 0, B)
-        wp1 = _packed_weight(w1.detach().reshape(1, Cn, Cn, taps), spec, (w1.data_ptr(), w1._version))
-        wp2 = _packed_weight(w2.detach().reshape(1, Cn, Cn, taps), spec, (w2.data_ptr(), w2._version))
+        wp1 = _packed_weight(w1.detach().reshape(1, Cn, Cn, taps), spec, w1)
+        wp2 = _packed_weight(w2.detach().reshape(1, Cn, Cn, taps), spec, w2)
         fl = 2.0 * B * H * W * Cn * taps * Cn
         t = torch.empty_like(x)
         conv_raw([xs], wp1, spec.kpad * taps * cp, b1.detach(), Cn, t.data_ptr(), H * W * Cn, Cn, B, H, W, Cn, taps, relu=True,
@@ -438,6 +452,7 @@ class ResBlockFn(torch.autograd.Function):
                  W, Cn, taps, residual=xs, flops=fl)
         ctx.save_for_backward(x, t, w1, w2)
         ctx.spec, ctx.taps = spec, taps
+        ctx.owners = (w1, w2)
         return y
 
     @staticmethod
@@ -453,14 +468,14 @@ class ResBlockFn(torch.autograd.Function):
         nkpad, c16 = coutpad(Cn), round_up(Cn, CK)
         dw2, db2 = _wgrad_plain(g, t, spec, w2.shape, taps) if (need[3] or need[4]) else (None, None)
         # d(pre-activation of conv1) = ReLU'(t) * conv2^T(g): mask epilogue
-        w2t = _packed_weight_t(w2.detach().reshape(1, Cn, Cn, taps), spec, 0, (w2.data_ptr(), w2._version))
+        w2t = _packed_weight_t(w2.detach().reshape(1, Cn, Cn, taps), spec, 0, ctx.owners[1])
         dt = torch.empty_like(g)
         conv_raw([gs], w2t, c16 * taps * nkpad, None, 0, dt.data_ptr(), H * W * Cn, Cn, B, H, W, Cn, taps,
                  mask=_src(t, 0, Cn, 0, None, 0, B), flops=fl)
         dw1, db1 = _wgrad_plain(dt, x, spec, w1.shape, taps) if (need[1] or need[2]) else (None, None)
         dx = None
         if need[0]:   # dx = conv1^T(dt) + g (skip path): residual epilogue
-            w1t = _packed_weight_t(w1.detach().reshape(1, Cn, Cn, taps), spec, 0, (w1.data_ptr(), w1._version))
+            w1t = _packed_weight_t(w1.detach().reshape(1, Cn, Cn, taps), spec, 0, ctx.owners[0])
             dx = torch.empty_like(g)
             conv_raw([_src(dt, 0, Cn, 0, None, 0, B)], w1t, c16 * taps * nkpad, None, 0, dx.data_ptr(), H * W * Cn, Cn, B, H, W,
                      Cn, taps, residual=gs, flops=fl)

@@ -14,7 +14,14 @@
 // the k-order inside a chunk is permuted identically for A and B, which a dot
 // product does not care about.
 #include "bmc_common.h"
+#include <stdlib.h>
 
+#ifndef BMC_LX
+#define BMC_LX 1   // measured: deeper rings (2, 3) do not help the 1x1 kernel (it is power/clock limited)
+#endif
+#ifndef BMC_DIAG_MODE
+#define BMC_DIAG_MODE 0   // ablation bits for diagnostic builds (tools/): 1 no epilogue stores, 2 no global loads, 4 no MFMAs
+#endif
 #ifdef BMC_DIAG
 // diagnostic build only (libbmc_hip_diag.so, tools/): per-block cycle / wall stamps; never in the product library
 __device__ unsigned long long* g_diag_buf = nullptr;
@@ -111,14 +118,15 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
         s_idx = 0; c_in = 0; xl_chunk = 0;
         src_select();
     };
-    f32x4 xr[NXLD], wr[NWLD];
-    auto load_x = [&]() {
+    constexpr int LX = TAPS == 1 ? BMC_LX : 1;   // X register ring depth = how many steps a 1x1 tile load runs ahead
+    f32x4 xr[LX][NXLD], wr[NWLD];
+    auto load_x = [&](int slot) {
         const float* base = sbase + c_in + q4;
 #pragma unroll
         for (int n = 0; n < NXLD; ++n) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (xok[n]) v = *reinterpret_cast<const f32x4*>(base + (long long)xpix[n] * spix);
-            xr[n] = v;
+            if (!(BMC_DIAG_MODE & 2) && xok[n]) v = *reinterpret_cast<const f32x4*>(base + (long long)xpix[n] * spix);
+            xr[slot][n] = v;
         }
         c_in += CK;
         if (++xl_chunk == a.nchunks) {
@@ -129,11 +137,11 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
             src_select();
         }
     };
-    auto store_x = [&](int buf) {
+    auto store_x = [&](int slot, int buf) {
 #pragma unroll
         for (int n = 0; n < NXLD; ++n) {
             const int e = tid + 256 * n, hp = e >> 2;
-            if (hp < NHALO) *reinterpret_cast<f32x4*>(Xb + buf * XBUF + hp * RS + q4) = xr[n];
+            if (hp < NHALO) *reinterpret_cast<f32x4*>(Xb + buf * XBUF + hp * RS + q4) = xr[slot][n];
         }
     };
     // ---- W loader: walks (tile, step)
@@ -150,6 +158,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
 #pragma unroll
         for (int n = 0; n < NWLD; ++n) {
             const int e = tid + 256 * n;
+            if (BMC_DIAG_MODE & 2) { wr[n] = f32x4{1.f, 1.f, 1.f, 1.f}; continue; }
             if (e < BN * 4) wr[n] = *reinterpret_cast<const f32x4*>(p + e * 4);
         }
         if (++wl_step == nsteps) {
@@ -199,6 +208,13 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
         for (int u = 0; u < NT; ++u) bf[u] = *reinterpret_cast<const f32x4*>(wb + boff[u] + 8 * kg);
     };
     auto mfma16 = [&](const f32x4 (&af)[MT], const f32x4 (&bf)[NT]) {
+        if (BMC_DIAG_MODE & 4) {   // ablation: keep the fragments live, skip the matrix pipe
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[t][u][0] += af[t][0] * bf[u][0] + af[t][3] * bf[u][3];
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -209,47 +225,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
     };
     auto tap_off = [](int tap) { return TAPS == 9 ? ((tap / 3) * HWD + (tap % 3)) * RS : 0; };
 
-    xl_setup(xl_tile);
-    wl_setup(wl_tile);
-    load_x();
-    load_w();
-    store_x(0);
-    store_w(0);
-    if (total_steps > 1) load_w();
-    if (TAPS == 1 && total_chunks > 1) load_x();
-    __syncthreads();
-    read_frags(Xb, Wb, 0, 0, af0, bf0);
-
-    int gs = 0, gc = 0;   // global step / chunk counters of this workgroup (LDS buffer parity)
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        for (int c = 0; c < a.nchunks; ++c, ++gc) {
-            const float* const xb = Xb + (gc & 1) * XBUF;
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap, ++gs) {
-                const bool has_next = gs + 1 < total_steps;
-                const bool last_tap = tap == TAPS - 1;
-                const bool store_next_x = last_tap && (gc + 1 < total_chunks);
-                const float* const wb = Wb + (gs & 1) * WBUF;
-                read_frags(xb, wb, tap_off(tap), 1, af1, bf1);
-                if (has_next) store_w((gs + 1) & 1);
-                if (store_next_x) store_x((gc + 1) & 1);
-                mfma16(af0, bf0);
-                __syncthreads();
-                if (has_next) {
-                    const float* const xbn = last_tap ? Xb + ((gc + 1) & 1) * XBUF : xb;
-                    read_frags(xbn, Wb + ((gs + 1) & 1) * WBUF, tap_off(last_tap ? 0 : tap + 1), 0, af0, bf0);
-                }
-                if (gs + 2 < total_steps) load_w();
-                {   // the X tile written at the top of a chunk's last tap is loaded one step ahead of that
-                    const int tap1 = last_tap ? 0 : tap + 1;
-                    const int gc1 = last_tap ? gc + 1 : gc;
-                    if (tap1 == TAPS - 1 && gc1 + 1 < total_chunks && has_next) load_x();
-                }
-                mfma16(af1, bf1);
-            }
-        }
-
-        // ---- epilogue of this tile
+    auto epilogue = [&](int tile) {   // bias / residual / ReLU / mask, 16-byte stores, then clear the accumulators
         int b, y0, x0, nt;
         decode(tile, b, y0, x0, nt);
         const int g = b / a.batch_per_group;
@@ -269,6 +245,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     const int co = nt * BN + cobase + 32 * u + 8 * rq + 4 * lh;
+                    if ((BMC_DIAG_MODE & 1) && acc[t][u][4 * rq] != 12345.678f) continue;   // ablation: no stores
                     if (pok && co < a.Cout) {      // Cout is a multiple of 4: a quad is all-in or all-out
                         f32x4 v;
 #pragma unroll
@@ -292,6 +269,79 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
             }
         }
         zero_acc();
+    };
+
+    xl_setup(xl_tile);
+    wl_setup(wl_tile);
+    load_x(0);
+    load_w();
+    store_x(0, 0);
+    store_w(0);
+    if (total_steps > 1) load_w();
+    if (TAPS == 1) {
+#pragma unroll
+        for (int j = 1; j <= LX; ++j)
+            if (j < total_steps) load_x(j % LX);
+    }
+    __syncthreads();
+    read_frags(Xb, Wb, 0, 0, af0, bf0);
+
+    if constexpr (TAPS == 1) {
+        // one step per 16-channel chunk; X tiles come from HBM, so their loads run LX steps ahead (register ring)
+        int tile = blockIdx.x, cc = 0;
+        for (int base = 0; base < total_steps; base += LX) {
+#pragma unroll
+            for (int d = 0; d < LX; ++d) {
+                const int s = base + d;
+                if (s < total_steps) {
+                    const bool has_next = s + 1 < total_steps;
+                    read_frags(Xb + (s & 1) * XBUF, Wb + (s & 1) * WBUF, 0, 1, af1, bf1);
+                    if (has_next) {
+                        store_w((s + 1) & 1);
+                        store_x((d + 1) % LX, (s + 1) & 1);
+                    }
+                    mfma16(af0, bf0);
+                    __syncthreads();
+                    if (has_next) read_frags(Xb + ((s + 1) & 1) * XBUF, Wb + ((s + 1) & 1) * WBUF, 0, 0, af0, bf0);
+                    if (s + 2 < total_steps) load_w();
+                    if (s + 1 + LX < total_steps) load_x((d + 1) % LX);
+                    mfma16(af1, bf1);
+                    if (++cc == a.nchunks) {
+                        epilogue(tile);
+                        tile += gridDim.x;
+                        cc = 0;
+                    }
+                }
+            }
+        }
+    } else {
+        int gs = 0, gc = 0;   // global step / chunk counters of this workgroup (LDS buffer parity)
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            for (int c = 0; c < a.nchunks; ++c, ++gc) {
+                const float* const xb = Xb + (gc & 1) * XBUF;
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap, ++gs) {
+                    const bool has_next = gs + 1 < total_steps;
+                    const bool last_tap = tap == TAPS - 1;
+                    const float* const wb = Wb + (gs & 1) * WBUF;
+                    read_frags(xb, wb, tap_off(tap), 1, af1, bf1);
+                    if (has_next) store_w((gs + 1) & 1);
+                    if (last_tap && gc + 1 < total_chunks) store_x(0, (gc + 1) & 1);
+                    mfma16(af0, bf0);
+                    __syncthreads();
+                    if (has_next) {
+                        const float* const xbn = last_tap ? Xb + ((gc + 1) & 1) * XBUF : xb;
+                        read_frags(xbn, Wb + ((gs + 1) & 1) * WBUF, tap_off(last_tap ? 0 : tap + 1), 0, af0, bf0);
+                    }
+                    if (gs + 2 < total_steps) load_w();
+                    // the next chunk's halo tile is written to LDS at the top of this chunk's last tap: issue its
+                    // global loads right at the chunk's first step (8 steps of MFMAs to land from HBM)
+                    if (tap == 0 && gc + 1 < total_chunks) load_x(0);
+                    mfma16(af1, bf1);
+                }
+            }
+            epilogue(tile);
+        }
     }
 #ifdef BMC_DIAG
     if (g_diag_buf && tid == 0) {
@@ -343,6 +393,7 @@ extern "C" int bmc_conv(const bmc_conv_args_t* h, bmc_stream_t stream) {
     const long long ntiles = (long long)h->B * k.tiles_x * k.tiles_y * k.ntn;
     BMC_CHECK_ARG(ntiles < (1ll << 31), "bmc_conv: too many tiles");
     k.ntiles = (int)ntiles;
+
     const int max_blocks = bmc_num_cus() * 3;   // 3 resident workgroups per CU (LDS 49 KB, 154 registers)
     dim3 grid((unsigned)(ntiles < max_blocks ? ntiles : max_blocks)), block(256);
     hipStream_t st = (hipStream_t)stream;

@@ -340,3 +340,23 @@ def test_bptt_step_recompute_is_bit_identical():
     assert len(res[0][1]) == len(res[1][1]) > 20
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
+
+
+def test_packed_weight_cache_is_not_fooled_by_recycled_addresses():
+    """Two different weight tensors that the caching allocator places at the same address (same shape, version 0)
+    must not share a packed-weight cache entry."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from bmc_hip.ops import ConvSpec, View
+    spec = ConvSpec.dense(16)
+    x = torch.randn(1, 9, 9, 16, device=dev)
+    outs, refs = [], []
+    for seed in (1, 2, 3):
+        g = torch.Generator().manual_seed(seed)
+        w = (torch.randn(16, 16, 3, 3, generator=g) * 0.1).to(dev)
+        with torch.no_grad():
+            outs.append(ops.conv([View(x)], w, None, spec).clone())
+        refs.append(F.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1))
+        del w
+    for o, r in zip(outs, refs):
+        assert rel_l2(o, r) < 2e-5

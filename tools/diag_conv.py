@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "bmcnet-esr_amd"))
 import torch
 import bmc_hip.lib as L
-diag = ctypes.CDLL(os.path.join(ROOT, "bmcnet-esr_amd", "csrc", "libbmc_hip_diag.so"))
+diag = ctypes.CDLL(os.path.join(ROOT, "bmcnet-esr_amd", "csrc", "libbmc_hip_diag%s.so" % os.environ.get("BMC_DIAG_MODE", "")))
 # route the binding to the diag library
 for name in L.EXPORTS:
     fn = getattr(diag, name); old = getattr(L._lib, name)
