@@ -42,8 +42,7 @@ class ConvArgs(C.Structure):
 
 class PgemmArgs(C.Structure):
     _fields_ = [("a", Src), ("nsrc", C.c_int), ("src", Src * MAX_SRC), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
-                ("taps", C.c_int), ("batch_per_group", C.c_int), ("slabs", C.c_void_p), ("nsplit", C.c_int),
-                ("bias_slabs", C.c_void_p)]
+                ("taps", C.c_int), ("batch_per_group", C.c_int), ("slabs", C.c_void_p), ("nsplit", C.c_int)]
 
 
 def _sig(name, argtypes, restype=C.c_int):
@@ -63,7 +62,6 @@ _pack_wt = _sig("bmc_pack_weight_t", [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p
 _conv = _sig("bmc_conv", [C.POINTER(ConvArgs), _p])
 _pgemm = _sig("bmc_pgemm", [C.POINTER(PgemmArgs), _p])
 _red_w = _sig("bmc_pgemm_reduce_weight", [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p])
-_red_b = _sig("bmc_pgemm_reduce_bias", [_p, _i, _i, _i, _p, _i, _p])
 _red_p = _sig("bmc_pgemm_reduce_plain", [_p, _i, _i, _i, _i, _f, _p, _p])
 _colsum = _sig("bmc_colsum", [_p, _ll, _i, _i, _p, _p, _i, _p])
 _relu_bwd = _sig("bmc_relu_bwd", [_p, _p, _p, _ll, _p])
@@ -76,7 +74,7 @@ _unshuffle = _sig("bmc_unshuffle_to_nhwc", [_p, _i, _i, _i, _i, _i, _p, _p])
 _shuffle = _sig("bmc_shuffle_to_hr", [_p, _i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _ll, _p, _p])
 
 EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_pack_weight", "bmc_pack_weight_t", "bmc_conv",
-           "bmc_pgemm", "bmc_pgemm_reduce_weight", "bmc_pgemm_reduce_bias", "bmc_pgemm_reduce_plain", "bmc_colsum", "bmc_relu_bwd",
+           "bmc_pgemm", "bmc_pgemm_reduce_weight", "bmc_pgemm_reduce_plain", "bmc_colsum", "bmc_relu_bwd",
            "bmc_layernorm_fwd", "bmc_layernorm_bwd", "bmc_softmax_fwd", "bmc_softmax_bwd", "bmc_pack_inputs",
            "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr"]
 

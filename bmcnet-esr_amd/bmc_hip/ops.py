@@ -217,8 +217,8 @@ def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stri
     _prof_end(e0, "conv_kernel<%d,%d>" % (taps, 32 if a.Coutpad == 32 else 128), flops)
 
 
-def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, device, flops=0.0, want_bias=False):
-    """Returns (slabs, nsplit, G) or, with want_bias, (slabs, nsplit, G, db[G,M]) where db = column sums of A."""
+def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, device, flops=0.0):
+    """Returns (slabs, nsplit, G)."""
     G = B // bpg
     mpad, npad = round_up(M, 32), round_up(N, 32)
     if taps == 9:
@@ -239,19 +239,9 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
     p.batch_per_group = bpg
     p.slabs = slabs.data_ptr()
     p.nsplit = nsplit
-    bslabs = None
-    if want_bias:
-        bslabs = torch.empty(nsplit * 8 * G * mpad, device=device, dtype=torch.float32)
-        p.bias_slabs = bslabs.data_ptr()
-    else:
-        p.bias_slabs = None
     e0 = _prof_begin()
     lib.call(lib._pgemm, "bmc_pgemm", C.byref(p), _stream())
     _prof_end(e0, "pgemm_kernel<%d>" % taps, flops)
-    if want_bias:
-        db = torch.empty((G, M), device=device, dtype=torch.float32)
-        lib.call(lib._red_b, "bmc_pgemm_reduce_bias", bslabs.data_ptr(), nsplit * 8, G, M, db.data_ptr(), 0, _stream())
-        return slabs, nsplit, G, db
     return slabs, nsplit, G
 
 
@@ -328,17 +318,13 @@ class ConvFn(torch.autograd.Function):
         if need[1]:
             srcs = [_src(t, *v, B) for t, v in zip(src_ts, meta.views)]
             a_src = _src(g, 0, Cout, 0, None, 0, B)
-            wb = ctx.has_bias and need[2] and taps == 1
-            res_pg = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
-                               flops=2.0 * B * H * W * Cout * taps * spec.cin, want_bias=wb)
-            slabs, nsplit = res_pg[0], res_pg[1]
-            if wb:
-                db = res_pg[3][0] if G == 1 else res_pg[3]
+            slabs, nsplit, _ = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
+                                         flops=2.0 * B * H * W * Cout * taps * spec.cin)
             dwf = torch.zeros(G * Cout * spec.cin * taps, device=dev, dtype=torch.float32)
             lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, G, taps, Cout, spec.kpad,
                      spec.kmap(dev).data_ptr(), spec.cin, dwf.data_ptr(), 0, _stream())
             dw = dwf.view(weight.shape)
-        if ctx.has_bias and need[2] and db is None:
+        if ctx.has_bias and need[2]:
             bpg = B // G
             parts = [colsum(g.data_ptr() + 4 * gi * bpg * H * W * Cout, bpg * H * W, Cout, Cout, dev) for gi in range(G)]
             db = parts[0] if G == 1 else torch.stack(parts)
@@ -419,14 +405,9 @@ def _wgrad_plain(g, x, spec, weight_shape, taps):
     """-> (dW, db): weight gradient and bias gradient (column sums of g) from one pgemm launch."""
     B, H, W, Cout = g.shape
     dev = g.device
-    if taps == 1:
-        slabs, nsplit, _, db = pgemm_raw(_src(g, 0, Cout, 0, None, 0, B), [_src(x, 0, x.shape[3], 0, None, 0, B)], B, H, W,
-                                         taps, B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.cin,
-                                         want_bias=True)
-    else:   # the 3x3 pgemm kernel has no registers to spare for the fused column sums
-        slabs, nsplit, _ = pgemm_raw(_src(g, 0, Cout, 0, None, 0, B), [_src(x, 0, x.shape[3], 0, None, 0, B)], B, H, W, taps,
-                                     B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.cin)
-        db = colsum(g.data_ptr(), B * H * W, Cout, Cout, dev).view(1, Cout)
+    slabs, nsplit, _ = pgemm_raw(_src(g, 0, Cout, 0, None, 0, B), [_src(x, 0, x.shape[3], 0, None, 0, B)], B, H, W, taps, B,
+                                 Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.cin)
+    db = colsum(g.data_ptr(), B * H * W, Cout, Cout, dev).view(1, Cout)
     dw = torch.zeros(Cout * spec.cin * taps, device=dev, dtype=torch.float32)
     lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, 1, taps, Cout, spec.kpad,
              spec.kmap(dev).data_ptr(), spec.cin, dw.data_ptr(), 0, _stream())

@@ -26,13 +26,12 @@ struct PgemmK {
     int batch_per_group;
     float* slabs;
     int nsplit;
-    float* bias_slabs;
     int M, Mpad, N, Npad;
     int n_nblk, n_mblk, G;
     int tiles_x, tiles_y, tiles_per_img;
 };
 
-template <int TAPS, int NT, bool BIAS>
+template <int TAPS, int NT>
 __global__ __launch_bounds__(256, 2) void pgemm_kernel(const PgemmK a) {
     constexpr int P = TAPS == 9 ? 1 : 0;
     constexpr int HWD = PT_W + 2 * P, HHT = PT_H + 2 * P;
@@ -120,16 +119,11 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const PgemmK a) {
             xr[n] = v;
         }
     };
-    // bias gradient = column sums of A: the first n-block adds up the A registers it stages (thread t holds rows
-    // t>>5, t>>5 + 8, ... of channel quad (t&31)*4) -> 8 partial rows per block, summed by bmc_pgemm_reduce_bias
-    const bool do_bias = BIAS && nb == 0;
-    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     auto lstore = [&]() {
 #pragma unroll
         for (int n = 0; n < NA; ++n) {
             const int e = tid + 256 * n, p = e >> 5, c4 = (e & 31) * 4;
             *reinterpret_cast<f32x4*>(At + p * AS + c4) = ar[n];
-            if (BIAS && do_bias) bsum += ar[n];
         }
 #pragma unroll
         for (int n = 0; n < NX; ++n) {
@@ -172,11 +166,6 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const PgemmK a) {
         }
     }
 
-    if (BIAS && do_bias) {
-        const int c4 = (tid & 31) * 4, part = tid >> 5;
-        if (m0 + c4 < a.Mpad)
-            *reinterpret_cast<f32x4*>(a.bias_slabs + (((long long)split * 8 + part) * a.G + g) * a.Mpad + m0 + c4) = bsum;
-    }
     // ---- write this split's partial tile: slabs[split][g][tap][Mpad][Npad]
     if (wave_active) {
         float* const sl = a.slabs + (((long long)split * a.G + g) * TAPS) * a.Mpad * a.Npad;
@@ -241,19 +230,6 @@ __global__ void reduce_weight_kernel(const float* slabs, int nsplit, int G, int 
     }
 }
 
-__global__ void reduce_bias_kernel(const float* bs, int npart, int G, int M, int Mpad, float* db, int accumulate) {
-    __shared__ float red[256];
-    const long long total = (long long)G * M;
-    const long long slab = (long long)G * Mpad;
-    const long long nchunk = (total + 31) / 32;
-    for (long long chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
-        const long long idx = chunk * 32 + (threadIdx.x & 31);
-        const float* p = idx < total ? bs + (idx / M) * Mpad + idx % M : nullptr;
-        const float s = split_sum(p, slab, npart, red);
-        if (threadIdx.x < 32 && idx < total) db[idx] = accumulate ? db[idx] + s : s;
-    }
-}
-
 __global__ void reduce_plain_kernel(const float* slabs, int nsplit, int G, int M, int N, int Mpad, int Npad, float scale,
                                     float* out) {
     __shared__ float red[256];
@@ -297,7 +273,7 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
         } else k.src[i] = to_dev(h->src[0]);
     }
     k.B = h->B; k.H = h->H; k.W = h->W; k.batch_per_group = h->batch_per_group;
-    k.slabs = h->slabs; k.nsplit = h->nsplit; k.bias_slabs = h->bias_slabs;
+    k.slabs = h->slabs; k.nsplit = h->nsplit;
     k.M = h->a.nch; k.Mpad = bmc_round_up(k.M, 32); k.N = N; k.Npad = bmc_round_up(N, 32);
     k.G = h->B / h->batch_per_group;
     k.n_mblk = (k.Mpad + 127) / 128;
@@ -307,15 +283,13 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
         k.tiles_x = (h->W + PT_W - 1) / PT_W; k.tiles_y = (h->H + PT_H - 1) / PT_H;
         k.tiles_per_img = k.tiles_x * k.tiles_y;
         dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * k.nsplit));
-        BMC_CHECK_ARG(h->bias_slabs == nullptr, "bmc_pgemm: fused bias sums are available for taps == 1 only");
-        hipLaunchKernelGGL((pgemm_kernel<9, 1, false>), grid, dim3(256), 0, st, k);
+        hipLaunchKernelGGL((pgemm_kernel<9, 1>), grid, dim3(256), 0, st, k);
     } else {
         k.n_nblk = (k.Npad + 127) / 128;
         k.tiles_x = k.tiles_y = 0;
         k.tiles_per_img = (h->H * h->W + PT - 1) / PT;
         dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * k.nsplit));
-        if (h->bias_slabs) hipLaunchKernelGGL((pgemm_kernel<1, 4, true>), grid, dim3(256), 0, st, k);
-        else hipLaunchKernelGGL((pgemm_kernel<1, 4, false>), grid, dim3(256), 0, st, k);
+        hipLaunchKernelGGL((pgemm_kernel<1, 4>), grid, dim3(256), 0, st, k);
     }
     BMC_CHECK_LAUNCH("bmc_pgemm");
     return 0;
@@ -329,17 +303,6 @@ extern "C" int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, in
     hipLaunchKernelGGL(reduce_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, taps, M, N,
                        bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, dw, accumulate);
     BMC_CHECK_LAUNCH("bmc_pgemm_reduce_weight");
-    return 0;
-}
-
-extern "C" int bmc_pgemm_reduce_bias(const float* bias_slabs, int npart, int G, int M, float* db, int accumulate,
-                                     bmc_stream_t stream) {
-    BMC_CHECK_ARG(bias_slabs && db && npart >= 1, "bmc_pgemm_reduce_bias: bad args");
-    const long long total = (long long)G * M;
-    const int blocks = (int)((total + 31) / 32);
-    hipLaunchKernelGGL(reduce_bias_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bias_slabs, npart, G, M,
-                       bmc_round_up(M, 32), db, accumulate);
-    BMC_CHECK_LAUNCH("bmc_pgemm_reduce_bias");
     return 0;
 }
 

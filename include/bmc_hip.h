@@ -115,14 +115,11 @@ typedef struct bmc_pgemm_args {
     int batch_per_group;
     float* slabs;
     int nsplit;
-    float* bias_slabs;          /* optional (taps == 1 only): column sums of A over pixels (bias gradients), partials [nsplit][8][G][Mpad] */
 } bmc_pgemm_args_t;
 int bmc_pgemm(const bmc_pgemm_args_t* host_args, bmc_stream_t s);
 /* slabs -> dW[Cout][Cin][taps] (nn.Conv2d layout) through kmap; beta 0/1 = overwrite/accumulate */
 int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, int taps, int M, int N, const int* kmap,
                             int Cin, float* dw, int accumulate, bmc_stream_t s);
-/* bias partials -> db[G][M] (npart = nsplit*8) */
-int bmc_pgemm_reduce_bias(const float* bias_slabs, int npart, int G, int M, float* db, int accumulate, bmc_stream_t s);
 /* slabs -> out[G][M][N] * scale */
 int bmc_pgemm_reduce_plain(const float* slabs, int nsplit, int G, int M, int N, float scale,
                            float* out, bmc_stream_t s);
