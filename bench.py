@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--n_c", type=int, default=128)
     ap.add_argument("--n_b", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture the whole step in a HIP graph and replay it (single GPU; pays off when the step is launch-bound, i.e. small frames)")
     ap.add_argument("--recompute", action="store_true", help="per-window activation recompute (long sequences / big batches)")
     args = ap.parse_args()
 
@@ -154,7 +155,8 @@ def main():
     B, H, W, L = args.batch, args.height, args.width, args.seql
     torch.manual_seed(3407)                                   # same init on every rank (reference default seed)
     model = BMCNet(scale, n_c, n_b).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, amsgrad=True)   # config/train_nfs.yml:28-34
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, amsgrad=True,    # config/train_nfs.yml:28-34
+                           capturable=args.graph)
     reducer = GradAllReducer(model, opt) if use_dist else None
     n_lr = int(round(0.5689 * H * W / 1024)) * 1024 if (H, W) != (180, 240) else 24576
     ev = synthetic_events(B, L, H, W, scale, n_lr, dev, seed=3407 + rank)
@@ -163,6 +165,26 @@ def main():
         inp, gt = encode_sequence(ev, B, L, H, W, scale)
         return bptt_step(model, opt, inp, gt, n_c, scale, recompute=args.recompute)
 
+    eager_step = step
+    if args.graph:
+        if use_dist:
+            raise SystemExit("--graph is single-GPU only")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):            # PyTorch's capture protocol: warm up on a side stream first
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        opt.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g_loss, g_mse = eager_step()
+
+        def step():
+            graph.replay()
+            return g_loss, g_mse
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -188,7 +210,7 @@ def main():
         frames_per_step = world * B * windows
         value = frames_per_step * args.steps / dt
         step_flops = FLOP_PER_LRPX_FWD_BWD * H * W * B * windows if (n_c, n_b) == (128, 5) else None
-        roof = dominant_kernel_roofline(step, isolated_conv(dev, B, H, W, n_c))
+        roof = dominant_kernel_roofline(eager_step, isolated_conv(dev, B, H, W, n_c))
         if step_flops:
             roof["step_achieved_tflops_per_gpu"] = round(step_flops * args.steps / dt / 1e12, 2)
             roof["step_frac_of_peak"] = round(step_flops * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
@@ -200,7 +222,7 @@ def main():
             "config": {"workload": "BMCNet x4 NFS %dx%d->%dx%d, bs=%d/GPU fp32, SEQL=%d SEQN=2 (%d windows BPTT), "
                                    "event scatter + fwd + MSE + bwd + Adam(amsgrad)%s%s" %
                                    (H, W, scale * H, scale * W, B, L, windows, " + RCCL grad all-reduce" if use_dist else "",
-                                    " [per-window recompute]" if args.recompute else ""),
+                                    " [per-window recompute]" if args.recompute else "") + (" [HIP graph replay]" if args.graph else ""),
                        "global_batch": world * B, "frames_per_step": frames_per_step,
                        "parallelism": "dp%d" % world, "n_c": n_c, "n_b": n_b, "peak_mem_GiB": round(peak_mem, 1),
                        "final_loss": round(float(loss), 6)},

@@ -29,11 +29,12 @@ class ParallelBlk(nn.Module):
         self.gBIE = BIE(nf)   # global BIE
         initialize_weights([self.conv1, self.conv2, self.conv1_st, self.conv2_st], 0.1)
 
-    def forward_nhwc(self, x12, xs, xst12, xsst12):
-        """x12 = [x_1; x_2], xst12 = [x_1_st; x_2_st], xsst12 = [x_1_s_st; x_2_s_st] (batch-stacked twins)."""
+    def forward_nhwc(self, x12, xs, xst12, xsst12, need_st=True):
+        """x12 = [x_1; x_2], xst12 = [x_1_st; x_2_st], xsst12 = [x_1_s_st; x_2_s_st] (batch-stacked twins).
+        need_st=False: the caller will not read the returned xst12 (it is None then)."""
         x12 = self.conv1.forward_nhwc(x12)
         xst12 = self.conv1_st.forward_nhwc(xst12)
-        x12, xst12, xsst12 = self.lBIE.forward_pair(x12, xst12, xsst12)
+        x12, xst12, xsst12 = self.lBIE.forward_pair(x12, xst12, xsst12, need_second=need_st)
         x12, xs = self.gBIE.forward_twin(x12, xs)
         return x12, xs, xst12, xsst12
 
@@ -102,8 +103,9 @@ class Backbone(nn.Module):
         fs3 = ops.conv([View(h3)], wfs[:, 2 * n_c:3 * n_c].contiguous(), None, self._sp_h, B=3 * B, relu=True,
                        residual=View(shared, mod=B), cache=False)          # [xs_p_st; xs_n_st; xs]
         sst12, xs = fs3[:2 * B], fs3[2 * B:]
-        for layer in self.para_reschunk:
-            s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12)
+        n_layers = len(self.para_reschunk)
+        for i, layer in enumerate(self.para_reschunk):      # x*_st of the last block is never read: skip what only feeds it
+            s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12, need_st=i + 1 < n_layers)
         x_h = ops.conv([View(xs)], self.conv_hs.weight, self.conv_hs.bias, self._sp_h, relu=True)
         hw = torch.stack([self.conv_hp.weight, self.conv_hn.weight])
         hb = torch.stack([self.conv_hp.bias, self.conv_hn.bias])

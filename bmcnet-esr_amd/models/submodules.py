@@ -106,18 +106,22 @@ class BIE(nn.Module):
         z = self.norm_s.forward_nhwc(z)
         return ops.conv([View(z)], self.clustering.weight, self.clustering.bias, self._s1)
 
-    def forward_pair(self, first, second, xs):
+    def forward_pair(self, first, second, xs, need_second=True):
+        """need_second=False skips everything that only feeds the second output (o2 = softmax(att2) v2 + Res(first)):
+        the last ParallelBlk of the backbone discards it (models/BMCNet.py:75-82 never reads x*_st after the loop)."""
         B = first.shape[0]
-        r1 = self.conv1.forward_nhwc(first)
         r2 = self.conv1.forward_nhwc(second)
         c1 = self._centre([View(xs), View(second)], B)
         c2 = self._centre([View(xs), View(first)], B)
         v1 = ops.conv([View(first)], self.v1.weight, self.v1.bias, self._s1)
-        v2 = ops.conv([View(second)], self.v2.weight, self.v2.bias, self._s1)
         p1 = ops.softmax_rows(ops.gram(c1, v1, self.scale))
-        p2 = ops.softmax_rows(ops.gram(c2, v2, self.scale))
         o1 = ops.attn_apply(p1, v1, residual=View(r2))
-        o2 = ops.attn_apply(p2, v2, residual=View(r1))
+        o2 = None
+        if need_second:
+            r1 = self.conv1.forward_nhwc(first)
+            v2 = ops.conv([View(second)], self.v2.weight, self.v2.bias, self._s1)
+            p2 = ops.softmax_rows(ops.gram(c2, v2, self.scale))
+            o2 = ops.attn_apply(p2, v2, residual=View(r1))
         xs_new = ops.conv([View(c1), View(c2)], self.unclustering.weight, self.unclustering.bias, self._s2,
                           residual=View(xs))
         return o1, o2, xs_new
