@@ -79,10 +79,21 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
 #endif
     // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ... ; the load pipeline runs ahead of the
     // MFMA pipeline across tile boundaries, so only the very first tile of a workgroup pays load latency.
+    // XCD-aware tile walk: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an L2), so give each
+    // XCD one contiguous eighth of the tile list and let its workgroups sweep it side by side -- neighbouring tiles
+    // (shared halo rows/columns) then meet in the same L2 while hot.  Speed only; any placement is correct.
     const int ntiles = a.ntiles;
-    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    constexpr int NX_ = 8;
+    const bool xcd_map = (gridDim.x % NX_) == 0 && ntiles >= (int)gridDim.x;
+    const int xcd = blockIdx.x % NX_, xj = blockIdx.x / NX_, per_x = gridDim.x / NX_;
+    const int t_lo = xcd_map ? (int)((long long)ntiles * xcd / NX_) : 0;
+    const int t_hi = xcd_map ? (int)((long long)ntiles * (xcd + 1) / NX_) : ntiles;
+    const int t_first = xcd_map ? t_lo + xj : (int)blockIdx.x;
+    const int t_stride = xcd_map ? per_x : (int)gridDim.x;
+    const int my_tiles = t_first < t_hi ? (t_hi - t_first + t_stride - 1) / t_stride : 0;
     const int nsteps = a.nchunks * TAPS;
     const int total_steps = my_tiles * nsteps, total_chunks = my_tiles * a.nchunks;
+    if (my_tiles == 0) return;   // block-uniform
     const long long wstep = (long long)a.Coutpad * CK;
 
     auto decode = [&](int tile, int& b, int& y0, int& x0, int& nt) {
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
     const int q4 = (tid & 3) * 4;
 
     // ---- X loader: walks (tile, chunk) in consumption order
-    int xl_tile = blockIdx.x, xl_chunk = 0, xl_b = 0, s_idx = 0, c_in = 0;
+    int xl_tile = t_first, xl_chunk = 0, xl_b = 0, s_idx = 0, c_in = 0;
     const float* sbase = nullptr;   // current source: batch base pointer, pixel stride, channel count
     int spix = 0, snch = 0;
     auto src_select = [&]() {
@@ -130,8 +141,8 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
         }
         c_in += CK;
         if (++xl_chunk == a.nchunks) {
-            xl_tile += gridDim.x;
-            if (xl_tile < ntiles) xl_setup(xl_tile);
+            xl_tile += t_stride;
+            if (xl_tile < t_hi) xl_setup(xl_tile);
         } else if (c_in >= snch) {
             c_in = 0; ++s_idx;
             src_select();
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
         }
     };
     // ---- W loader: walks (tile, step)
-    int wl_tile = blockIdx.x, wl_step = 0;
+    int wl_tile = t_first, wl_step = 0;
     const float* wl_base = nullptr;
     auto wl_setup = [&](int tile) {
         int b, y0, x0, nt;
@@ -162,8 +173,8 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
             if (e < BN * 4) wr[n] = *reinterpret_cast<const f32x4*>(p + e * 4);
         }
         if (++wl_step == nsteps) {
-            wl_tile += gridDim.x;
-            if (wl_tile < ntiles) wl_setup(wl_tile);
+            wl_tile += t_stride;
+            if (wl_tile < t_hi) wl_setup(wl_tile);
         }
     };
     auto store_w = [&](int buf) {
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
 
     if constexpr (TAPS == 1) {
         // one step per 16-channel chunk; X tiles come from HBM, so their loads run LX steps ahead (register ring)
-        int tile = blockIdx.x, cc = 0;
+        int tile = t_first, cc = 0;
         for (int base = 0; base < total_steps; base += LX) {
 #pragma unroll
             for (int d = 0; d < LX; ++d) {
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
                     mfma16(af1, bf1);
                     if (++cc == a.nchunks) {
                         epilogue(tile);
-                        tile += gridDim.x;
+                        tile += t_stride;
                         cc = 0;
                     }
                 }
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
         }
     } else {
         int gs = 0, gc = 0;   // global step / chunk counters of this workgroup (LDS buffer parity)
-        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int tile = t_first; tile < t_hi; tile += t_stride) {
             for (int c = 0; c < a.nchunks; ++c, ++gc) {
                 const float* const xb = Xb + (gc & 1) * XBUF;
 #pragma unroll
