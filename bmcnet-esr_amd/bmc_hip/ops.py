@@ -217,18 +217,31 @@ def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stri
     _prof_end(e0, "conv_kernel<%d,%d>" % (taps, 32 if a.Coutpad == 32 else 128), flops)
 
 
+_ZEROS = {}
+
+
+def _zeros(device):
+    z = _ZEROS.get(device)
+    if z is None:
+        z = torch.zeros(64, device=device, dtype=torch.float32)
+        _ZEROS[device] = z
+    return z
+
+
 def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, device, flops=0.0):
     """Returns (slabs, nsplit, G)."""
     G = B // bpg
     mpad, npad = round_up(M, 32), round_up(N, 32)
-    if taps == 9:
-        n_nblk = npad // 32
+    if taps == 9:       # LDS-DMA kernel: one 8-wave workgroup per CU, 64 columns per workgroup
+        n_nblk = (npad + 63) // 64
         tiles = ((H + 3) // 4) * ((W + 15) // 16)
-    else:
+        target = 256
+    else:               # register-prefetch kernel: two 4-wave workgroups per CU, 128 columns per workgroup
         n_nblk = (npad + 127) // 128
         tiles = (H * W + 63) // 64
+        target = 512
     other = G * ((mpad + 127) // 128) * n_nblk
-    nsplit = max(1, min(bpg * tiles, 512 // max(other, 1)))   # 2 resident workgroups per CU
+    nsplit = max(1, min(bpg * tiles, target // max(other, 1)))
     slabs = torch.empty(nsplit * G * taps * mpad * npad, device=device, dtype=torch.float32)
     p = lib.PgemmArgs()
     p.a = a_src
@@ -239,6 +252,7 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
     p.batch_per_group = bpg
     p.slabs = slabs.data_ptr()
     p.nsplit = nsplit
+    p.zeros = _zeros(device).data_ptr()
     e0 = _prof_begin()
     lib.call(lib._pgemm, "bmc_pgemm", C.byref(p), _stream())
     _prof_end(e0, "pgemm_kernel<%d>" % taps, flops)

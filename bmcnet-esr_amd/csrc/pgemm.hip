@@ -26,6 +26,7 @@ struct PgemmK {
     int batch_per_group;
     float* slabs;
     int nsplit;
+    const float* zeros;
     int M, Mpad, N, Npad;
     int n_nblk, n_mblk, G;
     int tiles_x, tiles_y, tiles_per_img;
@@ -185,6 +186,109 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const PgemmK a) {
     }
 }
 
+// 3x3 weight gradient, LDS-DMA variant: ONE 8-wave workgroup per CU owns 128 rows x 64 columns x 9 taps
+// (wave = 32 x 32 x 9 taps, 144 accumulator registers).  Both tiles are double-buffered in LDS and filled by
+// global_load_lds_dwordx4 (no staging registers, no ds_write): the fill of tile t+1 is in flight under the 288 MFMAs
+// per wave of tile t, one barrier per tile.  The LDS images are lane-linear ([px][128] and [halo px][64]); pixels outside
+// the image (and channels beyond M / N) are sourced from a small zero buffer.
+__global__ __launch_bounds__(512, 2) void pgemm9_dma_kernel(const PgemmK a) {
+    constexpr int HWD = PT_W + 2, HHT = PT_H + 2, NHALO = HWD * HHT;   // 18 x 6 = 108
+    constexpr int XCH = 64;                                            // columns (input channels) per block
+    constexpr int BUF = 2048 * 4;                                      // floats per LDS buffer (2048 float4)
+    __shared__ __attribute__((aligned(16))) float lds[4 * BUF];        // A[2], X[2]  (128 KB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int mw = wave & 3, nw = wave >> 2;
+
+    int bid = blockIdx.x;
+    const int split = bid % a.nsplit; bid /= a.nsplit;
+    const int nb = bid % a.n_nblk; bid /= a.n_nblk;
+    const int mb = bid % a.n_mblk;
+    const int g = bid / a.n_mblk;
+    const int m0 = mb * 128, n0 = nb * XCH;
+    const bool wave_active = m0 + 32 * mw < a.Mpad;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int ntiles = a.batch_per_group * a.tiles_per_img;
+    auto issue = [&](int tile, int buf) {
+        const int bb = tile / a.tiles_per_img, tin = tile - bb * a.tiles_per_img;
+        const int b = g * a.batch_per_group + bb;
+        const int y0 = (tin / a.tiles_x) * PT_H, x0 = (tin % a.tiles_x) * PT_W;
+        const float* ab = src_batch_ptr(a.a, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {            // A tile: [64 px][128 ch]
+            const int e = i * 512 + tid, p = e >> 5, c4 = (e & 31) * 4;
+            const int y = y0 + (p >> 4), x = x0 + (p & 15);
+            const float* src = a.zeros;
+            if (y < a.H && x < a.W && m0 + c4 < a.M) src = ab + ((long long)y * a.W + x) * a.a.pix_stride + m0 + c4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + buf * BUF + (i * 512 + wave * 64) * 4),
+                                             16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {            // X halo tile: [108 px][64 ch] (+ padding lanes)
+            const int e = i * 512 + tid, hp = e >> 4, c4 = (e & 15) * 4;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            int ch = n0 + c4;
+            const float* src = a.zeros;
+            if (hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W && ch < a.N) {
+                SrcDev S = a.src[0];
+#pragma unroll
+                for (int si = 1; si < BMC_MAX_SRC; ++si)
+                    if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; }
+                src = src_batch_ptr(S, b) + ((long long)y * a.W + x) * S.pix_stride + ch;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + (2 + buf) * BUF + (i * 512 + wave * 64) * 4),
+                                             16, 0, 0);
+        }
+    };
+
+    if (split < ntiles) issue(split, 0);
+    __syncthreads();
+    int it = 0;
+    for (int tile = split; tile < ntiles; tile += a.nsplit, ++it) {
+        const int cur = it & 1;
+        const int next = tile + a.nsplit;
+        if (next < ntiles) issue(next, cur ^ 1);
+        if (wave_active) {
+            const float* const ap = lds + cur * BUF + lh * 128 + 32 * mw + li;
+            const float* const xp = lds + (2 + cur) * BUF + lh * XCH + 32 * nw + li;
+#pragma unroll
+            for (int q = 0; q < PT / 2; ++q) {
+                const float av = ap[2 * q * 128];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int off = (((q >> 3) + tap / 3) * HWD + 2 * (q & 7) + tap % 3) * XCH;
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xp[off], acc[tap], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();    // drains the DMA of the next tile (vmcnt) and fences this tile's LDS reads
+    }
+
+    if (wave_active) {
+        float* const sl = a.slabs + (((long long)split * a.G + g) * 9) * a.Mpad * a.Npad;
+        const int n = n0 + 32 * nw + li;
+        if (n < a.Npad) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + 32 * mw + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    sl[((long long)tap * a.Mpad + m) * a.Npad + n] = acc[tap][r];
+                }
+        }
+    }
+}
+
 // Slab reductions: 32 outputs x 8 split-parts per 256-thread block (each part sums every 8th split, then a fixed
 // order LDS tree) -- deterministic, and short even when nsplit is in the hundreds.
 __device__ __forceinline__ float split_sum(const float* p, long long slab, int nsplit, float* red) {
@@ -273,17 +377,18 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
         } else k.src[i] = to_dev(h->src[0]);
     }
     k.B = h->B; k.H = h->H; k.W = h->W; k.batch_per_group = h->batch_per_group;
-    k.slabs = h->slabs; k.nsplit = h->nsplit;
+    k.slabs = h->slabs; k.nsplit = h->nsplit; k.zeros = h->zeros;
     k.M = h->a.nch; k.Mpad = bmc_round_up(k.M, 32); k.N = N; k.Npad = bmc_round_up(N, 32);
     k.G = h->B / h->batch_per_group;
     k.n_mblk = (k.Mpad + 127) / 128;
     hipStream_t st = (hipStream_t)stream;
     if (h->taps == 9) {
-        k.n_nblk = k.Npad / 32;
+        BMC_CHECK_ARG(h->zeros != nullptr, "bmc_pgemm: taps == 9 needs the zero buffer");
+        k.n_nblk = (k.Npad + 63) / 64;
         k.tiles_x = (h->W + PT_W - 1) / PT_W; k.tiles_y = (h->H + PT_H - 1) / PT_H;
         k.tiles_per_img = k.tiles_x * k.tiles_y;
         dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * k.nsplit));
-        hipLaunchKernelGGL((pgemm_kernel<9, 1>), grid, dim3(256), 0, st, k);
+        hipLaunchKernelGGL(pgemm9_dma_kernel, grid, dim3(512), 0, st, k);
     } else {
         k.n_nblk = (k.Npad + 127) / 128;
         k.tiles_x = k.tiles_y = 0;
