@@ -236,10 +236,10 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
         n_nblk = (npad + 63) // 64
         tiles = ((H + 3) // 4) * ((W + 15) // 16)
         target = 256
-    else:               # register-prefetch kernel: two 4-wave workgroups per CU, 128 columns per workgroup
+    else:               # same kernel family, 128 columns per workgroup
         n_nblk = (npad + 127) // 128
         tiles = (H * W + 63) // 64
-        target = 512
+        target = 256
     other = G * ((mpad + 127) // 128) * n_nblk
     nsplit = max(1, min(bpg * tiles, target // max(other, 1)))
     slabs = torch.empty(nsplit * G * taps * mpad * npad, device=device, dtype=torch.float32)

@@ -3,20 +3,15 @@
 // = the weight gradient of a 3x3 / 1x1 convolution (A = dY, src = the conv inputs),
 // and the channel Gram matrix center . v^T of the BIE block (and its backward).
 //
-// The reduction axis is the pixel axis, so both MFMA operands are read
-// "k-major" straight from NHWC tiles in LDS (lane i -> channel i: conflict-free
-// ds_read_b32).  A workgroup (4 waves) owns 128 rows (m) x NT*32 columns (n) x
-// TAPS taps of the output and loops over its share of pixel tiles, accumulating
-// in registers (TAPS*NT 32x32 tiles per wave); the 9 taps re-use one A fragment
-// and read the X halo tile at 9 constant LDS offsets.  Partial sums of the
-// `nsplit` pixel splits go to slabs and are summed by a second kernel in a fixed
-// order (deterministic, no float atomics).
+// The reduction axis is the pixel axis, so both MFMA operands are read "k-major" straight from NHWC tiles in LDS
+// (lane i -> channel i: conflict-free ds_read_b32); the 9 taps re-use one A fragment and read the X halo tile at 9
+// constant LDS offsets.  Pixel tiles (4x16 / 64 flat pixels) are dealt round-robin to `nsplit` splits; partial sums
+// go to slabs and are summed by a second kernel in a fixed order (deterministic, no float atomics).
 #include "bmc_common.h"
 
 namespace {
 
 constexpr int PT_H = 4, PT_W = 16, PT = PT_H * PT_W;  // 64-pixel tile
-constexpr int AS = 128;                                // LDS row stride of the A tile
 
 struct PgemmK {
     SrcDev a;
@@ -32,170 +27,22 @@ struct PgemmK {
     int tiles_x, tiles_y, tiles_per_img;
 };
 
-template <int TAPS, int NT>
-__global__ __launch_bounds__(256, 2) void pgemm_kernel(const PgemmK a) {
-    constexpr int P = TAPS == 9 ? 1 : 0;
-    constexpr int HWD = PT_W + 2 * P, HHT = PT_H + 2 * P;
-    constexpr int NHALO = TAPS == 9 ? HWD * HHT : PT;
-    constexpr int NB = 32 * NT;  // columns per block
-    constexpr int XS = NB;       // LDS row stride of the X tile
-    __shared__ __attribute__((aligned(16))) float lds[PT * AS + NHALO * XS];
-    float* const At = lds;
-    float* const Xt = lds + PT * AS;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-
-    int bid = blockIdx.x;
-    const int split = bid % a.nsplit; bid /= a.nsplit;
-    const int nb = bid % a.n_nblk; bid /= a.n_nblk;
-    const int mb = bid % a.n_mblk;
-    const int g = bid / a.n_mblk;
-    const int m0 = mb * 128, n0 = nb * NB;
-    const bool wave_active = m0 + 32 * wave < a.Mpad;
-
-    f32x16 acc[TAPS * NT];
-#pragma unroll
-    for (int t = 0; t < TAPS * NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    const int ntiles = a.batch_per_group * a.tiles_per_img;
-    const int HWp = a.H * a.W;
-    constexpr int NA = PT * 32 / 256;                       // float4 per thread for the A tile
-    constexpr int F4_PER_PX = NB / 4;
-    constexpr int NX = (NHALO * F4_PER_PX + 255) / 256;     // float4 per thread for the X tile
-    f32x4 ar[NA], xr[NX];
-
-    // global -> registers for one pixel tile (issued one tile ahead, under the MFMAs of the current tile)
-    auto gload = [&](int tile) {
-        const int bb = tile / a.tiles_per_img, tin = tile - bb * a.tiles_per_img;
-        const int b = g * a.batch_per_group + bb;
-        int y0 = 0, x0 = 0, p0 = 0;
-        if (TAPS == 9) { y0 = (tin / a.tiles_x) * PT_H; x0 = (tin % a.tiles_x) * PT_W; }
-        else p0 = tin * PT;
-        const float* ab = src_batch_ptr(a.a, b);
-#pragma unroll
-        for (int n = 0; n < NA; ++n) {
-            const int e = tid + 256 * n, p = e >> 5, c4 = (e & 31) * 4;
-            long long pix;
-            bool ok;
-            if (TAPS == 9) {
-                const int y = y0 + (p >> 4), x = x0 + (p & 15);
-                ok = y < a.H && x < a.W;
-                pix = (long long)y * a.W + x;
-            } else {
-                pix = p0 + p;
-                ok = pix < HWp;
-            }
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok && m0 + c4 < a.M) v = *reinterpret_cast<const f32x4*>(ab + pix * a.a.pix_stride + m0 + c4);
-            ar[n] = v;
-        }
-#pragma unroll
-        for (int n = 0; n < NX; ++n) {
-            const int e = tid + 256 * n, hp = e / F4_PER_PX, c4 = (e - hp * F4_PER_PX) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (hp < NHALO) {
-                long long pix;
-                bool ok;
-                if (TAPS == 9) {
-                    const int hy = hp / HWD, hx = hp - hy * HWD;
-                    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-                    ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
-                    pix = (long long)y * a.W + x;
-                } else {
-                    pix = p0 + hp;
-                    ok = pix < HWp;
-                }
-                int ch = n0 + c4;   // channel -> source
-                if (ok && ch < a.N) {
-                    SrcDev S = a.src[0];
-#pragma unroll
-                    for (int si = 1; si < BMC_MAX_SRC; ++si)
-                        if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; }
-                    v = *reinterpret_cast<const f32x4*>(src_batch_ptr(S, b) + pix * S.pix_stride + ch);
-                }
-            }
-            xr[n] = v;
-        }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int n = 0; n < NA; ++n) {
-            const int e = tid + 256 * n, p = e >> 5, c4 = (e & 31) * 4;
-            *reinterpret_cast<f32x4*>(At + p * AS + c4) = ar[n];
-        }
-#pragma unroll
-        for (int n = 0; n < NX; ++n) {
-            const int e = tid + 256 * n, hp = e / F4_PER_PX, c4 = (e - hp * F4_PER_PX) * 4;
-            if (hp < NHALO) *reinterpret_cast<f32x4*>(Xt + hp * XS + c4) = xr[n];
-        }
-    };
-
-    if (split < ntiles) {
-        gload(split);
-        lstore();
-    }
-    __syncthreads();
-    for (int tile = split; tile < ntiles; tile += a.nsplit) {
-        const int next = tile + a.nsplit;
-        if (next < ntiles) gload(next);
-        if (wave_active) {
-            const float* const ap = At + lh * AS + 32 * wave + li;
-            const float* const xp = Xt + lh * XS + li;
-#pragma unroll
-            for (int q = 0; q < PT / 2; ++q) {
-                const float av = ap[2 * q * AS];
-#pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap) {
-#pragma unroll
-                    for (int u = 0; u < NT; ++u) {
-                        int off;
-                        if (TAPS == 9) off = (((q >> 3) + tap / 3) * HWD + 2 * (q & 7) + tap % 3) * XS;
-                        else off = 2 * q * XS + 32 * u;
-                        acc[tap * NT + u] =
-                            __builtin_amdgcn_mfma_f32_32x32x2f32(av, xp[off], acc[tap * NT + u], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (next < ntiles) {
-            lstore();
-            __syncthreads();
-        }
-    }
-
-    // ---- write this split's partial tile: slabs[split][g][tap][Mpad][Npad]
-    if (wave_active) {
-        float* const sl = a.slabs + (((long long)split * a.G + g) * TAPS) * a.Mpad * a.Npad;
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap)
-#pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                const int n = n0 + 32 * u + li;
-                if (n < a.Npad) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        sl[((long long)tap * a.Mpad + m) * a.Npad + n] = acc[tap * NT + u][r];
-                    }
-                }
-            }
-    }
-}
-
-// 3x3 weight gradient, LDS-DMA variant: ONE 8-wave workgroup per CU owns 128 rows x 64 columns x 9 taps
-// (wave = 32 x 32 x 9 taps, 144 accumulator registers).  Both tiles are double-buffered in LDS and filled by
-// global_load_lds_dwordx4 (no staging registers, no ds_write): the fill of tile t+1 is in flight under the 288 MFMAs
-// per wave of tile t, one barrier per tile.  The LDS images are lane-linear ([px][128] and [halo px][64]); pixels outside
-// the image (and channels beyond M / N) are sourced from a small zero buffer.
-__global__ __launch_bounds__(512, 2) void pgemm9_dma_kernel(const PgemmK a) {
-    constexpr int HWD = PT_W + 2, HHT = PT_H + 2, NHALO = HWD * HHT;   // 18 x 6 = 108
-    constexpr int XCH = 64;                                            // columns (input channels) per block
-    constexpr int BUF = 2048 * 4;                                      // floats per LDS buffer (2048 float4)
-    __shared__ __attribute__((aligned(16))) float lds[4 * BUF];        // A[2], X[2]  (128 KB)
+// LDS-DMA pixel-reduction GEMM: ONE 8-wave workgroup per CU.
+//   TAPS = 9: 128 rows x 64 columns x 9 taps per workgroup (wave = 32 x 32 x 9 taps, 144 accumulator registers);
+//   TAPS = 1: 128 rows x 128 columns              (wave = 32 x 64, 32 accumulator registers).
+// Both operand tiles are double-buffered in LDS and filled by global_load_lds_dwordx4 (no staging registers, no
+// ds_write): the fill of pixel tile t+1 is in flight under the MFMAs of tile t, one barrier per tile.  The LDS images
+// are lane-linear ([px][128] for A, [halo px][64] or [px][128] for X); pixels outside the image and channels beyond
+// M / N are sourced from a small zero buffer.
+template <int TAPS>
+__global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
+    constexpr int HWD = PT_W + 2, HHT = PT_H + 2;
+    constexpr int NHALO = TAPS == 9 ? HWD * HHT : PT;                   // 108 halo pixels or 64 pixels
+    constexpr int XCH = TAPS == 9 ? 64 : 128;                           // columns per workgroup
+    constexpr int NT = TAPS == 9 ? 1 : 2;                               // 32-column tiles per wave
+    constexpr int XSH = TAPS == 9 ? 4 : 5;                              // log2(float4 per X row)
+    constexpr int BUF = 2048 * 4;                                       // floats per LDS buffer (2048 float4)
+    __shared__ __attribute__((aligned(16))) float lds[4 * BUF];         // A[2], X[2]  (128 KB)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -208,10 +55,11 @@ __global__ __launch_bounds__(512, 2) void pgemm9_dma_kernel(const PgemmK a) {
     const int g = bid / a.n_mblk;
     const int m0 = mb * 128, n0 = nb * XCH;
     const bool wave_active = m0 + 32 * mw < a.Mpad;
+    const int HWp = a.H * a.W;
 
-    f32x16 acc[9];
+    f32x16 acc[TAPS * NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < TAPS * NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -219,31 +67,51 @@ __global__ __launch_bounds__(512, 2) void pgemm9_dma_kernel(const PgemmK a) {
     auto issue = [&](int tile, int buf) {
         const int bb = tile / a.tiles_per_img, tin = tile - bb * a.tiles_per_img;
         const int b = g * a.batch_per_group + bb;
-        const int y0 = (tin / a.tiles_x) * PT_H, x0 = (tin % a.tiles_x) * PT_W;
+        int y0 = 0, x0 = 0, p0 = 0;
+        if (TAPS == 9) { y0 = (tin / a.tiles_x) * PT_H; x0 = (tin % a.tiles_x) * PT_W; }
+        else p0 = tin * PT;
         const float* ab = src_batch_ptr(a.a, b);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {            // A tile: [64 px][128 ch]
             const int e = i * 512 + tid, p = e >> 5, c4 = (e & 31) * 4;
-            const int y = y0 + (p >> 4), x = x0 + (p & 15);
+            long long pix;
+            bool ok;
+            if (TAPS == 9) {
+                const int y = y0 + (p >> 4), x = x0 + (p & 15);
+                ok = y < a.H && x < a.W;
+                pix = (long long)y * a.W + x;
+            } else {
+                pix = p0 + p;
+                ok = pix < HWp;
+            }
             const float* src = a.zeros;
-            if (y < a.H && x < a.W && m0 + c4 < a.M) src = ab + ((long long)y * a.W + x) * a.a.pix_stride + m0 + c4;
+            if (ok && m0 + c4 < a.M) src = ab + pix * a.a.pix_stride + m0 + c4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(lds + buf * BUF + (i * 512 + wave * 64) * 4),
                                              16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {            // X halo tile: [108 px][64 ch] (+ padding lanes)
-            const int e = i * 512 + tid, hp = e >> 4, c4 = (e & 15) * 4;
-            const int hy = hp / HWD, hx = hp - hy * HWD;
-            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        for (int i = 0; i < 4; ++i) {            // X tile: [108 halo px][64 ch] (+ padding lanes) or [64 px][128 ch]
+            const int e = i * 512 + tid, hp = e >> XSH, c4 = (e & ((1 << XSH) - 1)) * 4;
+            long long pix;
+            bool ok;
+            if (TAPS == 9) {
+                const int hy = hp / HWD, hx = hp - hy * HWD;
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                ok = hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W;
+                pix = (long long)y * a.W + x;
+            } else {
+                pix = p0 + hp;
+                ok = pix < HWp;
+            }
             int ch = n0 + c4;
             const float* src = a.zeros;
-            if (hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W && ch < a.N) {
+            if (ok && ch < a.N) {
                 SrcDev S = a.src[0];
 #pragma unroll
                 for (int si = 1; si < BMC_MAX_SRC; ++si)
                     if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; }
-                src = src_batch_ptr(S, b) + ((long long)y * a.W + x) * S.pix_stride + ch;
+                src = src_batch_ptr(S, b) + pix * S.pix_stride + ch;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(lds + (2 + buf) * BUF + (i * 512 + wave * 64) * 4),
@@ -260,32 +128,39 @@ __global__ __launch_bounds__(512, 2) void pgemm9_dma_kernel(const PgemmK a) {
         if (next < ntiles) issue(next, cur ^ 1);
         if (wave_active) {
             const float* const ap = lds + cur * BUF + lh * 128 + 32 * mw + li;
-            const float* const xp = lds + (2 + cur) * BUF + lh * XCH + 32 * nw + li;
+            const float* const xp = lds + (2 + cur) * BUF + lh * XCH + 32 * NT * nw + li;
 #pragma unroll
             for (int q = 0; q < PT / 2; ++q) {
                 const float av = ap[2 * q * 128];
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int off = (((q >> 3) + tap / 3) * HWD + 2 * (q & 7) + tap % 3) * XCH;
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xp[off], acc[tap], 0, 0, 0);
-                }
+                for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) {
+                        int off;
+                        if (TAPS == 9) off = (((q >> 3) + tap / 3) * HWD + 2 * (q & 7) + tap % 3) * XCH;
+                        else off = 2 * q * XCH + 32 * u;
+                        acc[tap * NT + u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xp[off], acc[tap * NT + u], 0, 0, 0);
+                    }
             }
         }
         __syncthreads();    // drains the DMA of the next tile (vmcnt) and fences this tile's LDS reads
     }
 
     if (wave_active) {
-        float* const sl = a.slabs + (((long long)split * a.G + g) * 9) * a.Mpad * a.Npad;
-        const int n = n0 + 32 * nw + li;
-        if (n < a.Npad) {
+        float* const sl = a.slabs + (((long long)split * a.G + g) * TAPS) * a.Mpad * a.Npad;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
+        for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + 32 * mw + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    sl[((long long)tap * a.Mpad + m) * a.Npad + n] = acc[tap][r];
+            for (int u = 0; u < NT; ++u) {
+                const int n = n0 + 32 * NT * nw + 32 * u + li;
+                if (n < a.Npad) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + 32 * mw + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        sl[((long long)tap * a.Mpad + m) * a.Npad + n] = acc[tap * NT + u][r];
+                    }
                 }
-        }
+            }
     }
 }
 
@@ -363,6 +238,7 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
     BMC_CHECK_ARG(h->taps == 1 || h->taps == 9, "bmc_pgemm: taps must be 1 or 9");
     BMC_CHECK_ARG(h->batch_per_group >= 1 && h->B % h->batch_per_group == 0, "bmc_pgemm: B %% batch_per_group != 0");
     BMC_CHECK_ARG(h->nsplit >= 1 && h->slabs, "bmc_pgemm: nsplit/slabs");
+    BMC_CHECK_ARG(h->zeros != nullptr, "bmc_pgemm: the zero buffer is required");
     BMC_CHECK_ARG(h->a.ptr && h->a.nch > 0 && h->a.nch % 4 == 0 && h->a.pix_stride % 4 == 0, "bmc_pgemm: bad A operand");
     PgemmK k;
     k.a = to_dev(h->a);
@@ -383,18 +259,17 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
     k.n_mblk = (k.Mpad + 127) / 128;
     hipStream_t st = (hipStream_t)stream;
     if (h->taps == 9) {
-        BMC_CHECK_ARG(h->zeros != nullptr, "bmc_pgemm: taps == 9 needs the zero buffer");
         k.n_nblk = (k.Npad + 63) / 64;
         k.tiles_x = (h->W + PT_W - 1) / PT_W; k.tiles_y = (h->H + PT_H - 1) / PT_H;
         k.tiles_per_img = k.tiles_x * k.tiles_y;
         dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * k.nsplit));
-        hipLaunchKernelGGL(pgemm9_dma_kernel, grid, dim3(512), 0, st, k);
+        hipLaunchKernelGGL(pgemm_dma_kernel<9>, grid, dim3(512), 0, st, k);
     } else {
         k.n_nblk = (k.Npad + 127) / 128;
         k.tiles_x = k.tiles_y = 0;
         k.tiles_per_img = (h->H * h->W + PT - 1) / PT;
         dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * k.nsplit));
-        hipLaunchKernelGGL((pgemm_kernel<1, 4>), grid, dim3(256), 0, st, k);
+        hipLaunchKernelGGL(pgemm_dma_kernel<1>, grid, dim3(512), 0, st, k);
     }
     BMC_CHECK_LAUNCH("bmc_pgemm");
     return 0;

@@ -115,7 +115,7 @@ typedef struct bmc_pgemm_args {
     int batch_per_group;
     float* slabs;
     int nsplit;
-    const float* zeros;         /* >= 64 bytes of zeros in device memory (source for out-of-image LDS-DMA lanes), taps 9 */
+    const float* zeros;         /* >= 64 bytes of zeros in device memory (source for out-of-image LDS-DMA lanes) */
 } bmc_pgemm_args_t;
 int bmc_pgemm(const bmc_pgemm_args_t* host_args, bmc_stream_t s);
 /* slabs -> dW[Cout][Cin][taps] (nn.Conv2d layout) through kmap; beta 0/1 = overwrite/accumulate */
