@@ -334,7 +334,7 @@ class ConvFn(torch.autograd.Function):
             a_src = _src(g, 0, Cout, 0, None, 0, B)
             slabs, nsplit, _ = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
                                          flops=2.0 * B * H * W * Cout * taps * spec.cin)
-            dwf = torch.zeros(G * Cout * spec.cin * taps, device=dev, dtype=torch.float32)
+            dwf = torch.empty(G * Cout * spec.cin * taps, device=dev, dtype=torch.float32)   # every (co, ci, tap) is written
             lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, G, taps, Cout, spec.kpad,
                      spec.kmap(dev).data_ptr(), spec.cin, dwf.data_ptr(), 0, _stream())
             dw = dwf.view(weight.shape)
@@ -422,7 +422,7 @@ def _wgrad_plain(g, x, spec, weight_shape, taps):
     slabs, nsplit, _ = pgemm_raw(_src(g, 0, Cout, 0, None, 0, B), [_src(x, 0, x.shape[3], 0, None, 0, B)], B, H, W, taps, B,
                                  Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.cin)
     db = colsum(g.data_ptr(), B * H * W, Cout, Cout, dev).view(1, Cout)
-    dw = torch.zeros(Cout * spec.cin * taps, device=dev, dtype=torch.float32)
+    dw = torch.empty(Cout * spec.cin * taps, device=dev, dtype=torch.float32)
     lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, 1, taps, Cout, spec.kpad,
              spec.kmap(dev).data_ptr(), spec.cin, dw.data_ptr(), 0, _stream())
     return dw.view(weight_shape), db[0]

@@ -1,0 +1,45 @@
+"""Streaming single-GPU inference with the reference's semantics (infer_BMCNet.py:20-103):
+the recurrent state (h, h_p, h_n, previous HR prediction) is created once and carried across calls, every call
+runs one window under no_grad, and the per-window latency is measured with events on the launch stream exactly
+where the reference puts its `starter/ender` pair (infer_BMCNet.py:54,66-68)."""
+import torch
+
+
+class StreamingSR:
+    def __init__(self, model, n_c=128, scale=4, plain=False):
+        self.model = model.eval()
+        self.n_c, self.scale, self.plain = n_c, scale, plain
+        self.state = None
+        self.times_ms = []
+
+    def reset(self):
+        self.state = None
+        self.times_ms = []
+
+    @torch.no_grad()
+    def step(self, x, timed=True):
+        """x [B,2,T>=2,H,W] on the GPU (inp_cnt.transpose(1,2) of the reference) -> HR prediction [B,2,sH,sW]."""
+        B, _, _, H, W = x.shape
+        start = end = None
+        if timed:
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+        if self.state is None:
+            z = lambda c: torch.zeros(B, c, H, W, device=x.device)
+            if self.plain:
+                out = self.model(x, z(self.n_c), z(2 * self.scale ** 2), True)
+            else:
+                out = self.model(x, z(self.n_c), z(self.n_c), z(self.n_c), z(2 * self.scale ** 2), True)
+        else:
+            out = self.model(x, *self.state, False)
+        self.state = tuple(out)
+        if timed:
+            end.record()
+            end.synchronize()
+            self.times_ms.append(start.elapsed_time(end))
+        return out[-1]
+
+    def latency_ms(self, skip=1):
+        """Mean per-window latency (the reference's `time` metric), ignoring the first `skip` windows."""
+        t = self.times_ms[skip:] or self.times_ms
+        return sum(t) / max(len(t), 1)

@@ -360,3 +360,21 @@ def test_packed_weight_cache_is_not_fooled_by_recycled_addresses():
         del w
     for o, r in zip(outs, refs):
         assert rel_l2(o, r) < 2e-5
+
+
+def test_streaming_inference_matches_training_forward():
+    """infer.StreamingSR (no_grad, state carried across calls, infer_BMCNet.py:45-64 semantics) must reproduce the
+    golden recurrent predictions."""
+    dev = _gpu()
+    from models.BMCNet import BMCNet
+    from infer import StreamingSR
+    z = load("bmcnet_nc16.npz")
+    scale, n_c, n_b, B, H, W, nwin = (int(v) for v in z["meta"])
+    m = BMCNet(scale, n_c, n_b); _load_sd(m, z); m.to(dev)
+    sr = StreamingSR(m, n_c=n_c, scale=scale)
+    frames = torch.tensor(z["frames"])
+    for i in range(nwin):
+        pred = sr.step(frames[:, i:i + 2].transpose(1, 2).to(dev))
+        assert not pred.requires_grad
+        assert rel_l2(pred, z[f"pred{i}"]) < 1e-4
+    assert len(sr.times_ms) == nwin and sr.latency_ms() > 0
