@@ -689,3 +689,21 @@ def events_to_channels_batched(xs, ys, ps, offsets, H, W, mutate=True):
     lib.call(lib._events, "bmc_events_to_channels", xs.data_ptr(), ys.data_ptr(), ps.data_ptr(), offsets.data_ptr(),
              nframes, H, W, out.data_ptr(), int(mutate), _stream())
     return out
+
+
+def encode_raw_events(xs_i16, ys_i16, ps_f64, offsets, flips, H, W):
+    """Raw dataset columns (int16, int16, float64 device vectors) + per-frame flip flags (uint8 or None)
+    -> [nframes,2,H,W] count images; see bmc_encode_raw_events."""
+    for t, dt in ((xs_i16, torch.int16), (ys_i16, torch.int16), (ps_f64, torch.float64), (offsets, torch.int64)):
+        if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+            raise RuntimeError("encode_raw_events: expected contiguous %s tensors on the GPU (no CPU fallback)" % dt)
+    nframes = offsets.numel() - 1
+    out = torch.empty((nframes, 2, H, W), device=xs_i16.device, dtype=torch.float32)
+    fp = None
+    if flips is not None:
+        if flips.dtype != torch.uint8 or not flips.is_cuda or flips.numel() != nframes:
+            raise RuntimeError("encode_raw_events: flips must be a uint8 GPU vector with one entry per frame")
+        fp = flips.data_ptr()
+    lib.call(lib._enc_raw, "bmc_encode_raw_events", xs_i16.data_ptr(), ys_i16.data_ptr(), ps_f64.data_ptr(),
+             offsets.data_ptr(), fp, nframes, H, W, out.data_ptr(), _stream())
+    return out

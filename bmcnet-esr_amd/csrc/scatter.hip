@@ -31,7 +31,47 @@ __global__ void events_kernel(float* __restrict__ xs, float* __restrict__ ys, co
     }
 }
 
+// Raw HDF5 columns (generate_dataset/tools/event_packagers.py:128-156: xs/ys int16, ps float64) -> count images, with
+// the dataset's flip augmentation (dataloader/h5dataset.py:559-578) folded into the index arithmetic:
+// flags bit0: x = W-1-x, bit1: y = H-1-y, bit2: p = -p; then event_formatting's float32 cast
+// (dataloader/base_dataset.py:24-31) and the events_to_channels() semantics above.
+__global__ void encode_raw_kernel(const short* __restrict__ xs, const short* __restrict__ ys, const double* __restrict__ ps,
+                                  const long long* __restrict__ offsets, const unsigned char* __restrict__ flips, int H, int W,
+                                  float* __restrict__ out) {
+    const int f = blockIdx.y;
+    const long long e0 = offsets[f], e1 = offsets[f + 1];
+    const int fl = flips ? flips[f] : 0;
+    float* const img = out + (long long)f * 2 * H * W;
+    for (long long e = e0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += (long long)gridDim.x * blockDim.x) {
+        double xd = (double)xs[e], yd = (double)ys[e], pd = ps[e];
+        if (fl & 1) xd = (double)(W - 1) - xd;
+        if (fl & 2) yd = (double)(H - 1) - yd;
+        if (fl & 4) pd = pd * -1.0;
+        float x = (float)xd, y = (float)yd;
+        const float p = (float)pd;
+        const bool oob = (x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f);
+        if (oob) { x = 0.f; y = 0.f; }
+        const int xi = (int)x, yi = H - (int)y - 1;
+        const float wpos = (!oob && p > 0.f) ? p * p : 0.f;
+        const float wneg = p < 0.f ? p * p : 0.f;
+        if (wpos != 0.f) atomicAdd(img + (long long)yi * W + xi, wpos);
+        if (wneg != 0.f) atomicAdd(img + (long long)H * W + (long long)yi * W + xi, wneg);
+    }
+}
+
 }  // namespace
+
+extern "C" int bmc_encode_raw_events(const short* xs, const short* ys, const double* ps, const long long* offsets,
+                                     const unsigned char* flips, int nframes, int H, int W, float* out, bmc_stream_t s) {
+    BMC_CHECK_ARG(nframes >= 0 && H > 0 && W > 0 && out, "bmc_encode_raw_events: bad shape");
+    hipStream_t st = (hipStream_t)s;
+    if (nframes == 0) return 0;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)nframes * 2 * H * W * sizeof(float), st);
+    if (e != hipSuccess) { bmc_set_error("bmc_encode_raw_events: memset failed: %s", hipGetErrorString(e)); return -2; }
+    hipLaunchKernelGGL(encode_raw_kernel, dim3(64, nframes), dim3(256), 0, st, xs, ys, ps, offsets, flips, H, W, out);
+    BMC_CHECK_LAUNCH("bmc_encode_raw_events");
+    return 0;
+}
 
 extern "C" int bmc_events_to_channels(float* xs, float* ys, const float* ps, const long long* offsets, int nframes, int H,
                                       int W, float* out, int mutate, bmc_stream_t s) {

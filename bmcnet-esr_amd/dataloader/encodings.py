@@ -24,3 +24,32 @@ def events_to_channels(xs, ys, ps, sensor_size=(180, 240)):
 def events_to_channels_batch(xs, ys, ps, offsets, sensor_size=(180, 240), mutate=True):
     """Many frames in one launch: frame f owns events [offsets[f], offsets[f+1]) -> [nframes,2,H,W]."""
     return ops.events_to_channels_batched(xs, ys, ps, offsets, int(sensor_size[0]), int(sensor_size[1]), mutate=mutate)
+
+
+def augment_flags(seed, mechanisms=("Horizontal", "Vertical", "Polarity"), probs=(0.5, 0.5, 0.5)):
+    """Flip decisions of H5Dataset.augment_event (dataloader/h5dataset.py:559-578) for one sample seed, as the bit
+    flags bmc_encode_raw_events takes (bit0 horizontal, bit1 vertical, bit2 polarity).  Same seeding as the reference:
+    random.seed(seed), seed+1, seed+2 for H / V / P, one random.random() draw each; the caller's `random` state is
+    left as the reference leaves it (re-seeded)."""
+    import random
+    flags = 0
+    for i, mech in enumerate(mechanisms):
+        if mech == "Horizontal":
+            random.seed(seed)
+            if random.random() < probs[i]:
+                flags |= 1
+        elif mech == "Vertical":
+            random.seed(seed + 1)
+            if random.random() < probs[i]:
+                flags |= 2
+        elif mech == "Polarity":
+            random.seed(seed + 2)
+            if random.random() < probs[i]:
+                flags |= 4
+    return flags
+
+
+def raw_events_to_channels_batch(xs_i16, ys_i16, ps_f64, offsets, flips=None, sensor_size=(180, 240)):
+    """GPU sequence encoder on raw HDF5 columns (int16 x/y, float64 p) with the flip augmentation folded in:
+    replaces get_events -> augment_event -> event_formatting -> events_to_channels of the CPU workers."""
+    return ops.encode_raw_events(xs_i16, ys_i16, ps_f64, offsets, flips, int(sensor_size[0]), int(sensor_size[1]))

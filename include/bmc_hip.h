@@ -59,6 +59,14 @@ const char* bmc_last_error(void);
 int bmc_events_to_channels(float* xs, float* ys, const float* ps, const long long* offsets,
                            int nframes, int H, int W, float* out, int mutate, bmc_stream_t s);
 
+/* Sequence encoder on raw dataset columns: what H5Dataset.__getitem__ does per frame on the CPU
+ * (dataloader/h5dataset.py:261-316: get_events :407-414 -> augment_event :559-578 -> event_formatting
+ * base_dataset.py:24-31 -> events_to_channels), for all frames of a batch in one launch.
+ * xs/ys int16, ps float64 (generate_dataset/tools/event_packagers.py:128-156); flips[f] bit0 horizontal
+ * (x = W-1-x), bit1 vertical (y = H-1-y), bit2 polarity (p = -p); flips NULL = no augmentation. */
+int bmc_encode_raw_events(const short* xs, const short* ys, const double* ps, const long long* offsets,
+                          const unsigned char* flips, int nframes, int H, int W, float* out, bmc_stream_t s);
+
 /* ---- weight packing ------------------------------------------------------
  * Conv weights [G][Cout][Cin][taps] (taps = kh*kw = 1 or 9; nn.Conv2d layout)
  * -> MFMA staging layout [G][Kpad/16][taps][Coutpad][16] where packed input

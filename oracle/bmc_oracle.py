@@ -67,6 +67,37 @@ def events_to_channels_np(xs, ys, ps, sensor_size=(180, 240)):
     return out, xs, ys
 
 
+def encode_raw_frame_np(xs_i16, ys_i16, ps_f64, flags, sensor_size):
+    """One dataset item's count image from raw HDF5 columns: get_events (dataloader/h5dataset.py:407-414, the
+    int16/float64 columns are concatenated into ONE float64 array), augment_event (:559-578, flips in float64),
+    event_formatting (dataloader/base_dataset.py:24-31, float32 cast), then events_to_channels.
+    flags: bit0 horizontal, bit1 vertical, bit2 polarity."""
+    H, W = int(sensor_size[0]), int(sensor_size[1])
+    xs = np.asarray(xs_i16, np.int16).astype(np.float64)
+    ys = np.asarray(ys_i16, np.int16).astype(np.float64)
+    ps = np.asarray(ps_f64, np.float64).copy()
+    if flags & 1:
+        xs = W - 1 - xs
+    if flags & 2:
+        ys = H - 1 - ys
+    if flags & 4:
+        ps = ps * -1
+    img, _, _ = events_to_channels_np(xs.astype(np.float32), ys.astype(np.float32), ps.astype(np.float32), (H, W))
+    return img
+
+
+def augment_flags(seed, mechanisms=("Horizontal", "Vertical", "Polarity"), probs=(0.5, 0.5, 0.5)):
+    """Which flips H5Dataset.augment_event applies for a sample seed (dataloader/h5dataset.py:559-578)."""
+    import random
+    flags = 0
+    for i, mech in enumerate(mechanisms):
+        bit, s = {"Horizontal": (1, seed), "Vertical": (2, seed + 1), "Polarity": (4, seed + 2)}[mech]
+        random.seed(s)
+        if random.random() < probs[i]:
+            flags |= bit
+    return flags
+
+
 # --------------------------------------------------------------------------
 # building blocks (models/submodules.py)
 # --------------------------------------------------------------------------

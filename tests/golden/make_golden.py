@@ -224,8 +224,57 @@ def gen_adam():
     np.savez_compressed(os.path.join(OUT, "adam.npz"), **out)
 
 
+# ---------------------------------------------------------------- raw dataset columns + flip augmentation
+def gen_raw_events():
+    """Runs the reference's per-item CPU chain on raw int16/float64 columns: H5Dataset.augment_event
+    (dataloader/h5dataset.py:559-578) -> BaseDataset.event_formatting (base_dataset.py:24-31) ->
+    H5Dataset.create_cnt_encoding (h5dataset.py:518-526) -> events_to_channels.  h5py / cv2 are stubbed: they are
+    imported by dataloader/h5dataset.py but not touched by these methods."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    for name in ("h5py", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    plt.style.use = lambda *a, **k: None          # 'seaborn-whitegrid' no longer exists (h5dataset.py:15)
+    from dataloader.h5dataset import H5Dataset
+    rng = np.random.default_rng(77)
+    out = {}
+    fake = types.SimpleNamespace(config={"data_augment": {"enabled": True,
+                                                         "augment": ["Horizontal", "Vertical", "Polarity"],
+                                                         "augment_prob": [0.5, 0.5, 0.5]}})
+    cases = [("lr", (45, 80), 2048), ("odd", (17, 23), 700), ("hr", (180, 320), 32768)]
+    seeds = [0, 1, 2, 3, 4, 5, 7, 22, 2 ** 31 + 5]      # 0..22 cover all 8 flip combinations
+    idx = 0
+    for tag, (H, W), n in cases:
+        for seed in (seeds if n < 10000 else seeds[:2]):
+            xs = rng.integers(-2, W + 2, n).astype(np.int16)       # a few out-of-range coordinates
+            ys = rng.integers(-2, H + 2, n).astype(np.int16)
+            ts = np.sort(rng.uniform(0, 1, n))
+            ps = rng.choice([-1.0, 1.0], n).astype(np.float64)
+            ev = np.concatenate((xs[None], ys[None], ts[None], ps[None]), axis=0)          # get_events layout (:407-414)
+            aug = H5Dataset.augment_event(fake, ev, (H, W), seed)
+            fm = H5Dataset.event_formatting(aug)
+            cnt = H5Dataset.create_cnt_encoding(fake, fm, (H, W))
+            k = f"c{idx}"
+            out[k + "/xs"], out[k + "/ys"], out[k + "/ps"] = xs, ys, ps
+            out[k + "/size"], out[k + "/seed"] = np.asarray((H, W)), np.asarray(seed, np.int64)
+            out[k + "/cnt"] = cnt.numpy()
+            fl = 0      # which flips happened, recovered from the augmented arrays (data, not code)
+            if not np.array_equal(aug[0], xs.astype(np.float64)): fl |= 1
+            if not np.array_equal(aug[1], ys.astype(np.float64)): fl |= 2
+            if not np.array_equal(aug[3], ps): fl |= 4
+            out[k + "/flags"] = np.asarray(fl, np.int64)
+            idx += 1
+    out["n"] = np.asarray(idx)
+    np.savez_compressed(os.path.join(OUT, "events_raw.npz"), **out)
+
+
 if __name__ == "__main__":
+    if os.environ.get("BMC_GOLDEN_ONLY") == "raw":
+        gen_raw_events()
+        sys.exit(0)
     gen_events()
+    gen_raw_events()
     gen_layers()
     gen_model("bmcnet_nc16", BMCNet, 16, 2, 2, 10, 12, 3, seed=21, plain=False, wscale=0.6)
     gen_model("plain_nc16", BMCNet_plain, 16, 2, 2, 9, 7, 3, seed=22, plain=True)

@@ -378,3 +378,28 @@ def test_streaming_inference_matches_training_forward():
         assert not pred.requires_grad
         assert rel_l2(pred, z[f"pred{i}"]) < 1e-4
     assert len(sr.times_ms) == nwin and sr.latency_ms() > 0
+
+
+def test_raw_column_sequence_encoder_bit_exact():
+    """bmc_encode_raw_events (int16/int16/float64 columns + flip flags, all frames in one launch) vs the reference's
+    CPU chain get_events -> augment_event -> event_formatting -> events_to_channels (golden) -- bit-exact."""
+    dev = _gpu()
+    from dataloader.encodings import augment_flags, raw_events_to_channels_batch
+    z = load("events_raw.npz")
+    n = int(z["n"])
+    by_size = {}
+    for i in range(n):
+        by_size.setdefault(tuple(int(v) for v in z[f"c{i}/size"]), []).append(i)
+    for size, idxs in by_size.items():
+        xs = torch.tensor(np.concatenate([z[f"c{i}/xs"] for i in idxs]), device=dev)
+        ys = torch.tensor(np.concatenate([z[f"c{i}/ys"] for i in idxs]), device=dev)
+        ps = torch.tensor(np.concatenate([z[f"c{i}/ps"] for i in idxs]), device=dev)
+        off = torch.tensor(np.concatenate([[0], np.cumsum([len(z[f"c{i}/xs"]) for i in idxs])]), dtype=torch.int64, device=dev)
+        flips = torch.tensor([augment_flags(int(z[f"c{i}/seed"])) for i in idxs], dtype=torch.uint8, device=dev)
+        out = raw_events_to_channels_batch(xs, ys, ps, off, flips, size).cpu().numpy()
+        for j, i in enumerate(idxs):
+            assert np.array_equal(out[j], z[f"c{i}/cnt"]), (size, i)
+        # no augmentation == flags 0
+        out0 = raw_events_to_channels_batch(xs, ys, ps, off, None, size)
+        outz = raw_events_to_channels_batch(xs, ys, ps, off, torch.zeros_like(flips), size)
+        assert torch.equal(out0, outz)

@@ -171,3 +171,26 @@ def test_adam_amsgrad():
         O.adam_amsgrad_step(ws, [torch.tensor(z[f"g{step}_{i}"]) for i in range(2)], st)
         for i in range(2):
             assert np.abs(ws[i].numpy() - z[f"w_after{step}_{i}"]).max() < 1e-7
+
+
+def test_raw_column_encoder_and_augmentation_flags():
+    """Raw int16/float64 columns + flip augmentation (dataloader/h5dataset.py:261-316 chain) vs the reference."""
+    z = load("events_raw.npz")
+    n = int(z["n"])
+    seen = set()
+    for i in range(n):
+        k = f"c{i}"
+        size = tuple(int(v) for v in z[k + "/size"])
+        flags = O.augment_flags(int(z[k + "/seed"]))
+        assert flags == int(z[k + "/flags"]), k
+        seen.add(flags)
+        img = O.encode_raw_frame_np(z[k + "/xs"], z[k + "/ys"], z[k + "/ps"], flags, size)
+        assert np.array_equal(img, z[k + "/cnt"]), k
+    assert seen == set(range(8))   # every flip combination exercised
+
+
+def test_product_augment_flags_match_reference_seeding():
+    from dataloader.encodings import augment_flags
+    z = load("events_raw.npz")
+    for i in range(int(z["n"])):
+        assert augment_flags(int(z[f"c{i}/seed"])) == int(z[f"c{i}/flags"])
