@@ -66,7 +66,6 @@ _pgemm = _sig("bmc_pgemm", [C.POINTER(PgemmArgs), _p])
 _red_w = _sig("bmc_pgemm_reduce_weight", [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p])
 _red_p = _sig("bmc_pgemm_reduce_plain", [_p, _i, _i, _i, _i, _f, _p, _p])
 _colsum = _sig("bmc_colsum", [_p, _ll, _i, _i, _p, _p, _i, _p])
-_colsum_b = _sig("bmc_colsum_batched", [_p, _i, _ll, _ll, _i, _i, _p, _p, _p])
 _relu_bwd = _sig("bmc_relu_bwd", [_p, _p, _p, _ll, _p])
 _ln_fwd = _sig("bmc_layernorm_fwd", [_p, _p, _p, _ll, _i, _f, _p, _p, _p])
 _ln_bwd = _sig("bmc_layernorm_bwd", [_p, _p, _p, _p, _ll, _i, _p, _p, _p, _p, _i, _p])
@@ -77,7 +76,7 @@ _unshuffle = _sig("bmc_unshuffle_to_nhwc", [_p, _i, _i, _i, _i, _i, _p, _p])
 _shuffle = _sig("bmc_shuffle_to_hr", [_p, _i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _ll, _p, _p])
 
 EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_encode_raw_events", "bmc_pack_weight", "bmc_pack_weight_t", "bmc_conv",
-           "bmc_pgemm", "bmc_pgemm_reduce_weight", "bmc_pgemm_reduce_plain", "bmc_colsum", "bmc_colsum_batched", "bmc_relu_bwd",
+           "bmc_pgemm", "bmc_pgemm_reduce_weight", "bmc_pgemm_reduce_plain", "bmc_colsum", "bmc_relu_bwd",
            "bmc_layernorm_fwd", "bmc_layernorm_bwd", "bmc_softmax_fwd", "bmc_softmax_bwd", "bmc_pack_inputs",
            "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr"]
 

@@ -599,120 +599,6 @@ def softmax_rows(a):
     return SoftmaxFn.apply(a)
 
 
-def colsum_batched(x, G):
-    """x [nb,H,W,C] -> [G,C]: column sums over the pixels of each of G equal batch groups."""
-    nb, H, W, Cn = x.shape
-    npix = (nb // G) * H * W
-    ws = torch.empty(G * 256 * Cn, device=x.device, dtype=torch.float32)
-    out = torch.empty((G, Cn), device=x.device, dtype=torch.float32)
-    lib.call(lib._colsum_b, "bmc_colsum_batched", x.data_ptr(), G, npix, npix * Cn, Cn, Cn, ws.data_ptr(), out.data_ptr(),
-             _stream())
-    return out
-
-
-def _pixel_gram(a, x):
-    """[nb,H,W,Ca], [nb,H,W,Cx] -> [nb,Ca,Cx]: per-sample sum over pixels of a_i * x_k (pgemm + fixed-order reduce)."""
-    nb, H, W, Ca = a.shape
-    Cx = x.shape[3]
-    slabs, nsplit, G = pgemm_raw(_src(a, 0, Ca, 0, None, 0, nb), [_src(x, 0, Cx, 0, None, 0, nb)], nb, H, W, 1, 1, Ca, Cx,
-                                 a.device, flops=2.0 * nb * H * W * Ca * Cx)
-    out = torch.empty((nb, Ca, Cx), device=a.device, dtype=torch.float32)
-    lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Ca, Cx, 1.0, out.data_ptr(), _stream())
-    return out
-
-
-def _persample_conv1x1(x, w_s, bias_s, out=None, residual: Optional[lib.Src] = None):
-    """out[b,px,i] = sum_k w_s[b,i,k] x[b,px,k] + bias_s[b,i] (+ residual): 1x1 conv with one weight matrix per sample."""
-    nb, H, W, Cx = x.shape
-    Co = w_s.shape[1]
-    spec = _dense_spec(Cx)
-    wp = _packed_weight(w_s.contiguous().view(nb, Co, Cx, 1), spec, None)
-    if out is None:
-        out = torch.empty((nb, H, W, Co), device=x.device, dtype=torch.float32)
-    conv_raw([_src(x, 0, Cx, 0, None, 0, nb)], wp, spec.kpad * coutpad(Co), bias_s.contiguous() if bias_s is not None else None,
-             Co, out.data_ptr(), H * W * Co, Co, nb, H, W, Co, 1, residual=residual, bpg=1, flops=2.0 * nb * H * W * Co * Cx)
-    return out
-
-
-class AttentionFn(torch.autograd.Function):
-    """One attention branch of the BIE block (models/submodules.py:63-73):
-           center = Wc y + bc  (clustering of the LayerNorm output y),   v = Wv x + bv  (value projection),
-           att = scale * center v^T  [C,C per sample],   out = softmax(att) v  (+ residual)
-    with BOTH 1x1 projections folded into the two big contractions instead of being materialised:
-           Gy[i',k] = sum_px y_i' x_k                      one pixel-reduction GEMM over (y, x)
-           att = scale * ((Wc Gy + bc xsum^T) Wv^T + (Wc ysum + npix bc) bv^T)
-           out = (P Wv) x + P bv                           one 1x1 conv with per-sample weights
-    Mathematically identical (fp32 re-association only).  It removes the clustering and value convolutions, their
-    data/weight gradients and the stored center / v tensors.  The [C,C]-sized algebra per sample is a small PyTorch
-    graph (batched matmuls + softmax) differentiated by autograd inside backward."""
-
-    @staticmethod
-    def _small(Gy, ysum, xsum, wc, bc, wv, bv, scale, npix, nb):
-        Gc, Gv = wc.shape[0], wv.shape[0]
-        wc_s = wc.repeat_interleave(nb // Gc, 0)                                       # [nb, i, i']
-        bc_s = bc.repeat_interleave(nb // Gc, 0)                                       # [nb, i]
-        wv_s = wv.repeat_interleave(nb // Gv, 0)                                       # [nb, j, k]
-        bv_s = bv.repeat_interleave(nb // Gv, 0)                                       # [nb, j]
-        G = torch.baddbmm(bc_s.unsqueeze(2) * xsum.unsqueeze(1), wc_s, Gy)             # [nb, i, k]
-        csum = torch.bmm(wc_s, ysum.unsqueeze(2)).squeeze(2) + npix * bc_s             # [nb, i]
-        att = torch.baddbmm(csum.unsqueeze(2) * bv_s.unsqueeze(1), G, wv_s.transpose(1, 2)) * scale
-        p = torch.softmax(att, dim=-1)
-        return torch.bmm(p, wv_s), torch.bmm(p, bv_s.unsqueeze(2)).squeeze(2)         # W' [nb,i,k], b' [nb,i]
-
-    @staticmethod
-    def forward(ctx, y, x, wc, bc, wv, bv, res_t, scale, res_shift, res_mod):
-        _need_gpu(y)
-        y, x = y.contiguous(), x.contiguous()
-        nb, H, W, Cn = y.shape
-        yd, xd = y.detach(), x.detach()
-        leaves = [_pixel_gram(yd, xd).requires_grad_(), colsum_batched(yd, nb).requires_grad_(),
-                  colsum_batched(xd, nb).requires_grad_()]
-        prm = [t.detach().reshape(s).requires_grad_() for t, s in
-               ((wc, (-1, Cn, Cn)), (bc, (-1, Cn)), (wv, (-1, Cn, Cn)), (bv, (-1, Cn)))]
-        with torch.enable_grad():
-            wp, bp = AttentionFn._small(*leaves, *prm, scale, float(H * W), nb)
-        res = _src(res_t.detach(), 0, Cn, res_shift, res_mod, 0, nb) if res_t is not None else None
-        out = _persample_conv1x1(xd, wp.detach(), bp.detach(), residual=res)
-        ctx.save_for_backward(y, x)
-        ctx.small = (leaves, prm, wp, bp)
-        ctx.meta = (res_shift, res_mod, res_t is not None, wc.shape, bc.shape, wv.shape, bv.shape)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        y, x = ctx.saved_tensors
-        leaves, prm, wp, bp = ctx.small
-        ctx.small = None
-        res_shift, res_mod, has_res, wc_shape, bc_shape, wv_shape, bv_shape = ctx.meta
-        g = dout.contiguous()
-        nb, H, W, Cn = g.shape
-        need = ctx.needs_input_grad
-        dwp = _pixel_gram(g, x)                                                       # [nb, i, k]
-        dbp = colsum_batched(g, nb)                                                   # [nb, i]
-        dGy, dysum, dxsum, dwc, dbc, dwv, dbv = torch.autograd.grad([wp, bp], leaves + prm, [dwp, dbp])
-        dy = dx = dres = None
-        if need[0]:     # dy[px,i'] = sum_k dGy[i',k] x[px,k] + dysum[i']
-            dy = _persample_conv1x1(x, dGy, dysum)
-        if need[1]:     # dx[px,k] = sum_i W'[i,k] g[px,i] + sum_i' dGy[i',k] y[px,i'] + dxsum[k]
-            dx1 = _persample_conv1x1(g, wp.detach().transpose(1, 2), None)
-            dx = _persample_conv1x1(y, dGy.transpose(1, 2), dxsum, residual=_src(dx1, 0, Cn, 0, None, 0, nb))
-        if has_res and need[6]:
-            dres = g
-            if res_mod is not None and res_mod < nb:
-                dres = g.view(nb // res_mod, res_mod, H, W, Cn).sum(0)
-            elif res_shift:
-                dres = torch.roll(g, shifts=res_shift, dims=0)
-        return (dy, dx, dwc.reshape(wc_shape) if need[2] else None, dbc.reshape(bc_shape) if need[3] else None,
-                dwv.reshape(wv_shape) if need[4] else None, dbv.reshape(bv_shape) if need[5] else None, dres, None, None, None)
-
-
-def attention(y, x, wc, bc, wv, bv, scale, residual: Optional[View] = None):
-    """y: LayerNorm output feeding the clustering conv (wc [Gc,C,C], bc [Gc,C]); x: input of the value conv
-    (wv [Gv,C,C], bv [Gv,C]); Gc / Gv weight groups over the batch (1, or 2 for the twin launch)."""
-    res_t, shift, mod = (residual.t, residual.shift, residual.mod) if residual is not None else (None, 0, None)
-    return AttentionFn.apply(y, x, wc, bc, wv, bv, res_t, scale, shift, mod)
-
-
 def attn_apply(p, v, residual: Optional[View] = None):
     """out[b,px,i] = sum_j p[b,i,j] v[b,px,j] (+ residual) -- torch.bmm(softmax, v^T) of models/submodules.py:72-73
     as a 1x1 convolution with one weight matrix per sample."""

@@ -326,51 +326,6 @@ extern "C" int bmc_relu_bwd(const float* dy, const float* y, float* g, long long
     return 0;
 }
 
-// G independent column sums (one per batch group) in one pair of launches: blockIdx.y = group
-__global__ void colsum_b_stage1(const float* __restrict__ x, long long npix, long long group_stride, int pix_stride, int C,
-                                float* __restrict__ ws) {
-    const float* xg = x + (long long)blockIdx.y * group_stride;
-    const int c = threadIdx.x % C, pl = threadIdx.x / C, npl = blockDim.x / C;
-    float s = 0.f;
-    if (pl < npl)
-        for (long long p = (long long)blockIdx.x * npl + pl; p < npix; p += (long long)gridDim.x * npl)
-            s += xg[p * pix_stride + c];
-    __shared__ float red[1024];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < C) {
-        float t = 0.f;
-        for (int k = 0; k < npl; ++k) t += red[k * C + threadIdx.x];
-        ws[((long long)blockIdx.y * gridDim.x + blockIdx.x) * C + threadIdx.x] = t;
-    }
-}
-__global__ void colsum_b_stage2(const float* __restrict__ ws, int nblk, int C, float* __restrict__ out) {
-    const int c = blockIdx.x, g = blockIdx.y;
-    float s = 0.f;
-    for (int b = threadIdx.x; b < nblk; b += blockDim.x) s += ws[((long long)g * nblk + b) * C + c];
-    __shared__ float red[256];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[(long long)g * C + c] = red[0];
-}
-
-extern "C" int bmc_colsum_batched(const float* x, int G, long long npix, long long group_stride, int pix_stride, int C,
-                                  float* ws, float* out, bmc_stream_t s) {
-    BMC_CHECK_ARG(C >= 1 && C <= 1024 && G >= 1, "bmc_colsum_batched: bad C/G");
-    const int threads = C <= 256 ? 256 : 1024;
-    const int npl = threads / C;
-    int nblk = nblocks(npix, npl * 16);
-    if (nblk > 256) nblk = 256;          // ws >= G * 256 * C floats
-    hipLaunchKernelGGL(colsum_b_stage1, dim3(nblk, G), dim3(threads), 0, (hipStream_t)s, x, npix, group_stride, pix_stride, C, ws);
-    hipLaunchKernelGGL(colsum_b_stage2, dim3(C, G), dim3(256), 0, (hipStream_t)s, ws, nblk, C, out);
-    BMC_CHECK_LAUNCH("bmc_colsum_batched");
-    return 0;
-}
-
 extern "C" int bmc_colsum(const float* x, long long npix, int pix_stride, int C, float* ws, float* out, int accumulate,
                           bmc_stream_t s) {
     BMC_CHECK_ARG(C >= 1 && C <= 1024, "bmc_colsum: C=%d out of range", C);

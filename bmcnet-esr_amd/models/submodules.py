@@ -101,55 +101,43 @@ class BIE(nn.Module):
         self._s1 = ConvSpec.dense(nf)
         self._s2 = ConvSpec.dense(nf, nf)
 
-    def _normed(self, views, B):
-        """LayerNorm(convf(cat[...])): the input of the clustering conv.  clustering itself (a 1x1 conv) is never
-        launched: it is folded into the attention contraction and into the unclustering weights (ops.AttentionFn)."""
+    def _centre(self, views, B):
         z = ops.conv(views, self.convf1.weight, self.convf1.bias, self._s2, B=B)
-        return self.norm_s.forward_nhwc(z)
-
-    def _unclustering_folded(self):
-        """unclustering(cat[c1, c2]) with c_i = Wc y_i + bc  ==  [Wu_a Wc | Wu_b Wc] cat[y1, y2] + (Wu_a + Wu_b) bc + bu.
-        The composed [C, 2C] weight is a tiny parameter-space product (autograd routes its gradient to both convs)."""
-        nf = self.nf
-        wu = self.unclustering.weight.view(nf, 2 * nf)
-        wc = self.clustering.weight.view(nf, nf)
-        w_eff = torch.cat([wu[:, :nf] @ wc, wu[:, nf:] @ wc], 1).view(nf, 2 * nf, 1, 1)
-        b_eff = (wu[:, :nf] + wu[:, nf:]) @ self.clustering.bias + self.unclustering.bias
-        return w_eff, b_eff
+        z = self.norm_s.forward_nhwc(z)
+        return ops.conv([View(z)], self.clustering.weight, self.clustering.bias, self._s1)
 
     def forward_pair(self, first, second, xs, need_second=True):
         """need_second=False skips everything that only feeds the second output (o2 = softmax(att2) v2 + Res(first)):
         the last ParallelBlk of the backbone discards it (models/BMCNet.py:75-82 never reads x*_st after the loop)."""
         B = first.shape[0]
         r2 = self.conv1.forward_nhwc(second)
-        y1 = self._normed([View(xs), View(second)], B)
-        y2 = self._normed([View(xs), View(first)], B)
-        nf = self.nf
-        wc, bc = self.clustering.weight.view(1, nf, nf), self.clustering.bias.view(1, nf)
-        o1 = ops.attention(y1, first, wc, bc, self.v1.weight.view(1, nf, nf), self.v1.bias.view(1, nf), self.scale,
-                           residual=View(r2))
+        c1 = self._centre([View(xs), View(second)], B)
+        c2 = self._centre([View(xs), View(first)], B)
+        v1 = ops.conv([View(first)], self.v1.weight, self.v1.bias, self._s1)
+        p1 = ops.softmax_rows(ops.gram(c1, v1, self.scale))
+        o1 = ops.attn_apply(p1, v1, residual=View(r2))
         o2 = None
         if need_second:
             r1 = self.conv1.forward_nhwc(first)
-            o2 = ops.attention(y2, second, wc, bc, self.v2.weight.view(1, nf, nf), self.v2.bias.view(1, nf), self.scale,
-                               residual=View(r1))
-        w_eff, b_eff = self._unclustering_folded()
-        xs_new = ops.conv([View(y1), View(y2)], w_eff, b_eff, self._s2, residual=View(xs), cache=False)
+            v2 = ops.conv([View(second)], self.v2.weight, self.v2.bias, self._s1)
+            p2 = ops.softmax_rows(ops.gram(c2, v2, self.scale))
+            o2 = ops.attn_apply(p2, v2, residual=View(r1))
+        xs_new = ops.conv([View(c1), View(c2)], self.unclustering.weight, self.unclustering.bias, self._s2,
+                          residual=View(xs))
         return o1, o2, xs_new
 
     def forward_twin(self, x12, xs):
         B2 = x12.shape[0]
         B = B2 // 2
         r12 = self.conv1.forward_nhwc(x12)                                          # [r1; r2]
-        y12 = self._normed([View(xs, mod=B), View(x12, shift=B, mod=B2)], B2)       # [y1; y2]
-        nf = self.nf
-        vw = torch.stack([self.v1.weight.view(nf, nf), self.v2.weight.view(nf, nf)])   # value projections of the two halves
+        c12 = self._centre([View(xs, mod=B), View(x12, shift=B, mod=B2)], B2)       # [c1; c2]
+        vw = torch.stack([self.v1.weight, self.v2.weight])
         vb = torch.stack([self.v1.bias, self.v2.bias])
-        o12 = ops.attention(y12, x12, self.clustering.weight.view(1, nf, nf), self.clustering.bias.view(1, nf), vw, vb,
-                            self.scale, residual=View(r12, shift=B, mod=B2))        # [o1 + r2; o2 + r1]
-        w_eff, b_eff = self._unclustering_folded()
-        xs_new = ops.conv([View(y12, b0=0), View(y12, b0=B)], w_eff, b_eff, self._s2, B=B, residual=View(xs),
-                          cache=False)
+        v12 = ops.conv([View(x12)], vw, vb, self._s1, G=2, cache=False)             # [v1(first); v2(second)]
+        p12 = ops.softmax_rows(ops.gram(c12, v12, self.scale))
+        o12 = ops.attn_apply(p12, v12, residual=View(r12, shift=B, mod=B2))         # [o1 + r2; o2 + r1]
+        xs_new = ops.conv([View(c12, b0=0), View(c12, b0=B)], self.unclustering.weight, self.unclustering.bias,
+                          self._s2, B=B, residual=View(xs))
         return o12, xs_new
 
     def forward(self, x_1, x_2, x_s):

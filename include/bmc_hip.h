@@ -137,10 +137,6 @@ int bmc_pgemm_reduce_plain(const float* slabs, int nsplit, int G, int M, int N, 
 /* column sums over pixels (bias gradients): out[c] (+)= sum_p x[p*pix_stride + c]; ws >= 2048*C floats */
 int bmc_colsum(const float* x, long long npix, int pix_stride, int C, float* ws, float* out,
                int accumulate, bmc_stream_t s);
-/* G independent column sums (per-sample sums for the attention bias terms): out[g][c] = sum_p x[g*group_stride + p*pix_stride + c];
- * ws >= G*256*C floats */
-int bmc_colsum_batched(const float* x, int G, long long npix, long long group_stride, int pix_stride, int C,
-                       float* ws, float* out, bmc_stream_t s);
 /* ReLU backward: g = y > 0 ? dy : 0 (F.relu at models/BMCNet.py:64-80, submodules.py:33) */
 int bmc_relu_bwd(const float* dy, const float* y, float* g, long long n, bmc_stream_t s);
 /* LayerNorm2d over channels per pixel: models/submodules.py:127-140 (fwd), :141-154 (bwd).

@@ -403,3 +403,61 @@ def test_raw_column_sequence_encoder_bit_exact():
         out0 = raw_events_to_channels_batch(xs, ys, ps, off, None, size)
         outz = raw_events_to_channels_batch(xs, ys, ps, off, torch.zeros_like(flips), size)
         assert torch.equal(out0, outz)
+
+
+# ------------------------------------------------------------------ BASELINE.json full sizes (C2: 180x240, n_c=128)
+def test_full_size_conv3x3_vs_oracle_and_linearity():
+    """The dominant launch shape at full size: 3x3 128->128 over the doubled twin batch (2B = 8, 180x240), against
+    the CPU oracle (F.conv2d) on two samples, plus linearity conv(a*x1 + b*x2) = a*conv(x1) + b*conv(x2) on all."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from bmc_hip.ops import ConvSpec, View
+    g = torch.Generator().manual_seed(0)
+    B, H, W, Cn = 8, 180, 240, 128
+    x1 = torch.randn(B, H, W, Cn, generator=g)
+    x2 = torch.randn(B, H, W, Cn, generator=g)
+    w = torch.randn(Cn, Cn, 3, 3, generator=g) / (9 * Cn) ** 0.5
+    b = torch.randn(Cn, generator=g)
+    spec = ConvSpec.dense(Cn)
+    wg, bg = w.to(dev), b.to(dev)
+    with torch.no_grad():
+        y1 = ops.conv([View(x1.to(dev))], wg, bg, spec)
+        y2 = ops.conv([View(x2.to(dev))], wg, bg, spec)
+        y12 = ops.conv([View((0.5 * x1 - 2.0 * x2).to(dev))], wg, None, spec)
+        lin = 0.5 * (y1 - bg) - 2.0 * (y2 - bg)
+        assert rel_l2(y12, lin) < 1e-5
+        for s in (0, 7):
+            ref = F.conv2d(x1[s:s + 1].permute(0, 3, 1, 2), w, b, padding=1)
+            assert rel_l2(y1[s:s + 1].permute(0, 3, 1, 2), ref) < 1e-5
+
+
+def test_full_size_window_forward_vs_oracle():
+    """One full-size recurrent window pair (B=1, 180x240 -> 720x960, n_c=128, n_b=5) through the HIP path vs the CPU
+    oracle: SR tensor within 1e-4 rel-L2 (the bar BASELINE.json states)."""
+    dev = _gpu()
+    from models.BMCNet import BMCNet
+    from oracle import bmc_oracle as O
+    torch.manual_seed(3407)
+    scale, n_c, n_b, H, W = 4, 128, 5, 180, 240
+    m = BMCNet(scale, n_c, n_b)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(3.0)                         # make every branch matter (the 0.1-scaled init is nearly linear)
+    params, seen = {}, {}
+    for k, v in m.state_dict().items():
+        params[k] = seen.setdefault(v.data_ptr(), v.clone())
+    frames = torch.poisson(torch.full((1, 3, 2, H, W), 0.284))
+    z = lambda c: torch.zeros(1, c, H, W)
+    with torch.no_grad():
+        h, hp, hn, pred = z(n_c), z(n_c), z(n_c), z(2 * scale * scale)
+        ref = []
+        for i in range(2):
+            h, hp, hn, pred = O.bmcnet_forward(params, frames[:, i:i + 2].transpose(1, 2), h, hp, hn, pred, i == 0, scale)
+            ref.append(pred)
+        m.to(dev)
+        zz = lambda c: torch.zeros(1, c, H, W, device=dev)
+        h, hp, hn, pred = zz(n_c), zz(n_c), zz(n_c), zz(2 * scale * scale)
+        for i in range(2):
+            h, hp, hn, pred = m(frames[:, i:i + 2].transpose(1, 2).to(dev), h, hp, hn, pred, i == 0)
+            assert pred.shape == (1, 2, 720, 960)
+            assert rel_l2(pred, ref[i]) < 1e-4, i
