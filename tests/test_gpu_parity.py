@@ -432,8 +432,11 @@ def test_full_size_conv3x3_vs_oracle_and_linearity():
 
 
 def test_full_size_window_forward_vs_oracle():
-    """One full-size recurrent window pair (B=1, 180x240 -> 720x960, n_c=128, n_b=5) through the HIP path vs the CPU
-    oracle: SR tensor within 1e-4 rel-L2 (the bar BASELINE.json states)."""
+    """Two full-size recurrent windows (B=1, 180x240 -> 720x960, n_c=128, n_b=5) through the HIP path vs the CPU
+    oracle evaluated in float64 (so the comparison measures OUR fp32 error, not the sum of two fp32 paths):
+    SR tensor within 1e-4 rel-L2 (the bar BASELINE.json states).  Weights are scaled x3 so every branch matters
+    (the 0.1-scaled init is nearly linear); that also makes the second, state-carrying window ill-conditioned --
+    the float32 oracle itself sits at ~7e-5 from float64 there."""
     dev = _gpu()
     from models.BMCNet import BMCNet
     from oracle import bmc_oracle as O
@@ -442,17 +445,17 @@ def test_full_size_window_forward_vs_oracle():
     m = BMCNet(scale, n_c, n_b)
     with torch.no_grad():
         for p in m.parameters():
-            p.mul_(3.0)                         # make every branch matter (the 0.1-scaled init is nearly linear)
+            p.mul_(3.0)
     params, seen = {}, {}
     for k, v in m.state_dict().items():
-        params[k] = seen.setdefault(v.data_ptr(), v.clone())
+        params[k] = seen.setdefault(v.data_ptr(), v.double())
     frames = torch.poisson(torch.full((1, 3, 2, H, W), 0.284))
-    z = lambda c: torch.zeros(1, c, H, W)
+    z = lambda c: torch.zeros(1, c, H, W, dtype=torch.float64)
     with torch.no_grad():
         h, hp, hn, pred = z(n_c), z(n_c), z(n_c), z(2 * scale * scale)
         ref = []
         for i in range(2):
-            h, hp, hn, pred = O.bmcnet_forward(params, frames[:, i:i + 2].transpose(1, 2), h, hp, hn, pred, i == 0, scale)
+            h, hp, hn, pred = O.bmcnet_forward(params, frames[:, i:i + 2].transpose(1, 2).double(), h, hp, hn, pred, i == 0, scale)
             ref.append(pred)
         m.to(dev)
         zz = lambda c: torch.zeros(1, c, H, W, device=dev)
@@ -460,4 +463,49 @@ def test_full_size_window_forward_vs_oracle():
         for i in range(2):
             h, hp, hn, pred = m(frames[:, i:i + 2].transpose(1, 2).to(dev), h, hp, hn, pred, i == 0)
             assert pred.shape == (1, 2, 720, 960)
-            assert rel_l2(pred, ref[i]) < 1e-4, i
+            err = rel_l2(pred, ref[i])
+            print("full-size window %d: SR rel-L2 vs float64 oracle %.2e" % (i, err))
+            assert err < 1e-4, i
+
+
+def test_quarter_frame_window_gradients_vs_oracle():
+    """Forward + backward of one BMCNet(4,128,5) window at 90x120 (a quarter of the C2 frame; ~10 s of CPU oracle):
+    loss and every parameter gradient vs the CPU oracle's autograd -- checks the pixel-split weight-gradient
+    reductions at realistic reduction lengths (10 800 pixels per sample)."""
+    dev = _gpu()
+    from models.BMCNet import BMCNet
+    from oracle import bmc_oracle as O
+    torch.manual_seed(11)
+    scale, n_c, n_b, H, W = 4, 128, 5, 90, 120
+    m = BMCNet(scale, n_c, n_b)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(3.0)
+    params, seen = {}, {}
+    for k, v in m.state_dict().items():
+        params[k] = seen.setdefault(v.data_ptr(), v.clone().requires_grad_())
+    x = torch.poisson(torch.full((1, 2, 2, H, W), 0.284))
+    gt = torch.poisson(torch.full((1, 2, scale * H, scale * W), 0.284))
+    z = lambda c: torch.zeros(1, c, H, W)
+    _, _, _, pred = O.bmcnet_forward(params, x, z(n_c), z(n_c), z(n_c), z(32), True, scale)
+    loss_ref = F.mse_loss(pred, gt)
+    loss_ref.backward()
+    m.to(dev)
+    zz = lambda c: torch.zeros(1, c, H, W, device=dev)
+    _, _, _, pg = m(x.to(dev), zz(n_c), zz(n_c), zz(n_c), zz(32), True)
+    loss = F.mse_loss(pg, gt.to(dev))
+    loss.backward()
+    assert rel_l2(pg, pred) < 1e-4
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
+    worst = 0.0
+    n = 0
+    for name, p in m.named_parameters():
+        if p.grad is None:
+            assert params[name].grad is None
+            continue
+        e = rel_l2(p.grad, params[name].grad)
+        worst = max(worst, e)
+        assert e < 1e-3, (name, e)
+        n += 1
+    assert n >= 40
+    print("quarter-frame: SR rel-L2 %.2e, worst parameter-gradient rel-L2 %.2e over %d tensors" % (rel_l2(pg, pred), worst, n))
