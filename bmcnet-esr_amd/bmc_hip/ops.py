@@ -428,9 +428,18 @@ def _wgrad_plain(g, x, spec, weight_shape, taps):
     return dw.view(weight_shape), db[0]
 
 
+class OutSlot:
+    """Where a Function should put its result: batches [b0, b0 + B) of a preallocated buffer (kept out of autograd's
+    sight on purpose -- see bie.Stack2Fn)."""
+    __slots__ = ("t", "b0")
+
+    def __init__(self, t, b0):
+        self.t, self.b0 = t, b0
+
+
 class ResBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, spec):
+    def forward(ctx, x, w1, b1, w2, b2, spec, out=None):
         _need_gpu(x)
         B, H, W, Cn = x.shape
         taps = w1.shape[-1] * w1.shape[-2]
@@ -442,7 +451,7 @@ class ResBlockFn(torch.autograd.Function):
         t = torch.empty_like(x)
         conv_raw([xs], wp1, spec.kpad * taps * cp, b1.detach(), Cn, t.data_ptr(), H * W * Cn, Cn, B, H, W, Cn, taps, relu=True,
                  flops=fl)
-        y = torch.empty_like(x)
+        y = torch.empty_like(x) if out is None else out.t[out.b0:out.b0 + B]
         conv_raw([_src(t, 0, Cn, 0, None, 0, B)], wp2, spec.kpad * taps * cp, b2.detach(), Cn, y.data_ptr(), H * W * Cn, Cn, B, H,
                  W, Cn, taps, residual=xs, flops=fl)
         ctx.save_for_backward(x, t, w1, w2)
@@ -474,11 +483,11 @@ class ResBlockFn(torch.autograd.Function):
             dx = torch.empty_like(g)
             conv_raw([_src(dt, 0, Cn, 0, None, 0, B)], w1t, c16 * taps * nkpad, None, 0, dx.data_ptr(), H * W * Cn, Cn, B, H, W,
                      Cn, taps, residual=gs, flops=fl)
-        return dx, dw1, db1, dw2, db2, None
+        return dx, dw1, db1, dw2, db2, None, None
 
 
-def res_block(x, w1, b1, w2, b2, spec):
-    return ResBlockFn.apply(x, w1, b1, w2, b2, spec)
+def res_block(x, w1, b1, w2, b2, spec, out=None):
+    return ResBlockFn.apply(x, w1, b1, w2, b2, spec, out)
 
 
 # --------------------------------------------------------------------------

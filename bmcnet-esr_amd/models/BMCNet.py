@@ -12,7 +12,7 @@ Execution differs from the reference on purpose (results do not):
 """
 from .submodules import *  # noqa: F401,F403  (same star-import surface as the reference)
 from .submodules import BIE, PixelUnShuffle, ResidualBlock_noBN, initialize_weights, to_nchw, to_nhwc
-from bmc_hip import ops
+from bmc_hip import bie, ops
 from bmc_hip.ops import ConvSpec, View
 
 
@@ -32,9 +32,19 @@ class ParallelBlk(nn.Module):
     def forward_nhwc(self, x12, xs, xst12, xsst12, need_st=True):
         """x12 = [x_1; x_2], xst12 = [x_1_st; x_2_st], xsst12 = [x_1_s_st; x_2_s_st] (batch-stacked twins).
         need_st=False: the caller will not read the returned xst12 (it is None then)."""
-        x12 = self.conv1.forward_nhwc(x12)
-        xst12 = self.conv1_st.forward_nhwc(xst12)
-        x12, xst12, xsst12 = self.lBIE.forward_pair(x12, xst12, xsst12, need_second=need_st)
+        if need_st:
+            # both residual blocks write into the halves of one buffer, so the two lBIE calls (and, inside them, the
+            # weight-shared conv1/conv2 and convf1/convf2 pairs) run as ONE fused twin node over 4B samples
+            B2 = x12.shape[0]
+            slot = ops.OutSlot(torch.empty((2 * B2,) + tuple(x12.shape[1:]), device=x12.device, dtype=x12.dtype), 0)
+            a = self.conv1.forward_nhwc(x12, out=slot)
+            b = self.conv1_st.forward_nhwc(xst12, out=ops.OutSlot(slot.t, B2))
+            o, xsst12 = self.lBIE.forward_twin(bie.Stack2Fn.apply(a, b, slot), xsst12)
+            x12, xst12 = bie.Unstack2Fn.apply(o)
+        else:
+            x12 = self.conv1.forward_nhwc(x12)
+            xst12 = self.conv1_st.forward_nhwc(xst12)
+            x12, xst12, xsst12 = self.lBIE.forward_pair(x12, xst12, xsst12, need_second=False)
         x12, xs = self.gBIE.forward_twin(x12, xs)
         return x12, xs, xst12, xsst12
 

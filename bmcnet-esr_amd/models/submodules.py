@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 from torch.nn import init
 
-from bmc_hip import ops
+from bmc_hip import bie, ops
 from bmc_hip.ops import ConvSpec, View
 
 
@@ -49,9 +49,10 @@ class ResidualBlock_noBN(nn.Module):
         initialize_weights([self.conv1, self.conv2], 0.1)
         self._spec = ConvSpec.dense(nf)
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, out=None):
+        """out: optional ops.OutSlot -- write the result into a batch range of a preallocated buffer."""
         return ops.res_block(x.contiguous(), self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
-                             self._spec)
+                             self._spec, out)
 
     def forward(self, x):
         return to_nchw(self.forward_nhwc(to_nhwc(x)))
@@ -127,6 +128,13 @@ class BIE(nn.Module):
         return o1, o2, xs_new
 
     def forward_twin(self, x12, xs):
+        """x12 = [first; second] -> ([out_1 + Res(second); out_2 + Res(first)], xs_new): one fused autograd node
+        (bmc_hip/bie.py) -- forward and backward written out launch by launch, every multi-contribution gradient
+        accumulated in convolution epilogues."""
+        return bie.bie_twin(self, x12, xs)
+
+    def forward_twin_unfused(self, x12, xs):
+        """The same computation out of the generic autograd Functions (kept as the cross-check of the fused node)."""
         B2 = x12.shape[0]
         B = B2 // 2
         r12 = self.conv1.forward_nhwc(x12)                                          # [r1; r2]

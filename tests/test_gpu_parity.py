@@ -509,3 +509,32 @@ def test_quarter_frame_window_gradients_vs_oracle():
         n += 1
     assert n >= 40
     print("quarter-frame: SR rel-L2 %.2e, worst parameter-gradient rel-L2 %.2e over %d tensors" % (rel_l2(pg, pred), worst, n))
+
+
+def test_fused_twin_bie_matches_unfused_autograd_path():
+    """bmc_hip.bie.BIETwinFn (hand-written forward + backward) against the same block composed from the generic
+    autograd Functions: outputs, input gradients and all 16 parameter gradients."""
+    dev = _gpu()
+    from models.submodules import BIE
+    torch.manual_seed(4)
+    Cn, B, H, W = 32, 2, 13, 21
+    m = BIE(Cn).to(dev)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(4.0).add_(0.05 * torch.randn_like(p))
+    x12 = torch.randn(2 * B, H, W, Cn, device=dev)
+    xs = torch.randn(B, H, W, Cn, device=dev)
+    go, gx = torch.randn(2 * B, H, W, Cn, device=dev), torch.randn(B, H, W, Cn, device=dev)
+    res = []
+    for fn in (m.forward_twin_unfused, m.forward_twin):
+        a, b = x12.clone().requires_grad_(), xs.clone().requires_grad_()
+        for p in m.parameters():
+            p.grad = None
+        o, s = fn(a, b)
+        torch.autograd.backward([o, s], [go, gx])
+        res.append((o.detach(), s.detach(), a.grad, b.grad, [p.grad.clone() for p in m.parameters()]))
+    for i in range(4):
+        assert rel_l2(res[1][i], res[0][i]) < 2e-5, i
+    assert len(res[0][4]) == 16
+    for ga, gb in zip(res[1][4], res[0][4]):
+        assert rel_l2(ga, gb) < 5e-5
