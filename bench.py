@@ -205,12 +205,14 @@ def main():
         dt = t.item()
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2**30
 
+    # the instrumented extra step contains the gradient all-reduce: every rank has to take part in it
+    iso = isolated_conv(dev, B, H, W, n_c) if rank == 0 else None
+    roof = dominant_kernel_roofline(eager_step, iso)
     if rank == 0:
         windows = L - 1
         frames_per_step = world * B * windows
         value = frames_per_step * args.steps / dt
         step_flops = FLOP_PER_LRPX_FWD_BWD * H * W * B * windows if (n_c, n_b) == (128, 5) else None
-        roof = dominant_kernel_roofline(eager_step, isolated_conv(dev, B, H, W, n_c))
         if step_flops:
             roof["step_achieved_tflops_per_gpu"] = round(step_flops * args.steps / dt / 1e12, 2)
             roof["step_frac_of_peak"] = round(step_flops * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)

@@ -13,7 +13,7 @@ from __future__ import annotations
 import torch
 
 from . import lib
-from .ops import (CK, ConvSpec, _dense_spec, _need_gpu, _packed_weight, _packed_weight_t, _src, _stream, colsum, conv_raw,
+from .ops import (CK, ConvSpec, _dense_spec, _need_gpu, _packed_weight, _packed_weight_t, _src, _stream, conv_raw,
                   coutpad, pgemm_raw, round_up)
 
 _SPEC2 = {}
@@ -50,18 +50,15 @@ def _dgrad(g_src, w4, spec, src_index, owner, out, B, residual=None, mask=None, 
 
 
 def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, G=1):
-    slabs, nsplit, _ = pgemm_raw(a_src, x_srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
-                                 flops=2.0 * B * H * W * Cout * taps * spec.cin)
+    """-> (dW flat [G*Cout*Cin*taps], db [G,Cout]): weight gradient + bias gradient (column sums of the same A operand,
+    taken from the tiles the pixel-reduction GEMM stages anyway)."""
+    slabs, nsplit, _, bsl = pgemm_raw(a_src, x_srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
+                                      flops=2.0 * B * H * W * Cout * taps * spec.cin, want_bias=True)
     dw = torch.empty(G * Cout * spec.cin * taps, device=dev, dtype=torch.float32)
+    db = torch.empty((G, Cout), device=dev, dtype=torch.float32)
     lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, G, taps, Cout, spec.kpad,
-             spec.kmap(dev).data_ptr(), spec.cin, dw.data_ptr(), 0, _stream())
-    return dw
-
-
-def _bsum(t, b0=0, nb=None):
-    nbt, H, W, Cn = t.shape
-    nb = nbt if nb is None else nb
-    return colsum(t.data_ptr() + 4 * b0 * H * W * Cn, nb * H * W, Cn, Cn, t.device)
+             spec.kmap(dev).data_ptr(), spec.cin, dw.data_ptr(), 0, bsl.data_ptr(), db.data_ptr(), _stream())
+    return dw, db
 
 
 class BIETwinFn(torch.autograd.Function):
@@ -142,18 +139,16 @@ class BIETwinFn(torch.autograd.Function):
         _conv([X(c12)], da.transpose(1, 2).contiguous().view(B2, Cn, Cn, 1), s1, None, None, dv12, B2, bpg=1,
               accumulate=True)                                                                           # dv +=
         # ---- unclustering(cat[c1, c2]) + xs
-        dwu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev)
-        dbu = _bsum(g_x)
+        dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev)
         _dgrad(X(g_x), w_u, s2, 0, o_wu, dc12, n, accumulate=True, out_b0=0)
         _dgrad(X(g_x), w_u, s2, 1, o_wu, dc12, n, accumulate=True, out_b0=n)
         # ---- value convs (two weight groups)
-        dwv = _wgrad(X(dv12), [X(x12)], s1, B2, H, W, 1, Cn, dev, G=2).view(2, Cn, Cn, 1, 1)
-        dbv1, dbv2 = _bsum(dv12, 0, n), _bsum(dv12, n, n)
+        dwv, dbv = _wgrad(X(dv12), [X(x12)], s1, B2, H, W, 1, Cn, dev, G=2)
+        dwv = dwv.view(2, Cn, Cn, 1, 1)
         dx12 = new(B2)
         _dgrad(X(dv12), w_v, s1, 0, None, dx12, B2, bpg=n)                                               # dx12  =
         # ---- clustering, LayerNorm, convf
-        dwc = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev)
-        dbc = _bsum(dc12)
+        dwc, dbc = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev)
         dy12 = new(B2)
         _dgrad(X(dc12), w_c, s1, 0, o_wc, dy12, B2)
         dz12 = new(B2)
@@ -162,24 +157,21 @@ class BIETwinFn(torch.autograd.Function):
         dbeta = torch.empty(Cn, device=dev, dtype=torch.float32)
         lib.call(lib._ln_bwd, "bmc_layernorm_bwd", dy12.data_ptr(), z12.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
                  B2 * H * W, Cn, dz12.data_ptr(), ws.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, _stream())
-        dwf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev)
-        dbf = _bsum(dz12)
+        dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev)
         dxs = new(n)
         _dgrad(X(dz12, b0=0, B=n), w_f, s2, 0, o_wf, dxs, n, residual=X(g_x))                            # dxs  = skip + half 0
         _dgrad(X(dz12, b0=n, B=n), w_f, s2, 0, o_wf, dxs, n, accumulate=True)                            # dxs += half 1
         _dgrad(X(dz12, shift=n, mod=B2), w_f, s2, 1, o_wf, dx12, B2, accumulate=True)                    # dx12 += (rotated)
         # ---- residual block, upstream gradient = batch-rotated g_o
         g_r = X(g_o, shift=n, mod=B2)
-        dw2 = _wgrad(g_r, [X(t12)], s1, B2, H, W, 9, Cn, dev)
-        db2 = _bsum(g_o)
+        dw2, db2 = _wgrad(g_r, [X(t12)], s1, B2, H, W, 9, Cn, dev)
         dt = new(B2)
         _dgrad(g_r, w_r2, s1, 0, o_rw2, dt, B2, mask=X(t12))
-        dw1 = _wgrad(X(dt), [X(x12)], s1, B2, H, W, 9, Cn, dev)
-        db1 = _bsum(dt)
+        dw1, db1 = _wgrad(X(dt), [X(x12)], s1, B2, H, W, 9, Cn, dev)
         _dgrad(X(dt), w_r1, s1, 0, o_rw1, dx12, B2, residual=g_r, accumulate=True)                       # dx12 += conv1^T + skip
-        return (dx12, dxs, dw1.view(rw1.shape), db1, dw2.view(rw2.shape), db2, dwf.view(wf.shape), dbf, dgamma, dbeta,
-                dwc.view(wc.shape), dbc, dwu.view(wu.shape), dbu, dwv[0].reshape(wv1.shape), dbv1,
-                dwv[1].reshape(wv2.shape), dbv2, None, None)
+        return (dx12, dxs, dw1.view(rw1.shape), db1[0], dw2.view(rw2.shape), db2[0], dwf.view(wf.shape), dbf[0], dgamma, dbeta,
+                dwc.view(wc.shape), dbc[0], dwu.view(wu.shape), dbu[0], dwv[0].reshape(wv1.shape), dbv[0],
+                dwv[1].reshape(wv2.shape), dbv[1], None, None)
 
 
 def bie_twin(m, x12, xs):

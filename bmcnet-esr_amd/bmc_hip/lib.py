@@ -43,7 +43,7 @@ class ConvArgs(C.Structure):
 class PgemmArgs(C.Structure):
     _fields_ = [("a", Src), ("nsrc", C.c_int), ("src", Src * MAX_SRC), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("taps", C.c_int), ("batch_per_group", C.c_int), ("slabs", C.c_void_p), ("nsplit", C.c_int),
-                ("zeros", C.c_void_p)]
+                ("zeros", C.c_void_p), ("bias_slabs", C.c_void_p)]
 
 
 def _sig(name, argtypes, restype=C.c_int):
@@ -63,7 +63,7 @@ _pack_w = _sig("bmc_pack_weight", [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p])
 _pack_wt = _sig("bmc_pack_weight_t", [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p])
 _conv = _sig("bmc_conv", [C.POINTER(ConvArgs), _p])
 _pgemm = _sig("bmc_pgemm", [C.POINTER(PgemmArgs), _p])
-_red_w = _sig("bmc_pgemm_reduce_weight", [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p])
+_red_w = _sig("bmc_pgemm_reduce_weight", [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p])
 _red_p = _sig("bmc_pgemm_reduce_plain", [_p, _i, _i, _i, _i, _f, _p, _p])
 _colsum = _sig("bmc_colsum", [_p, _ll, _i, _i, _p, _p, _i, _p])
 _relu_bwd = _sig("bmc_relu_bwd", [_p, _p, _p, _ll, _p])

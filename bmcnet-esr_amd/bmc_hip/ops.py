@@ -228,8 +228,9 @@ def _zeros(device):
     return z
 
 
-def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, device, flops=0.0):
-    """Returns (slabs, nsplit, G)."""
+def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, device, flops=0.0, want_bias=False):
+    """Returns (slabs, nsplit, G), or with want_bias (slabs, nsplit, G, bias_slabs): per-workgroup column sums of the
+    A operand (bias-gradient partials) for bmc_pgemm_reduce_weight."""
     G = B // bpg
     mpad, npad = round_up(M, 32), round_up(N, 32)
     if taps == 9:       # LDS-DMA kernel: one 8-wave workgroup per CU, 64 columns per workgroup
@@ -253,9 +254,17 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
     p.slabs = slabs.data_ptr()
     p.nsplit = nsplit
     p.zeros = _zeros(device).data_ptr()
+    bslabs = None
+    if want_bias:
+        bslabs = torch.empty(nsplit * G * 4 * mpad, device=device, dtype=torch.float32)
+        p.bias_slabs = bslabs.data_ptr()
+    else:
+        p.bias_slabs = None
     e0 = _prof_begin()
     lib.call(lib._pgemm, "bmc_pgemm", C.byref(p), _stream())
     _prof_end(e0, "pgemm_kernel<%d>" % taps, flops)
+    if want_bias:
+        return slabs, nsplit, G, bslabs
     return slabs, nsplit, G
 
 
@@ -332,13 +341,19 @@ class ConvFn(torch.autograd.Function):
         if need[1]:
             srcs = [_src(t, *v, B) for t, v in zip(src_ts, meta.views)]
             a_src = _src(g, 0, Cout, 0, None, 0, B)
-            slabs, nsplit, _ = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
-                                         flops=2.0 * B * H * W * Cout * taps * spec.cin)
+            wb = ctx.has_bias and need[2]
+            r_pg = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
+                             flops=2.0 * B * H * W * Cout * taps * spec.cin, want_bias=wb)
+            slabs, nsplit = r_pg[0], r_pg[1]
             dwf = torch.empty(G * Cout * spec.cin * taps, device=dev, dtype=torch.float32)   # every (co, ci, tap) is written
+            dbf = torch.empty((G, Cout), device=dev, dtype=torch.float32) if wb else None
             lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, G, taps, Cout, spec.kpad,
-                     spec.kmap(dev).data_ptr(), spec.cin, dwf.data_ptr(), 0, _stream())
+                     spec.kmap(dev).data_ptr(), spec.cin, dwf.data_ptr(), 0, r_pg[3].data_ptr() if wb else None,
+                     dbf.data_ptr() if wb else None, _stream())
+            if wb:
+                db = dbf[0] if G == 1 else dbf
             dw = dwf.view(weight.shape)
-        if ctx.has_bias and need[2]:
+        if ctx.has_bias and need[2] and db is None:
             bpg = B // G
             parts = [colsum(g.data_ptr() + 4 * gi * bpg * H * W * Cout, bpg * H * W, Cout, Cout, dev) for gi in range(G)]
             db = parts[0] if G == 1 else torch.stack(parts)
@@ -419,12 +434,12 @@ def _wgrad_plain(g, x, spec, weight_shape, taps):
     """-> (dW, db): weight gradient and bias gradient (column sums of g) from one pgemm launch."""
     B, H, W, Cout = g.shape
     dev = g.device
-    slabs, nsplit, _ = pgemm_raw(_src(g, 0, Cout, 0, None, 0, B), [_src(x, 0, x.shape[3], 0, None, 0, B)], B, H, W, taps, B,
-                                 Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.cin)
-    db = colsum(g.data_ptr(), B * H * W, Cout, Cout, dev).view(1, Cout)
+    slabs, nsplit, _, bsl = pgemm_raw(_src(g, 0, Cout, 0, None, 0, B), [_src(x, 0, x.shape[3], 0, None, 0, B)], B, H, W, taps,
+                                      B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.cin, want_bias=True)
+    db = torch.empty((1, Cout), device=dev, dtype=torch.float32)
     dw = torch.empty(Cout * spec.cin * taps, device=dev, dtype=torch.float32)
     lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, 1, taps, Cout, spec.kpad,
-             spec.kmap(dev).data_ptr(), spec.cin, dw.data_ptr(), 0, _stream())
+             spec.kmap(dev).data_ptr(), spec.cin, dw.data_ptr(), 0, bsl.data_ptr(), db.data_ptr(), _stream())
     return dw.view(weight_shape), db[0]
 
 

@@ -22,6 +22,7 @@ struct PgemmK {
     float* slabs;
     int nsplit;
     const float* zeros;
+    float* bias_slabs;   // optional: per-workgroup column sums of the A tiles (bias gradient partials)
     int M, Mpad, N, Npad;
     int n_nblk, n_mblk, G;
     int tiles_x, tiles_y, tiles_per_img;
@@ -121,11 +122,20 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
 
     if (split < ntiles) issue(split, 0);
     __syncthreads();
+    // bias gradient = column sums of A over pixels: the first n-block adds up its A tiles straight from LDS
+    // (thread -> channel tid & 127, rows (tid >> 7) * 16 .. + 16); 4 partial rows per workgroup go to bias_slabs
+    const bool do_bias = a.bias_slabs != nullptr && nb == 0;
+    float bsum = 0.f;
     int it = 0;
     for (int tile = split; tile < ntiles; tile += a.nsplit, ++it) {
         const int cur = it & 1;
         const int next = tile + a.nsplit;
         if (next < ntiles) issue(next, cur ^ 1);
+        if (do_bias) {
+            const float* const bp = lds + cur * BUF + (tid >> 7) * 16 * 128 + (tid & 127);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bsum += bp[r * 128];
+        }
         if (wave_active) {
             const float* const ap = lds + cur * BUF + lh * 128 + 32 * mw + li;
             const float* const xp = lds + (2 + cur) * BUF + lh * XCH + 32 * NT * nw + li;
@@ -146,6 +156,8 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
         __syncthreads();    // drains the DMA of the next tile (vmcnt) and fences this tile's LDS reads
     }
 
+    if (do_bias && m0 + (tid & 127) < a.Mpad)
+        a.bias_slabs[(((long long)split * a.G + g) * 4 + (tid >> 7)) * a.Mpad + m0 + (tid & 127)] = bsum;
     if (wave_active) {
         float* const sl = a.slabs + (((long long)split * a.G + g) * TAPS) * a.Mpad * a.Npad;
 #pragma unroll
@@ -183,12 +195,32 @@ __device__ __forceinline__ float split_sum(const float* p, long long slab, int n
 }
 
 __global__ void reduce_weight_kernel(const float* slabs, int nsplit, int G, int taps, int M, int N, int Mpad, int Npad,
-                                     const int* kmap, int Cin, float* dw, int accumulate) {
+                                     const int* kmap, int Cin, float* dw, int accumulate, const float* bias_slabs,
+                                     float* db, int wblocks) {
     __shared__ float red[256];
+    if ((int)blockIdx.x >= wblocks) {    // trailing blocks: bias gradient db[g][m] = sum over (split, part) partials
+        const long long total = (long long)G * M;
+        const long long idx = (long long)(blockIdx.x - wblocks) * 32 + (threadIdx.x & 31);
+        const int g = idx < total ? (int)(idx / M) : 0, m = idx < total ? (int)(idx % M) : 0;
+        // partial p = split * 4 + part lives at ((split*G + g)*4 + part)*Mpad + m
+        const int part = threadIdx.x >> 5;
+        float s = 0.f;
+        if (idx < total)
+            for (int i = part; i < nsplit * 4; i += 8) s += bias_slabs[(((long long)(i >> 2) * G + g) * 4 + (i & 3)) * Mpad + m];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < 32 && idx < total) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 32 + threadIdx.x];
+            db[idx] = accumulate ? db[idx] + t : t;
+        }
+        return;
+    }
     const long long total = (long long)G * taps * M * N;
     const long long slab = (long long)G * taps * Mpad * Npad;
     const long long nchunk = (total + 31) / 32;
-    for (long long chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+    for (long long chunk = blockIdx.x; chunk < nchunk; chunk += wblocks) {
         const long long idx = chunk * 32 + (threadIdx.x & 31);
         const float* p = nullptr;
         int m = 0, tap = 0, g = 0, ci = -1;
@@ -253,7 +285,7 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
         } else k.src[i] = to_dev(h->src[0]);
     }
     k.B = h->B; k.H = h->H; k.W = h->W; k.batch_per_group = h->batch_per_group;
-    k.slabs = h->slabs; k.nsplit = h->nsplit; k.zeros = h->zeros;
+    k.slabs = h->slabs; k.nsplit = h->nsplit; k.zeros = h->zeros; k.bias_slabs = h->bias_slabs;
     k.M = h->a.nch; k.Mpad = bmc_round_up(k.M, 32); k.N = N; k.Npad = bmc_round_up(N, 32);
     k.G = h->B / h->batch_per_group;
     k.n_mblk = (k.Mpad + 127) / 128;
@@ -276,12 +308,15 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
 }
 
 extern "C" int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, int taps, int M, int N, const int* kmap,
-                                       int Cin, float* dw, int accumulate, bmc_stream_t stream) {
+                                       int Cin, float* dw, int accumulate, const float* bias_slabs, float* db,
+                                       bmc_stream_t stream) {
     BMC_CHECK_ARG(slabs && dw && nsplit >= 1, "bmc_pgemm_reduce_weight: bad args");
+    BMC_CHECK_ARG((bias_slabs == nullptr) == (db == nullptr), "bmc_pgemm_reduce_weight: bias_slabs and db go together");
     const long long total = (long long)G * taps * M * N;
-    const int blocks = (int)((total + 31) / 32 > 8192 ? 8192 : (total + 31) / 32);
-    hipLaunchKernelGGL(reduce_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, taps, M, N,
-                       bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, dw, accumulate);
+    const int wblocks = (int)((total + 31) / 32 > 8192 ? 8192 : (total + 31) / 32);
+    const int bblocks = bias_slabs ? (int)(((long long)G * M + 31) / 32) : 0;
+    hipLaunchKernelGGL(reduce_weight_kernel, dim3(wblocks + bblocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, taps,
+                       M, N, bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, dw, accumulate, bias_slabs, db, wblocks);
     BMC_CHECK_LAUNCH("bmc_pgemm_reduce_weight");
     return 0;
 }

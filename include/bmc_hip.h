@@ -124,11 +124,14 @@ typedef struct bmc_pgemm_args {
     float* slabs;
     int nsplit;
     const float* zeros;         /* >= 64 bytes of zeros in device memory (source for out-of-image LDS-DMA lanes) */
+    float* bias_slabs;          /* optional [nsplit][G][4][Mpad]: column sums of A (the bias gradient of the same conv),
+                                   taken from the A tiles the kernel stages anyway; summed by bmc_pgemm_reduce_weight */
 } bmc_pgemm_args_t;
 int bmc_pgemm(const bmc_pgemm_args_t* host_args, bmc_stream_t s);
 /* slabs -> dW[Cout][Cin][taps] (nn.Conv2d layout) through kmap; beta 0/1 = overwrite/accumulate */
 int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, int taps, int M, int N, const int* kmap,
-                            int Cin, float* dw, int accumulate, bmc_stream_t s);
+                            int Cin, float* dw, int accumulate, const float* bias_slabs /* or NULL */,
+                            float* db /* [G][M] or NULL */, bmc_stream_t s);
 /* slabs -> out[G][M][N] * scale */
 int bmc_pgemm_reduce_plain(const float* slabs, int nsplit, int G, int M, int N, float scale,
                            float* out, bmc_stream_t s);
