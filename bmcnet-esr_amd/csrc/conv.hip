@@ -20,7 +20,8 @@
 #define BMC_LX 1   // measured: deeper rings (2, 3) do not help the 1x1 kernel (it is power/clock limited)
 #endif
 #ifndef BMC_DIAG_MODE
-#define BMC_DIAG_MODE 0   // ablation bits for diagnostic builds (tools/): 1 no epilogue stores, 2 no global loads, 4 no MFMAs
+#define BMC_DIAG_MODE 0   // ablation bits for diagnostic builds (tools/): 1 no epilogue stores, 2 no global loads, 4 no MFMAs,
+                          // 8 no weight loads, 16 no activation loads
 #endif
 #ifdef BMC_DIAG
 // diagnostic build only (libbmc_hip_diag.so, tools/): per-block cycle / wall stamps; never in the product library
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
 #pragma unroll
         for (int n = 0; n < NXLD; ++n) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (!(BMC_DIAG_MODE & 2) && xok[n]) v = *reinterpret_cast<const f32x4*>(base + (long long)xpix[n] * spix);
+            if (!(BMC_DIAG_MODE & (2 | 16)) && xok[n]) v = *reinterpret_cast<const f32x4*>(base + (long long)xpix[n] * spix);
             xr[slot][n] = v;
         }
         c_in += CK;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
 #pragma unroll
         for (int n = 0; n < NWLD; ++n) {
             const int e = tid + 256 * n;
-            if (BMC_DIAG_MODE & 2) { wr[n] = f32x4{1.f, 1.f, 1.f, 1.f}; continue; }
+            if (BMC_DIAG_MODE & (2 | 8)) { wr[n] = f32x4{1.f, 1.f, 1.f, 1.f}; continue; }
             if (e < BN * 4) wr[n] = *reinterpret_cast<const f32x4*>(p + e * 4);
         }
         if (++wl_step == nsteps) {
