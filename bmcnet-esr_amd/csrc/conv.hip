@@ -35,7 +35,7 @@ namespace {
 
 constexpr int CK = BMC_CK;  // channels per chunk
 constexpr int RS = 20;      // LDS row stride in floats (16 + 4 pad: conflict-free ds_read_b128)
-constexpr int TH = 8, TW = 16;
+constexpr int TW = 16;      // tile width; the tile height TH (8 or 4 rows) is a kernel template parameter
 
 struct ConvK {
     int nsrc;
@@ -56,11 +56,15 @@ struct ConvK {
     int tiles_x, tiles_y, ntn, nchunks, ntiles;
 };
 
-template <int TAPS, int BN>
-__global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const ConvK a) {
+// Tile shapes (4 waves): BN = 128: waves 2(px) x 2(ch), wave = (TH/2 rows x 16) px x 64 ch  [TH = 8: 2x2 MFMA tiles, TH = 4: 1x2]
+//                        BN =  64: waves 2 x 2,           wave = (TH/2 rows x 16) px x 32 ch  [small problems: 4x the workgroups]
+//                        BN =  32: waves 4(px) x 1,       wave = 32 px x 32 ch (TH = 8)        [narrow outputs]
+template <int TAPS, int BN, int TH>
+__global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kernel(const ConvK a) {
+    static_assert((BN == 32 && TH == 8) || ((BN == 128 || BN == 64) && (TH == 8 || TH == 4)), "unsupported tile shape");
     constexpr int P = TAPS == 9 ? 1 : 0;
     constexpr int HWD = TW + 2 * P, HHT = TH + 2 * P, NHALO = HWD * HHT;
-    constexpr int MT = BN == 128 ? 2 : 1, NT = BN == 128 ? 2 : 1;
+    constexpr int MT = BN == 32 ? 1 : TH / 4, NT = BN == 128 ? 2 : 1;
     constexpr int NXLD = (NHALO * 4 + 255) / 256;
     constexpr int NWLD = (BN * 4 + 255) / 256;
     constexpr int XBUF = NHALO * RS, WBUF = BN * RS;
@@ -187,8 +191,8 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void conv_kernel(const Conv
     };
 
     // ---- MFMA fragment addressing
-    const int rowbase = BN == 128 ? 4 * (wave >> 1) : 2 * wave;
-    const int cobase = BN == 128 ? 64 * (wave & 1) : 0;
+    const int rowbase = BN == 32 ? 2 * wave : (TH / 2) * (wave >> 1);
+    const int cobase = BN == 32 ? 0 : (BN / 2) * (wave & 1);
     int aoff[MT], boff[NT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) aoff[t] = ((rowbase + 2 * t + (li >> 4)) * HWD + (li & 15)) * RS + 4 * lh;
@@ -398,24 +402,40 @@ extern "C" int bmc_conv(const bmc_conv_args_t* h, bmc_stream_t stream) {
     k.out = h->out; k.out_batch_stride = h->out_batch_stride; k.out_pix_stride = h->out_pix_stride;
     k.B = h->B; k.H = h->H; k.W = h->W; k.Cout = h->Cout; k.Coutpad = h->Coutpad;
     k.relu = h->relu; k.residual = to_dev(h->residual); k.mask = to_dev(h->mask); k.accumulate = h->accumulate;
-    k.tiles_x = (h->W + TW - 1) / TW; k.tiles_y = (h->H + TH - 1) / TH;
-    const int BN = h->Coutpad == 32 ? 32 : 128;
+    // tile shape: 8x16 px x 128 ch when that fills the chip; small problems get 4-row tiles and/or 64-channel tiles so
+    // that 2-4x as many workgroups share the work (a workgroup's K loop is serial: its latency is the launch's latency)
+    const int cus = bmc_num_cus();
+    int BN = h->Coutpad == 32 ? 32 : 128, THv = 8;
+    auto count = [&](int th, int bn) {
+        return (long long)h->B * ((h->W + TW - 1) / TW) * ((h->H + th - 1) / th) * (h->Coutpad / bn);
+    };
+    if (BN == 128 && count(8, 128) < 2ll * cus) {
+        THv = 4;
+        if (count(4, 128) < 2ll * cus) BN = 64;
+    }
+    k.tiles_x = (h->W + TW - 1) / TW; k.tiles_y = (h->H + THv - 1) / THv;
     k.ntn = h->Coutpad / BN;
     k.nchunks = ktot / CK;
-    const long long ntiles = (long long)h->B * k.tiles_x * k.tiles_y * k.ntn;
+    const long long ntiles = count(THv, BN);
     BMC_CHECK_ARG(ntiles < (1ll << 31), "bmc_conv: too many tiles");
     k.ntiles = (int)ntiles;
-
-    const int max_blocks = bmc_num_cus() * 3;   // 3 resident workgroups per CU (LDS 49 KB, 154 registers)
+    const int per_cu = (BN == 128 && THv == 8) ? 3 : 4;       // resident workgroups per CU (LDS / registers)
+    const int max_blocks = cus * per_cu;
     dim3 grid((unsigned)(ntiles < max_blocks ? ntiles : max_blocks)), block(256);
     hipStream_t st = (hipStream_t)stream;
+#define BMC_LAUNCH_CONV(TAPS_, BN_, TH_) hipLaunchKernelGGL((conv_kernel<TAPS_, BN_, TH_>), grid, block, 0, st, k)
     if (h->taps == 9) {
-        if (BN == 128) hipLaunchKernelGGL((conv_kernel<9, 128>), grid, block, 0, st, k);
-        else hipLaunchKernelGGL((conv_kernel<9, 32>), grid, block, 0, st, k);
+        if (BN == 32) BMC_LAUNCH_CONV(9, 32, 8);
+        else if (BN == 64) BMC_LAUNCH_CONV(9, 64, 4);
+        else if (THv == 4) BMC_LAUNCH_CONV(9, 128, 4);
+        else BMC_LAUNCH_CONV(9, 128, 8);
     } else {
-        if (BN == 128) hipLaunchKernelGGL((conv_kernel<1, 128>), grid, block, 0, st, k);
-        else hipLaunchKernelGGL((conv_kernel<1, 32>), grid, block, 0, st, k);
+        if (BN == 32) BMC_LAUNCH_CONV(1, 32, 8);
+        else if (BN == 64) BMC_LAUNCH_CONV(1, 64, 4);
+        else if (THv == 4) BMC_LAUNCH_CONV(1, 128, 4);
+        else BMC_LAUNCH_CONV(1, 128, 8);
     }
+#undef BMC_LAUNCH_CONV
     BMC_CHECK_LAUNCH("bmc_conv");
     return 0;
 }
