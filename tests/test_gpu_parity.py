@@ -538,3 +538,44 @@ def test_fused_twin_bie_matches_unfused_autograd_path():
     assert len(res[0][4]) == 16
     for ga, gb in zip(res[1][4], res[0][4]):
         assert rel_l2(ga, gb) < 5e-5
+
+
+def test_training_reduces_loss_and_matches_oracle_trajectory():
+    """Three optimizer steps of the reference's recipe (Adam lr=1e-4, wd=1e-5, amsgrad; train.py:647-656) on the HIP
+    path vs the same three steps of the CPU oracle + torch.optim.Adam: losses agree step by step (the trajectory, not
+    only one gradient), and the loss goes down."""
+    dev = _gpu()
+    from models.BMCNet_plain import BMCNet_plain
+    from oracle import bmc_oracle as O
+    from train_step import bptt_step
+    torch.manual_seed(5)
+    scale, n_c, n_b, B, L, H, W = 4, 16, 2, 2, 3, 10, 12
+    m = BMCNet_plain(scale, n_c, n_b)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(3.0)
+    # oracle side: same parameters (aliasing rebuilt), same optimizer
+    params, seen = {}, {}
+    for k, v in m.state_dict().items():
+        params[k] = seen.setdefault(v.data_ptr(), v.clone().requires_grad_())
+    uniq = list(seen.values())
+    opt_ref = torch.optim.Adam(uniq, lr=1e-3, weight_decay=1e-5, amsgrad=True)
+    inp = torch.poisson(torch.full((B, L, 2, H, W), 0.4))
+    gt = torch.poisson(torch.full((B, L, 2, scale * H, scale * W), 0.4))
+    ref_losses = []
+    for _ in range(3):
+        opt_ref.zero_grad()
+        loss, _, _ = O.bptt_loss(params, [inp[:, i:i + 2].transpose(1, 2) for i in range(L - 1)],
+                                 [gt[:, i + 1] for i in range(L - 1)], n_c, scale, plain=True)
+        loss.backward()
+        opt_ref.step()
+        ref_losses.append(loss.item())
+    m.to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-5, amsgrad=True)
+    losses = []
+    for _ in range(3):
+        loss, _ = bptt_step(m, opt, inp.to(dev), gt.to(dev), n_c, scale, plain=True)
+        losses.append(loss.item())
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) < 1e-4 * abs(b), (losses, ref_losses)
+    assert losses[-1] < losses[0]
