@@ -221,12 +221,12 @@ def main():
             "value": round(value, 3), "unit": "LR-voxel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BMCNet x4 NFS %dx%d->%dx%d, bs=%d/GPU fp32, SEQL=%d SEQN=2 (%d windows BPTT), "
+            "config": {"workload": "BMCNet(scale=4, n_c=%d, n_b=%d) x4 NFS %dx%d->%dx%d, bs=%d/GPU fp32, SEQL=%d SEQN=2 (%d windows BPTT), "
                                    "event scatter + fwd + MSE + bwd + Adam(amsgrad)%s%s" %
-                                   (H, W, scale * H, scale * W, B, L, windows, " + RCCL grad all-reduce" if use_dist else "",
+                                   (n_c, n_b, H, W, scale * H, scale * W, B, L, windows, " + RCCL grad all-reduce" if use_dist else "",
                                     " [per-window recompute]" if args.recompute else "") + (" [HIP graph replay]" if args.graph else ""),
                        "global_batch": world * B, "frames_per_step": frames_per_step,
-                       "parallelism": "dp%d" % world, "n_c": n_c, "n_b": n_b, "peak_mem_GiB": round(peak_mem, 1),
+                       "parallelism": "dp%d" % world, "peak_mem_GiB": round(peak_mem, 1),
                        "final_loss": round(float(loss), 6)},
             "roofline": roof,
         }
