@@ -579,3 +579,51 @@ def test_training_reduces_loss_and_matches_oracle_trajectory():
     for a, b in zip(losses, ref_losses):
         assert abs(a - b) < 1e-4 * abs(b), (losses, ref_losses)
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("cls_name,scale,n_c,n_b,H,W", [
+    ("BMCNet", 8, 16, 1, 9, 11),          # x8 SR: 64-channel pixel-unshuffle halves, 128-channel conv_o
+    ("BMCNet_plain", 4, 64, 1, 12, 20),   # n_c = 64: half-filled 128-channel tiles, LayerNorm over 64 channels
+    ("BMCNet", 4, 48, 2, 10, 17),         # n_c = 48 is not a power of two -> LayerNorm must refuse loudly
+])
+def test_other_model_shapes_vs_oracle(cls_name, scale, n_c, n_b, H, W):
+    dev = _gpu()
+    import models.BMCNet as MB
+    import models.BMCNet_plain as MP
+    from oracle import bmc_oracle as O
+    plain = cls_name == "BMCNet_plain"
+    torch.manual_seed(17)
+    m = (MP.BMCNet_plain if plain else MB.BMCNet)(scale, n_c, n_b)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(4.0)
+    params, seen = {}, {}
+    for k, v in m.state_dict().items():
+        params[k] = seen.setdefault(v.data_ptr(), v.clone().requires_grad_())
+    B, L = 2, 3
+    inp = torch.poisson(torch.full((B, L, 2, H, W), 0.4))
+    gt = torch.poisson(torch.full((B, L, 2, scale * H, scale * W), 0.4))
+    xs = [inp[:, i:i + 2].transpose(1, 2) for i in range(L - 1)]
+    gts = [gt[:, i + 1] for i in range(L - 1)]
+    m.to(dev)
+    z = lambda c: torch.zeros(B, c, H, W, device=dev)
+    if n_c == 48:
+        with pytest.raises(RuntimeError, match="unsupported"):
+            m(xs[0].to(dev), z(n_c), z(n_c), z(n_c), z(2 * scale * scale), True)
+        return
+    loss_ref, preds_ref, _ = O.bptt_loss(params, xs, gts, n_c, scale, plain)
+    loss_ref.backward()
+    state = (z(n_c), z(2 * scale * scale)) if plain else (z(n_c), z(n_c), z(n_c), z(2 * scale * scale))
+    loss = 0
+    for i in range(L - 1):
+        state = m(xs[i].to(dev), *state, i == 0)
+        assert rel_l2(state[-1], preds_ref[i]) < 1e-4, i
+        loss = loss + F.mse_loss(state[-1], gts[i].to(dev))
+    loss.backward()
+    n = 0
+    for name, p in m.named_parameters():
+        if params[name].grad is None:
+            continue
+        assert rel_l2(p.grad, params[name].grad) < 1e-3, name
+        n += 1
+    assert n >= 15
