@@ -627,3 +627,50 @@ def test_other_model_shapes_vs_oracle(cls_name, scale, n_c, n_b, H, W):
         assert rel_l2(p.grad, params[name].grad) < 1e-3, name
         n += 1
     assert n >= 15
+
+
+def test_conv_fuzz_random_shapes_vs_torch():
+    """40 random convolution problems (1x1 / 3x3, 1-5 sources of 16..64 channels, Cout 16..160, odd image sizes up to
+    70x90, batch 1..5, bias / ReLU / residual on or off): forward, data, weight and bias gradients vs F.conv2d.
+    Exercises every tile shape of the size-adaptive dispatcher (8x16x128, 4x16x128, 4x16x64, 8x16x32)."""
+    dev = _gpu()
+    import random
+    from bmc_hip import ops
+    from bmc_hip.ops import ConvSpec, View
+    rnd = random.Random(1234)
+    g = torch.Generator().manual_seed(99)
+    for case in range(40):
+        k = rnd.choice([1, 3])
+        nsrc = rnd.randint(1, 5)
+        cins = [16 * rnd.randint(1, 4) for _ in range(nsrc)]
+        cout = 16 * rnd.choice([1, 2, 3, 4, 8, 10])
+        B, H, W = rnd.randint(1, 5), rnd.randint(3, 70), rnd.randint(3, 90)
+        relu, res, bias = rnd.random() < 0.5, rnd.random() < 0.5, rnd.random() < 0.7
+        xs = [torch.randn(B, c, H, W, generator=g) for c in cins]
+        cin = sum(cins)
+        w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        b = torch.randn(cout, generator=g) if bias else None
+        r = torch.randn(B, cout, H, W, generator=g) if res else None
+        go = torch.randn(B, cout, H, W, generator=g)
+        xs_c = [x.clone().requires_grad_() for x in xs]
+        w_c = w.clone().requires_grad_()
+        b_c = b.clone().requires_grad_() if bias else None
+        y = F.conv2d(torch.cat(xs_c, 1), w_c, b_c, padding=k // 2)
+        if res:
+            y = y + r
+        if relu:
+            y = torch.relu(y)
+        y.backward(go)
+        xs_g = [_nhwc(x).to(dev).requires_grad_() for x in xs]
+        w_g = w.to(dev).requires_grad_()
+        b_g = b.to(dev).requires_grad_() if bias else None
+        yg = ops.conv([View(x) for x in xs_g], w_g, b_g, ConvSpec.dense(*cins), relu=relu,
+                      residual=View(_nhwc(r).to(dev)) if res else None)
+        yg.backward(_nhwc(go).to(dev))
+        tag = (case, k, cins, cout, B, H, W, relu, res, bias)
+        assert rel_l2(yg.permute(0, 3, 1, 2), y) < 2e-5, tag
+        for xg, xc in zip(xs_g, xs_c):
+            assert rel_l2(xg.grad.permute(0, 3, 1, 2), xc.grad) < 2e-5, tag
+        assert rel_l2(w_g.grad, w_c.grad) < 3e-5, tag
+        if bias:
+            assert rel_l2(b_g.grad, b_c.grad) < 3e-5, tag
