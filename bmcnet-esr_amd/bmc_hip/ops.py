@@ -731,3 +731,13 @@ def encode_raw_events(xs_i16, ys_i16, ps_f64, offsets, flips, H, W):
     lib.call(lib._enc_raw, "bmc_encode_raw_events", xs_i16.data_ptr(), ys_i16.data_ptr(), ps_f64.data_ptr(),
              offsets.data_ptr(), fp, nframes, H, W, out.data_ptr(), _stream())
     return out
+
+
+def events_to_voxel_batched(xs, ys, ts, ps, offsets, bins, H, W, mutate=True):
+    """fp32 device vectors + int64 frame offsets -> [nframes, bins, H, W] temporal-bilinear voxel grids."""
+    _need_gpu(xs)
+    nframes = offsets.numel() - 1
+    out = torch.empty((nframes, bins, H, W), device=xs.device, dtype=torch.float32)
+    lib.call(lib._voxel, "bmc_events_to_voxel", xs.data_ptr(), ys.data_ptr(), ts.data_ptr(), ps.data_ptr(),
+             offsets.data_ptr(), nframes, bins, H, W, out.data_ptr(), int(mutate), _stream())
+    return out

@@ -59,7 +59,46 @@ __global__ void encode_raw_kernel(const short* __restrict__ xs, const short* __r
     }
 }
 
+// Temporal-bilinear voxel grid (dataloader/encodings.py:272-287): bin b receives p * max(0, 1 - |t*(bins-1) - b|)
+// through events_to_image(), i.e. with the vertical flip and with the same side effect as above: the FIRST bin's call
+// zeroes out-of-range events and resets their coordinates in place, so in every later bin they are no longer masked
+// and deposit their weight at [H-1, 0].  Weights are arbitrary floats: the sum is accumulated with float atomics, so
+// (like the reference's multi-threaded index_put_) it is defined up to summation order.
+__global__ void voxel_kernel(float* __restrict__ xs, float* __restrict__ ys, const float* __restrict__ ts,
+                             const float* __restrict__ ps, const long long* __restrict__ offsets, int bins, int H, int W,
+                             float* __restrict__ out, int mutate) {
+    const int f = blockIdx.y;
+    const long long e0 = offsets[f], e1 = offsets[f + 1];
+    float* const vox = out + (long long)f * bins * H * W;
+    for (long long e = e0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += (long long)gridDim.x * blockDim.x) {
+        float x = xs[e], y = ys[e];
+        const float p = ps[e], t = ts[e] * (float)(bins - 1);
+        const bool oob = (x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f);
+        if (oob) {
+            x = 0.f; y = 0.f;
+            if (mutate) { xs[e] = 0.f; ys[e] = 0.f; }
+        }
+        const long long pix = (long long)(H - (int)y - 1) * W + (int)x;
+        for (int b = 0; b < bins; ++b) {
+            const float wgt = p * fmaxf(0.f, 1.0f - fabsf(t - (float)b));
+            if (wgt != 0.f && !(oob && b == 0)) atomicAdd(vox + (long long)b * H * W + pix, wgt);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int bmc_events_to_voxel(float* xs, float* ys, const float* ts, const float* ps, const long long* offsets,
+                                   int nframes, int bins, int H, int W, float* out, int mutate, bmc_stream_t s) {
+    BMC_CHECK_ARG(nframes >= 0 && bins >= 1 && H > 0 && W > 0 && out, "bmc_events_to_voxel: bad shape");
+    hipStream_t st = (hipStream_t)s;
+    if (nframes == 0) return 0;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)nframes * bins * H * W * sizeof(float), st);
+    if (e != hipSuccess) { bmc_set_error("bmc_events_to_voxel: memset failed: %s", hipGetErrorString(e)); return -2; }
+    hipLaunchKernelGGL(voxel_kernel, dim3(64, nframes), dim3(256), 0, st, xs, ys, ts, ps, offsets, bins, H, W, out, mutate);
+    BMC_CHECK_LAUNCH("bmc_events_to_voxel");
+    return 0;
+}
 
 extern "C" int bmc_encode_raw_events(const short* xs, const short* ys, const double* ps, const long long* offsets,
                                      const unsigned char* flips, int nframes, int H, int W, float* out, bmc_stream_t s) {

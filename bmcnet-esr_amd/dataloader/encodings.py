@@ -21,6 +21,16 @@ def events_to_channels(xs, ys, ps, sensor_size=(180, 240)):
     return ops.events_to_channels_batched(xs, ys, ps, off, int(sensor_size[0]), int(sensor_size[1]), mutate=True)[0]
 
 
+def events_to_voxel(xs, ys, ts, ps, num_bins, sensor_size=(180, 240)):
+    """Voxel grid [num_bins,H,W] with temporal bilinear interpolation (reference: dataloader/encodings.py:272-287),
+    on GPU tensors; as in the reference the caller's xs/ys lose their out-of-range entries (reset to 0)."""
+    assert len(xs) == len(ys) and len(ys) == len(ts) and len(ts) == len(ps)
+    if not (xs.is_cuda and ys.is_cuda and ts.is_cuda and ps.is_cuda):
+        raise RuntimeError("events_to_voxel: tensors must live on the MI355X (no CPU fallback in this build)")
+    off = torch.tensor([0, xs.numel()], dtype=torch.int64, device=xs.device)
+    return ops.events_to_voxel_batched(xs, ys, ts, ps, off, int(num_bins), int(sensor_size[0]), int(sensor_size[1]))[0]
+
+
 def events_to_channels_batch(xs, ys, ps, offsets, sensor_size=(180, 240), mutate=True):
     """Many frames in one launch: frame f owns events [offsets[f], offsets[f+1]) -> [nframes,2,H,W]."""
     return ops.events_to_channels_batched(xs, ys, ps, offsets, int(sensor_size[0]), int(sensor_size[1]), mutate=mutate)

@@ -59,6 +59,12 @@ const char* bmc_last_error(void);
 int bmc_events_to_channels(float* xs, float* ys, const float* ps, const long long* offsets,
                            int nframes, int H, int W, float* out, int mutate, bmc_stream_t s);
 
+/* events_to_voxel(): temporal-bilinear voxel grid [nframes][bins][H][W] (dataloader/encodings.py:272-287; ts already
+ * normalised to [0,1] by event_formatting).  Same coordinate conventions and first-call side effect as above; float
+ * weights are summed with float atomics (summation order undefined, as in the reference's threaded index_put_). */
+int bmc_events_to_voxel(float* xs, float* ys, const float* ts, const float* ps, const long long* offsets,
+                        int nframes, int bins, int H, int W, float* out, int mutate, bmc_stream_t s);
+
 /* Sequence encoder on raw dataset columns: what H5Dataset.__getitem__ does per frame on the CPU
  * (dataloader/h5dataset.py:261-316: get_events :407-414 -> augment_event :559-578 -> event_formatting
  * base_dataset.py:24-31 -> events_to_channels), for all frames of a batch in one launch.

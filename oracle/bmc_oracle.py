@@ -67,6 +67,27 @@ def events_to_channels_np(xs, ys, ps, sensor_size=(180, 240)):
     return out, xs, ys
 
 
+def events_to_voxel_np(xs, ys, ts, ps, num_bins, sensor_size=(180, 240)):
+    """Temporal-bilinear voxel grid, numpy restatement of dataloader/encodings.py:272-287 (events_to_voxel calling
+    events_to_image :241-269 once per bin).  The first bin's call resets out-of-range coordinates in the caller's
+    arrays (and zeroes only ITS temporary weights), so from the second bin on those events are unmasked and land on
+    [H-1, 0].  Accumulation in float32, in event order.  Returns (voxel[bins,H,W], xs_after, ys_after)."""
+    H, W = int(sensor_size[0]), int(sensor_size[1])
+    xs = np.array(xs, dtype=np.float32, copy=True)
+    ys = np.array(ys, dtype=np.float32, copy=True)
+    ps = np.asarray(ps, dtype=np.float32)
+    t = (np.asarray(ts, dtype=np.float32) * np.float32(num_bins - 1)).astype(np.float32)
+    out = np.zeros((num_bins, H, W), dtype=np.float32)
+    for b in range(num_bins):
+        wgt = (ps * np.maximum(np.float32(0), np.float32(1.0) - np.abs(t - np.float32(b)))).astype(np.float32)
+        oob = (xs >= W) | (xs < 0) | (ys >= H) | (ys < 0)
+        xs[oob] = 0
+        ys[oob] = 0
+        wgt = np.where(oob, np.float32(0), wgt)
+        np.add.at(out[b], (H - ys.astype(np.int64) - 1, xs.astype(np.int64)), wgt)
+    return out, xs, ys
+
+
 def encode_raw_frame_np(xs_i16, ys_i16, ps_f64, flags, sensor_size):
     """One dataset item's count image from raw HDF5 columns: get_events (dataloader/h5dataset.py:407-414, the
     int16/float64 columns are concatenated into ONE float64 array), augment_event (:559-578, flips in float64),

@@ -269,12 +269,37 @@ def gen_raw_events():
     np.savez_compressed(os.path.join(OUT, "events_raw.npz"), **out)
 
 
+# ---------------------------------------------------------------- temporal-bilinear voxel grid
+def gen_voxel():
+    from dataloader.encodings import events_to_voxel
+    rng = np.random.default_rng(5)
+    out = {}
+    cases = [("a", (17, 23), 900, 5), ("b", (45, 80), 2048, 3), ("c", (8, 9), 0, 4), ("d", (12, 10), 300, 1), ("e", (20, 31), 1500, 2)]
+    for tag, (H, W), n, bins in cases:
+        xs = rng.uniform(-1.5, W + 1.5, n).astype(np.float32)
+        ys = rng.uniform(-1.5, H + 1.5, n).astype(np.float32)
+        ts = np.sort(rng.uniform(0, 1, n)).astype(np.float32)
+        ps = rng.choice([-1.0, 1.0], n).astype(np.float32)
+        xt, yt, tt, pt = (torch.tensor(a) for a in (xs, ys, ts, ps))
+        torch.set_num_threads(1)                     # sequential index_put_: a fixed summation order for the golden
+        vox = events_to_voxel(xt, yt, tt, pt, bins, sensor_size=(H, W))
+        torch.set_num_threads(8)
+        for k, v in (("xs", xs), ("ys", ys), ("ts", ts), ("ps", ps), ("vox", vox.numpy()), ("xs_after", xt.numpy()),
+                     ("ys_after", yt.numpy()), ("meta", np.asarray([H, W, bins]))):
+            out[f"{tag}/{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "voxel.npz"), **out)
+
+
 if __name__ == "__main__":
+    if os.environ.get("BMC_GOLDEN_ONLY") == "voxel":
+        gen_voxel()
+        sys.exit(0)
     if os.environ.get("BMC_GOLDEN_ONLY") == "raw":
         gen_raw_events()
         sys.exit(0)
     gen_events()
     gen_raw_events()
+    gen_voxel()
     gen_layers()
     gen_model("bmcnet_nc16", BMCNet, 16, 2, 2, 10, 12, 3, seed=21, plain=False, wscale=0.6)
     gen_model("plain_nc16", BMCNet_plain, 16, 2, 2, 9, 7, 3, seed=22, plain=True)

@@ -674,3 +674,18 @@ def test_conv_fuzz_random_shapes_vs_torch():
         assert rel_l2(w_g.grad, w_c.grad) < 3e-5, tag
         if bias:
             assert rel_l2(b_g.grad, b_c.grad) < 3e-5, tag
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+def test_events_to_voxel_golden(tag):
+    """GPU voxel encoder vs the reference's output.  Float weights + atomics: equal up to summation order
+    (abs 1e-5 on values of O(1..10)); the in-place reset of out-of-range coordinates is exact."""
+    dev = _gpu()
+    from dataloader.encodings import events_to_voxel
+    z = load("voxel.npz")
+    H, W, bins = (int(v) for v in z[f"{tag}/meta"])
+    xs, ys, ts, ps = (torch.tensor(z[f"{tag}/{k}"], device=dev) for k in ("xs", "ys", "ts", "ps"))
+    vox = events_to_voxel(xs, ys, ts, ps, bins, (H, W))
+    assert vox.shape == (bins, H, W)
+    assert np.abs(vox.cpu().numpy() - z[f"{tag}/vox"]).max() <= 1e-5
+    assert np.array_equal(xs.cpu().numpy(), z[f"{tag}/xs_after"]) and np.array_equal(ys.cpu().numpy(), z[f"{tag}/ys_after"])

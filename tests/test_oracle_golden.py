@@ -194,3 +194,15 @@ def test_product_augment_flags_match_reference_seeding():
     z = load("events_raw.npz")
     for i in range(int(z["n"])):
         assert augment_flags(int(z[f"c{i}/seed"])) == int(z[f"c{i}/flags"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+def test_events_to_voxel_oracle(tag):
+    """Temporal-bilinear voxel grid (dataloader/encodings.py:272-287) incl. the out-of-range side effect of the first
+    bin's call; the golden was produced with one thread (sequential accumulation), which the oracle reproduces bit
+    for bit."""
+    z = load("voxel.npz")
+    H, W, bins = (int(v) for v in z[f"{tag}/meta"])
+    vox, xa, ya = O.events_to_voxel_np(z[f"{tag}/xs"], z[f"{tag}/ys"], z[f"{tag}/ts"], z[f"{tag}/ps"], bins, (H, W))
+    assert np.array_equal(vox, z[f"{tag}/vox"])
+    assert np.array_equal(xa, z[f"{tag}/xs_after"]) and np.array_equal(ya, z[f"{tag}/ys_after"])
