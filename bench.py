@@ -31,14 +31,16 @@ FLOP_PER_LRPX_FWD_BWD = 118_121_472      # BMCNet(4,128,5) one window forward+ba
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def cpu_baseline(budget_hw=(90, 120)):
+def cpu_baseline(budget_hw=(180, 240), threads=16):
     """CPU oracle (the PyTorch-CPU restatement of the reference path, oracle/bmc_oracle.py) timed on this host:
-    one BMCNet window forward+backward, B=1, on a bounded sample (a quarter-size LR frame), converted to
-    180x240 frame-equivalents per second.  Reported only; never the thing optimised."""
+    one BMCNet window forward+backward, B=1, on a bounded sample (one 180x240 LR frame), in frames per second.
+    16 threads is the measured optimum of torch-CPU on the GPU box's 256-thread host for this network (8: 1.08 s,
+    16: 0.67 s, 32: 1.08 s, 64: 2.3 s, 128: 8.6 s per quarter frame).  Reported only; never the thing optimised."""
     from models.BMCNet import BMCNet
     from oracle import bmc_oracle as O
     import torch.nn.functional as F
     torch.manual_seed(3407)
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
     scale, n_c, n_b = 4, 128, 5
     H, W = budget_hw
     m = BMCNet(scale, n_c, n_b)
