@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must come first: libbmc_hip.so has to bind to the
               # (torch ships its own libamdhip64; two runtimes in one process do not share the device context)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libbmc_hip.so")
+LIB_PATH = os.environ.get("BMC_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libbmc_hip.so")  # override: tools/ experiments only
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -37,7 +37,8 @@ class ConvArgs(C.Structure):
                 ("w_group_stride", C.c_longlong), ("bias_group_stride", C.c_int), ("batch_per_group", C.c_int),
                 ("out", C.c_void_p), ("out_batch_stride", C.c_longlong), ("out_pix_stride", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cout", C.c_int), ("Coutpad", C.c_int),
-                ("taps", C.c_int), ("relu", C.c_int), ("residual", Src), ("mask", Src), ("accumulate", C.c_int)]
+                ("taps", C.c_int), ("relu", C.c_int), ("residual", Src), ("mask", Src), ("accumulate", C.c_int),
+                ("math", C.c_int)]
 
 
 class PgemmArgs(C.Structure):
@@ -62,6 +63,7 @@ _voxel = _sig("bmc_events_to_voxel", [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i
 _enc_raw = _sig("bmc_encode_raw_events", [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p])
 _pack_w = _sig("bmc_pack_weight", [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p])
 _pack_wt = _sig("bmc_pack_weight_t", [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p])
+_split_w = _sig("bmc_split_weight", [_p, _p, _ll, _i, _i, _p])
 _conv = _sig("bmc_conv", [C.POINTER(ConvArgs), _p])
 _pgemm = _sig("bmc_pgemm", [C.POINTER(PgemmArgs), _p])
 _red_w = _sig("bmc_pgemm_reduce_weight", [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p])
@@ -76,7 +78,7 @@ _pack_in = _sig("bmc_pack_inputs", [_p, _ll, _ll, _ll, _ll, _ll, _i, _i, _i, _i,
 _unshuffle = _sig("bmc_unshuffle_to_nhwc", [_p, _i, _i, _i, _i, _i, _p, _p])
 _shuffle = _sig("bmc_shuffle_to_hr", [_p, _i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _ll, _p, _p])
 
-EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_events_to_voxel", "bmc_encode_raw_events", "bmc_pack_weight", "bmc_pack_weight_t", "bmc_conv",
+EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_events_to_voxel", "bmc_encode_raw_events", "bmc_pack_weight", "bmc_pack_weight_t", "bmc_split_weight", "bmc_conv",
            "bmc_pgemm", "bmc_pgemm_reduce_weight", "bmc_pgemm_reduce_plain", "bmc_colsum", "bmc_relu_bwd",
            "bmc_layernorm_fwd", "bmc_layernorm_bwd", "bmc_softmax_fwd", "bmc_softmax_bwd", "bmc_pack_inputs",
            "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr"]

@@ -8,6 +8,7 @@ models/BMCNet.py); each function cites what it stands in for.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import List, Optional, Sequence
 
@@ -133,6 +134,29 @@ def _prof_end(e0, kind, flops):
         PROFILE.append((kind, flops, e0, e1))
 
 
+# Arithmetic of the convolution kernels (include/bmc_hip.h BMC_MATH_*): 0 = native fp32 MFMA (default, the headline
+# path), 1 = bf16 operands / fp32 accumulate, 3 = fp32 operands split into three bf16 planes, six plane products
+# (fp32-equivalent).  Set with set_math() or BMC_MATH=fp32|bf16|bf16x6 before the first launch.
+MATH_NAMES = {"fp32": 0, "bf16": 1, "bf16x6": 3}
+MATH = MATH_NAMES[os.environ.get("BMC_MATH", "fp32")]
+
+
+def set_math(mode):
+    """mode: "fp32" | "bf16" | "bf16x6" (or 0 / 1 / 3).  Packed-weight caches are keyed by the mode."""
+    global MATH
+    MATH = MATH_NAMES[mode] if isinstance(mode, str) else int(mode)
+    if MATH not in (0, 1, 3):
+        raise ValueError("unknown math mode %r" % (mode,))
+
+
+def _split_planes(packed: torch.Tensor, cp: int):
+    """fp32 pack [nsteps][cp][16] -> bf16 planes [nsteps][MATH][cp][16] (bmc_split_weight)."""
+    nsteps = packed.numel() // (cp * CK)
+    out = torch.empty(nsteps * MATH * cp * (CK // 2), device=packed.device, dtype=torch.int32)
+    lib.call(lib._split_w, "bmc_split_weight", packed.data_ptr(), out.data_ptr(), nsteps, cp, MATH, _stream())
+    return out
+
+
 def _cache_get(spec: ConvSpec, kind, owner):
     """Packed weights are cached on the ConvSpec, keyed by (kind, id(owner)) and validated by a weak reference to
     the owning parameter plus its version counter (an address or id alone can be recycled by the allocator)."""
@@ -156,20 +180,22 @@ def _packed_weight(w4: torch.Tensor, spec: ConvSpec, owner):
     """[G,Cout,Cin,taps] -> MFMA staging layout (bmc_pack_weight).  owner: the parameter tensor w4 was derived
     from (cache key), or None for no caching."""
     G, Cout, Cin, taps = w4.shape
-    hit = _cache_get(spec, "f", owner)
+    hit = _cache_get(spec, ("f", MATH), owner)
     if hit is not None:
         return hit
     cp = coutpad(Cout)
     out = torch.empty(G * spec.kpad * taps * cp, device=w4.device, dtype=torch.float32)
     lib.call(lib._pack_w, "bmc_pack_weight", w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin, taps,
              spec.kpad, cp, out.data_ptr(), _stream())
-    _cache_put(spec, "f", owner, out)
+    if MATH:
+        out = _split_planes(out, cp)
+    _cache_put(spec, ("f", MATH), owner, out)
     return out
 
 
 def _packed_weight_t(w4: torch.Tensor, spec: ConvSpec, src_index: int, owner):
     G, Cout, Cin, taps = w4.shape
-    hit = _cache_get(spec, ("t", src_index), owner)
+    hit = _cache_get(spec, ("t", src_index, MATH), owner)
     if hit is not None:
         return hit
     k0 = sum(spec.nch[:src_index])
@@ -179,7 +205,9 @@ def _packed_weight_t(w4: torch.Tensor, spec: ConvSpec, src_index: int, owner):
     out = torch.empty(G * c16 * taps * nkpad, device=w4.device, dtype=torch.float32)
     lib.call(lib._pack_wt, "bmc_pack_weight_t", w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin, taps,
              k0, nk, nkpad, c16, out.data_ptr(), _stream())
-    _cache_put(spec, ("t", src_index), owner, out)
+    if MATH:
+        out = _split_planes(out, nkpad)
+    _cache_put(spec, ("t", src_index, MATH), owner, out)
     return out
 
 
@@ -199,7 +227,8 @@ def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stri
         a.src[i] = s
     a.wpacked = wpacked.data_ptr()
     a.bias = bias.data_ptr() if bias is not None else None
-    a.w_group_stride = w_group_stride
+    a.w_group_stride = w_group_stride * MATH // 2 if MATH else w_group_stride   # floats, or dwords of bf16 planes
+    a.math = MATH
     a.bias_group_stride = bias_group_stride
     a.batch_per_group = bpg if bpg else B
     a.out = out_ptr

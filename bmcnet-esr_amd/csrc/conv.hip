@@ -14,6 +14,7 @@
 // the k-order inside a chunk is permuted identically for A and B, which a dot
 // product does not care about.
 #include "bmc_common.h"
+#include "conv_k.h"
 #include <stdlib.h>
 
 #ifndef BMC_LX
@@ -37,24 +38,6 @@ constexpr int CK = BMC_CK;  // channels per chunk
 constexpr int RS = 20;      // LDS row stride in floats (16 + 4 pad: conflict-free ds_read_b128)
 constexpr int TW = 16;      // tile width; the tile height TH (8 or 4 rows) is a kernel template parameter
 
-struct ConvK {
-    int nsrc;
-    SrcDev src[BMC_MAX_SRC];
-    const float* w;
-    const float* bias;
-    long long w_group_stride;
-    int bias_group_stride;
-    int batch_per_group;
-    float* out;
-    long long out_batch_stride;
-    int out_pix_stride;
-    int B, H, W, Cout, Coutpad;
-    int relu;
-    SrcDev residual;
-    SrcDev mask;
-    int accumulate;
-    int tiles_x, tiles_y, ntn, nchunks, ntiles;
-};
 
 // Tile shapes (4 waves): BN = 128: waves 2(px) x 2(ch), wave = (TH/2 rows x 16) px x 64 ch  [TH = 8: 2x2 MFMA tiles, TH = 4: 1x2]
 //                        BN =  64: waves 2 x 2,           wave = (TH/2 rows x 16) px x 32 ch  [small problems: 4x the workgroups]
@@ -129,7 +112,7 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
             const int hy = hp / HWD, hx = hp - hy * HWD;
             const int y = y0 - P + hy, x = x0 - P + hx;
             xok[n] = hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W;
-            xpix[n] = y * a.W + x;
+            xpix[n] = xok[n] ? y * a.W + x : 0;   // out-of-image lanes load pixel 0 (valid memory) and are zeroed: no branch
         }
         s_idx = 0; c_in = 0; xl_chunk = 0;
         src_select();
@@ -141,8 +124,9 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
 #pragma unroll
         for (int n = 0; n < NXLD; ++n) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (!(BMC_DIAG_MODE & (2 | 16)) && xok[n]) v = *reinterpret_cast<const f32x4*>(base + (long long)xpix[n] * spix);
-            xr[slot][n] = v;
+            if (!(BMC_DIAG_MODE & (2 | 16))) v = *reinterpret_cast<const f32x4*>(base + (long long)xpix[n] * spix);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xr[slot][n][k] = xok[n] ? v[k] : 0.f;
         }
         c_in += CK;
         if (++xl_chunk == a.nchunks) {
@@ -166,7 +150,7 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
     auto wl_setup = [&](int tile) {
         int b, y0, x0, nt;
         decode(tile, b, y0, x0, nt);
-        wl_base = a.w + (long long)(b / a.batch_per_group) * a.w_group_stride + (long long)nt * BN * CK;
+        wl_base = static_cast<const float*>(a.w) + (long long)(b / a.batch_per_group) * a.w_group_stride + (long long)nt * BN * CK;
         wl_step = 0;
     };
     auto load_w = [&]() {
@@ -175,7 +159,10 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
         for (int n = 0; n < NWLD; ++n) {
             const int e = tid + 256 * n;
             if (BMC_DIAG_MODE & (2 | 8)) { wr[n] = f32x4{1.f, 1.f, 1.f, 1.f}; continue; }
-            if (e < BN * 4) wr[n] = *reinterpret_cast<const f32x4*>(p + e * 4);
+            // no branch around the load (a divergent branch makes the compiler serialise the loads with vmcnt(0)):
+            // lanes past the slice re-read its last piece and never store it
+            const int ec = (n + 1) * 256 <= BN * 4 ? e : (e < BN * 4 ? e : BN * 4 - 1);
+            wr[n] = *reinterpret_cast<const f32x4*>(p + ec * 4);
         }
         if (++wl_step == nsteps) {
             wl_tile += t_stride;
@@ -186,7 +173,7 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
 #pragma unroll
         for (int n = 0; n < NWLD; ++n) {
             const int e = tid + 256 * n;
-            if (e < BN * 4) *reinterpret_cast<f32x4*>(Wb + buf * WBUF + (e >> 2) * RS + q4) = wr[n];
+            if ((n + 1) * 256 <= BN * 4 || e < BN * 4) *reinterpret_cast<f32x4*>(Wb + buf * WBUF + (e >> 2) * RS + q4) = wr[n];
         }
     };
 
@@ -419,6 +406,10 @@ extern "C" int bmc_conv(const bmc_conv_args_t* h, bmc_stream_t stream) {
     const long long ntiles = count(THv, BN);
     BMC_CHECK_ARG(ntiles < (1ll << 31), "bmc_conv: too many tiles");
     k.ntiles = (int)ntiles;
+    BMC_CHECK_ARG(h->math == BMC_MATH_FP32 || h->math == BMC_MATH_BF16 || h->math == BMC_MATH_BF16X6,
+                  "bmc_conv: unknown math mode %d", h->math);
+    if (h->math != BMC_MATH_FP32)
+        return bmc_conv_bf_launch(k, h->taps, BN, THv, h->math == BMC_MATH_BF16 ? 1 : 3, cus, (hipStream_t)stream);
     const int per_cu = (BN == 128 && THv == 8) ? 3 : 4;       // resident workgroups per CU (LDS / registers)
     const int max_blocks = cus * per_cu;
     dim3 grid((unsigned)(ntiles < max_blocks ? ntiles : max_blocks)), block(256);

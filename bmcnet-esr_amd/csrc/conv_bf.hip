@@ -1,0 +1,409 @@
+// Implicit-GEMM 3x3 / 1x1 convolution on the bf16 matrix cores of gfx950
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate), same operator as conv.hip:
+// NHWC fp32 activations in HBM, multi-source, fused epilogue, per-group weights.
+//
+// NP (planes) selects the arithmetic:
+//   NP = 1  operands rounded to bf16 (RNE) on their way into LDS: the "bf16 compute / fp32 accumulate" mode;
+//   NP = 3  every fp32 operand is split EXACTLY into three bf16 planes x = h + m + l (8 significand bits each) and the
+//           product is rebuilt from the six plane products of weight >= 2^-16: hh, hm, mh, hl, lh, mm.  The three
+//           dropped ones (ml, lm, ll) are <= 2^-24 |x w| together, the size of ONE fp32 rounding of the product;
+//           bf16 x bf16 products are exact in fp32 and the matrix core accumulates in fp32.  The bf16 pipe runs 16x
+//           the fp32 MFMA rate, so six products cost 6/16 of the native fp32 time.
+// The split happens once per element, when a tile goes from registers to LDS (activations), or once per step on the
+// packed weights (bmc_split_weight); LDS holds bf16 planes only.
+//
+// LDS image: per plane [row][16 bf16] = 32 B rows without padding.  An MFMA fragment read is one ds_read_b128 per lane
+// (lane l: row of l & 31, 16-byte half l >> 5); the hardware serves it in 16-lane groups {0-3,12-15,20-27} /
+// {4-11,16-19,28-31} over 64 banks (256 B), so each group takes 8 rows from lanes 0-15 and 8 from lanes 16-31 that
+// fall on the same 8 bank slots.  Swapping the two halves of every row that lanes 16-31 read (weights: rows with bit 4
+// set; pixels: odd halo rows) makes all fragment reads conflict-free.
+#include "conv_k.h"
+
+#ifndef BMC_BF_ABL
+#define BMC_BF_ABL 0   // ablation bits for experiment builds (tools/): 4 no MFMAs, 8 no weight loads, 16 no activation loads, 32 no split
+#endif
+
+namespace {
+
+typedef unsigned int u32;
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CK = BMC_CK;
+constexpr int TW = 16;
+constexpr int RD = 8;   // dwords per LDS row (16 bf16)
+
+__device__ __forceinline__ u32 pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: RNE, low half = a
+    return __builtin_bit_cast(u32, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ float lo_f(u32 p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f(u32 p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// four fp32 values -> NP planes of four bf16 (two dwords per plane)
+template <int NP>
+__device__ __forceinline__ void split4(const f32x4 v, u32x2 (&pl)[NP]) {
+    f32x4 r = v;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const u32 a = pack_bf16(r[0], r[1]), b = pack_bf16(r[2], r[3]);
+        pl[p] = u32x2{a, b};
+        if (p + 1 < NP) {   // exact residual (Sterbenz: the bf16 value shares the leading bits of r)
+            r[0] -= lo_f(a); r[1] -= hi_f(a); r[2] -= lo_f(b); r[3] -= hi_f(b);
+        }
+    }
+}
+
+__device__ __forceinline__ int swz_w(int row, int half) { return row * RD + 4 * (half ^ ((row >> 4) & 1)); }
+__device__ __forceinline__ int swz_x(int hp, int hy, int half) { return hp * RD + 4 * (half ^ (hy & 1)); }
+
+// 16 bytes per lane from global memory straight into LDS (lane-linear image at the wave-uniform LDS byte address).
+// Inline asm on purpose: the compiler must not track this as an LDS store, or it drains vmcnt(0) before every later
+// ds_read and the ring could never run ahead.  Completion is waited for explicitly (dma_wait) before the barrier
+// that publishes the stage.
+__device__ __forceinline__ void dma16(const void* gptr, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void dma_wait() {   // all but the newest N vector-memory operations of this wave are done
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+// Loader roles are split by wave, because a wave's vmcnt completes IN ORDER: a wave that issued the next chunk's halo
+// loads (HBM, needed 8 steps later) and then waits for a weight slice (L2, needed next step) waits for the halo too.
+//   waves 0-1: activation halo: global -> registers at a chunk's first tap, split into planes -> LDS at its last tap;
+//   waves 2-3: weight slices: LDS-DMA into a 3-stage ring, two steps ahead.
+template <int TAPS, int BN, int TH, int NP>
+__global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 2 : 3) void conv_bf_kernel(const ConvK a) {
+    static_assert((BN == 32 && TH == 8) || ((BN == 128 || BN == 64) && (TH == 8 || TH == 4)), "unsupported tile shape");
+    static_assert(NP == 1 || NP == 3, "planes");
+    constexpr int P = TAPS == 9 ? 1 : 0;
+    constexpr int HWD = TW + 2 * P, HHT = TH + 2 * P, NHALO = HWD * HHT;
+    constexpr int MT = BN == 32 ? 1 : TH / 4, NT = BN == 128 ? 2 : 1;
+    constexpr int NXLD = (NHALO * 4 + 127) / 128;        // float4 per loader thread (128 loader threads)
+    constexpr int NDMA = NP * BN * 2 / 64;               // 1 KB wave-instructions per weight slice
+    constexpr int XPL = NHALO * RD, WPL = BN * RD;       // dwords per plane
+    constexpr int XBUF = NP * XPL, WBUF = NP * WPL, NSTG = 3;
+    __shared__ __attribute__((aligned(16))) u32 lds[2 * XBUF + NSTG * WBUF + BMC_MAX_SRC * 8];
+    u32* const Xb = lds;
+    u32* const Wb = lds + 2 * XBUF;
+    SrcDev* const tab = reinterpret_cast<SrcDev*>(lds + 2 * XBUF + NSTG * WBUF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool xrole = wave < 2;
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < BMC_MAX_SRC; ++i)
+        if (tid == i) tab[i] = a.src[i];
+    __syncthreads();
+
+    // persistent workgroups with the XCD-aware tile walk of conv.hip
+    const int ntiles = a.ntiles;
+    constexpr int NX_ = 8;
+    const bool xcd_map = (gridDim.x % NX_) == 0 && ntiles >= (int)gridDim.x;
+    const int xcd = blockIdx.x % NX_, xj = blockIdx.x / NX_, per_x = gridDim.x / NX_;
+    const int t_lo = xcd_map ? (int)((long long)ntiles * xcd / NX_) : 0;
+    const int t_hi = xcd_map ? (int)((long long)ntiles * (xcd + 1) / NX_) : ntiles;
+    const int t_first = xcd_map ? t_lo + xj : (int)blockIdx.x;
+    const int t_stride = xcd_map ? per_x : (int)gridDim.x;
+    const int my_tiles = t_first < t_hi ? (t_hi - t_first + t_stride - 1) / t_stride : 0;
+    const int nsteps = a.nchunks * TAPS;
+    const int total_steps = my_tiles * nsteps, total_chunks = my_tiles * a.nchunks;
+    if (my_tiles == 0) return;
+    const long long wstep = (long long)NP * a.Coutpad * RD;   // dwords per step in the packed planes
+
+    auto decode = [&](int tile, int& b, int& y0, int& x0, int& nt) {
+        nt = tile % a.ntn; tile /= a.ntn;
+        x0 = (tile % a.tiles_x) * TW; tile /= a.tiles_x;
+        y0 = (tile % a.tiles_y) * TH;
+        b = tile / a.tiles_y;
+    };
+
+    // ---- X loader (waves 0-1): fp32 from HBM into registers; split into planes when written to LDS
+    const int xt = tid & 127, q = tid & 3;
+    int xl_tile = t_first, xl_chunk = 0, xl_b = 0, s_idx = 0, c_in = 0;
+    const float* sbase = nullptr;
+    int spix = 0, snch = 0;
+    auto src_select = [&]() {
+        const SrcDev S = tab[s_idx];
+        sbase = src_batch_ptr(S, xl_b); spix = S.pix_stride; snch = S.nch;
+    };
+    int xpix[NXLD];
+    bool xok[NXLD];
+    auto xl_setup = [&](int tile) {
+        int b, y0, x0, nt;
+        decode(tile, b, y0, x0, nt);
+        xl_b = b;
+#pragma unroll
+        for (int n = 0; n < NXLD; ++n) {
+            const int e = xt + 128 * n, hp = e >> 2;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int y = y0 - P + hy, x = x0 - P + hx;
+            xok[n] = hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            xpix[n] = xok[n] ? y * a.W + x : 0;   // out-of-image lanes load pixel 0 (valid memory) and are zeroed: no branch
+        }
+        s_idx = 0; c_in = 0; xl_chunk = 0;
+        src_select();
+    };
+    f32x4 xr[NXLD];
+    auto load_x = [&]() {
+        const float* base = sbase + c_in + q * 4;
+#pragma unroll
+        for (int n = 0; n < NXLD; ++n) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (!(BMC_BF_ABL & 16)) v = *reinterpret_cast<const f32x4*>(base + (long long)xpix[n] * spix);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xr[n][k] = xok[n] ? v[k] : 0.f;
+        }
+        c_in += CK;
+        if (++xl_chunk == a.nchunks) {
+            xl_tile += t_stride;
+            if (xl_tile < t_hi) xl_setup(xl_tile);
+        } else if (c_in >= snch) {
+            c_in = 0; ++s_idx;
+            src_select();
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < NXLD; ++n) {
+            const int e = xt + 128 * n, hp = e >> 2;
+            if ((n + 1) * 128 <= NHALO * 4 || hp < NHALO) {
+                u32x2 pl[NP];
+                split4<NP>(xr[n], pl);
+                u32* const dst = Xb + buf * XBUF + swz_x(hp, hp / HWD, q >> 1) + 2 * (q & 1);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(dst + p * XPL) = pl[p];
+            }
+        }
+    };
+    // ---- W loader (waves 2-3): the packed planes are already the LDS image (swizzle included): linear 1 KB pieces
+    const int w2 = wave & 1;
+    int wl_tile = t_first, wl_step = 0, wl_stage = 0;
+    const u32* wl_base = nullptr;
+    auto wl_setup = [&](int tile) {
+        int b, y0, x0, nt;
+        decode(tile, b, y0, x0, nt);
+        wl_base = static_cast<const u32*>(a.w) + (long long)(b / a.batch_per_group) * a.w_group_stride + (long long)nt * BN * RD;
+        wl_step = 0;
+    };
+    const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Wb;
+    auto dma_w = [&]() {   // one slice into ring stage wl_stage; this wave issues the pieces j = w2, w2 + 2, ...
+        const u32* p = wl_base + (long long)wl_step * wstep;
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) {
+            if ((j & 1) != w2 && NDMA > 1) continue;
+            if (NDMA == 1 && w2) continue;
+            const int e = j * 64 + lane;
+            const int pl = e / (BN * 2), within = e - pl * (BN * 2);
+            if (!(BMC_BF_ABL & 8))
+                dma16(p + (long long)pl * a.Coutpad * RD + within * 4, wb_lds + (unsigned)((wl_stage * WBUF + j * 256) * 4));
+        }
+        wl_stage = wl_stage == NSTG - 1 ? 0 : wl_stage + 1;
+        if (++wl_step == nsteps) {
+            wl_tile += t_stride;
+            if (wl_tile < t_hi) wl_setup(wl_tile);
+        }
+    };
+    constexpr int DMA_W0 = (NDMA + 1) / 2, DMA_W1 = NDMA / 2;   // pieces per slice issued by loader wave 0 / 1
+    auto wait_older_slices = [&]() {   // every slice but the one just issued has landed
+        if (w2 == 0) dma_wait<DMA_W0>(); else dma_wait<DMA_W1>();
+    };
+
+    // ---- MFMA fragment addressing: A = weights (rows = output channels), B = pixels (cols)
+    const int rowbase = BN == 32 ? 2 * wave : (TH / 2) * (wave >> 1);
+    const int cobase = BN == 32 ? 0 : (BN / 2) * (wave & 1);
+    int arow[MT], boff[NT];
+    const int ahy = rowbase + (li >> 4);   // halo row of this lane's pixel for t = 0, tap row 0 (parity is what matters)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) arow[t] = (rowbase + 2 * t + (li >> 4)) * HWD + (li & 15);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) boff[u] = swz_w(cobase + 32 * u + li, lh);
+
+    f32x16 acc[MT][NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    };
+    zero_acc();
+
+    u32x4 xf[NP][MT], wf[NP][NT];
+    auto read_frags = [&](const u32* xb, const u32* wb, int tapshift, int taprow) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                xf[p][t] = *reinterpret_cast<const u32x4*>(xb + p * XPL + swz_x(arow[t] + tapshift, ahy + taprow, lh));
+#pragma unroll
+            for (int u = 0; u < NT; ++u) wf[p][u] = *reinterpret_cast<const u32x4*>(wb + p * WPL + boff[u]);
+        }
+    };
+    auto mma = [&](int pw, int px) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[pw][u]),
+                                                                    __builtin_bit_cast(bf16x8, xf[px][t]), acc[t][u], 0, 0, 0);
+    };
+    auto mma_all = [&]() {   // in the order the fragments arrive from LDS (plane 0 first)
+        mma(0, 0);
+        if constexpr (NP == 3) { mma(0, 1); mma(1, 0); mma(1, 1); mma(0, 2); mma(2, 0); }
+    };
+    auto tap_shift = [](int tap) { return TAPS == 9 ? (tap / 3) * HWD + (tap % 3) : 0; };
+
+    auto epilogue = [&](int tile) {
+        int b, y0, x0, nt;
+        decode(tile, b, y0, x0, nt);
+        const int g = b / a.batch_per_group;
+        const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
+        float* const outb = a.out + (long long)b * a.out_batch_stride;
+        const float* const resb = a.residual.ptr ? src_batch_ptr(a.residual, b) : nullptr;
+        const float* const maskb = a.mask.ptr ? src_batch_ptr(a.mask, b) : nullptr;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int y = y0 + rowbase + 2 * t + (li >> 4), x = x0 + (li & 15);
+            const bool pok = y < a.H && x < a.W;
+            const long long pix = (long long)y * a.W + x;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int co = nt * BN + cobase + 32 * u + 8 * rq + 4 * lh;
+                    if (pok && co < a.Cout) {
+                        f32x4 v;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = acc[t][u][4 * rq + k];
+                        if (biasg) v += *reinterpret_cast<const f32x4*>(biasg + co);
+                        if (resb) v += *reinterpret_cast<const f32x4*>(resb + pix * a.residual.pix_stride + co);
+                        if (a.relu) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                        }
+                        if (maskb) {
+                            const f32x4 m = *reinterpret_cast<const f32x4*>(maskb + pix * a.mask.pix_stride + co);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = m[k] > 0.f ? v[k] : 0.f;
+                        }
+                        f32x4* o = reinterpret_cast<f32x4*>(outb + pix * a.out_pix_stride + co);
+                        if (a.accumulate) v += *o;
+                        *o = v;
+                    }
+                }
+            }
+        }
+        zero_acc();
+    };
+
+    // ---- prologue: halo of chunk 0 in LDS, weight slices 0 and 1 in flight, slice 0 landed
+    if (xrole) {
+        xl_setup(xl_tile);
+        load_x();
+        store_x(0);
+        if (TAPS == 1 && total_chunks > 1) load_x();
+    } else {
+        wl_setup(wl_tile);
+        dma_w();
+        if (total_steps > 1) { dma_w(); wait_older_slices(); } else dma_wait<0>();
+    }
+    __syncthreads();
+
+    // ---- main loop, one barrier per step s:
+    //   loaders : halo waves  - first tap: issue the next chunk's global loads; last tap: split + write them to LDS
+    //             weight waves - issue the DMA of slice s+2 into ring stage (s+2) % 3
+    //   all     : read this step's fragments, MFMAs
+    //   weight waves: wait until slice s+1 has landed (slice s+2 may stay in flight); barrier
+    int gs = 0, gc = 0, stage = 0;
+    for (int tile = t_first; tile < t_hi; tile += t_stride) {
+        for (int c = 0; c < a.nchunks; ++c, ++gc) {
+            const u32* const xb = Xb + (gc & 1) * XBUF;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap, ++gs) {
+                const bool last_tap = tap == TAPS - 1;
+                if (xrole) {
+                    if (TAPS == 9) {
+                        if (tap == 0 && gc + 1 < total_chunks) load_x();
+                        if (last_tap && gc + 1 < total_chunks) store_x((gc + 1) & 1);
+                    } else {
+                        if (gc + 1 < total_chunks) store_x((gc + 1) & 1);
+                        if (gc + 2 < total_chunks) load_x();
+                    }
+                } else {
+                    if (gs + 2 < total_steps) dma_w();
+                }
+                read_frags(xb, Wb + stage * WBUF, tap_shift(tap), TAPS == 9 ? tap / 3 : 0);
+                mma_all();
+                if (!xrole) {
+                    if (gs + 2 < total_steps) wait_older_slices(); else dma_wait<0>();
+                }
+                stage = stage == NSTG - 1 ? 0 : stage + 1;
+                __syncthreads();
+            }
+        }
+        epilogue(tile);
+    }
+}
+
+// packed fp32 weights [S][Coutpad][16] -> bf16 planes [S][NP][Coutpad][16] in the kernel's LDS image (halves swizzled)
+template <int NP>
+__global__ void split_weight_kernel(const float* __restrict__ in, u32* __restrict__ out, long long nquads, int Coutpad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one 4-channel quad
+    if (i >= nquads) return;
+    const int qd = (int)(i & 3);
+    const long long rowg = i >> 2;
+    const int row = (int)(rowg % Coutpad);
+    const long long s = rowg / Coutpad;
+    u32x2 pl[NP];
+    split4<NP>(*reinterpret_cast<const f32x4*>(in + i * 4), pl);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+        *reinterpret_cast<u32x2*>(out + ((s * NP + p) * Coutpad) * RD + swz_w(row, qd >> 1) + 2 * (qd & 1)) = pl[p];
+}
+
+}  // namespace
+
+extern "C" int bmc_split_weight(const float* packed, void* out, long long nsteps, int Coutpad, int planes, bmc_stream_t stream) {
+    BMC_CHECK_ARG(packed && out && nsteps > 0 && Coutpad > 0 && Coutpad % 32 == 0, "bmc_split_weight: bad arguments");
+    BMC_CHECK_ARG(planes == 1 || planes == 3, "bmc_split_weight: planes must be 1 or 3 (got %d)", planes);
+    const long long nquads = nsteps * Coutpad * 4;
+    const unsigned blocks = (unsigned)((nquads + 255) / 256);
+    if (planes == 1)
+        hipLaunchKernelGGL(split_weight_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, (u32*)out, nquads, Coutpad);
+    else
+        hipLaunchKernelGGL(split_weight_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, (u32*)out, nquads, Coutpad);
+    BMC_CHECK_LAUNCH("bmc_split_weight");
+    return 0;
+}
+
+int bmc_conv_bf_launch(const ConvK& k, int taps, int BN, int TH, int planes, int cus, hipStream_t st) {
+    const int per_cu = (BN == 128 && TH == 8) ? 2 : 3;
+    const long long max_blocks = (long long)cus * per_cu;
+    dim3 grid((unsigned)(k.ntiles < max_blocks ? k.ntiles : max_blocks)), block(256);
+#define BMC_LAUNCH_BF(TAPS_, BN_, TH_)                                                                     \
+    do {                                                                                                   \
+        if (planes == 3) hipLaunchKernelGGL((conv_bf_kernel<TAPS_, BN_, TH_, 3>), grid, block, 0, st, k);  \
+        else hipLaunchKernelGGL((conv_bf_kernel<TAPS_, BN_, TH_, 1>), grid, block, 0, st, k);              \
+    } while (0)
+    if (taps == 9) {
+        if (BN == 32) BMC_LAUNCH_BF(9, 32, 8);
+        else if (BN == 64) BMC_LAUNCH_BF(9, 64, 4);
+        else if (TH == 4) BMC_LAUNCH_BF(9, 128, 4);
+        else BMC_LAUNCH_BF(9, 128, 8);
+    } else {
+        if (BN == 32) BMC_LAUNCH_BF(1, 32, 8);
+        else if (BN == 64) BMC_LAUNCH_BF(1, 64, 4);
+        else if (TH == 4) BMC_LAUNCH_BF(1, 128, 4);
+        else BMC_LAUNCH_BF(1, 128, 8);
+    }
+#undef BMC_LAUNCH_BF
+    BMC_CHECK_LAUNCH("bmc_conv (bf16 planes)");
+    return 0;
+}

@@ -1,0 +1,26 @@
+// Kernel-argument block shared by the convolution kernels (conv.hip: fp32 MFMA; conv_bf.hip: bf16-plane MFMA).
+#pragma once
+#include "bmc_common.h"
+
+struct ConvK {
+    int nsrc;
+    SrcDev src[BMC_MAX_SRC];
+    const void* w;     // packed weights: fp32 [S][Coutpad][16] or bf16 planes [S][NP][Coutpad][16] (conv_bf.hip)
+    const float* bias;
+    long long w_group_stride;
+    int bias_group_stride;
+    int batch_per_group;
+    float* out;
+    long long out_batch_stride;
+    int out_pix_stride;
+    int B, H, W, Cout, Coutpad;
+    int relu;
+    SrcDev residual;
+    SrcDev mask;
+    int accumulate;
+    int tiles_x, tiles_y, ntn, nchunks, ntiles;
+};
+
+// conv_bf.hip: launch the bf16-plane kernel (planes = 1: bf16 operands; 3: fp32 operands split into three bf16 planes,
+// six plane products -- fp32-equivalent result) for an already validated argument block.
+int bmc_conv_bf_launch(const ConvK& k, int taps, int BN, int TH, int planes, int cus, hipStream_t st);

@@ -83,6 +83,13 @@ int bmc_pack_weight(const float* w, const int* kmap, int G, int Cout, int Cin, i
                     int Kpad, int Coutpad, float* out, bmc_stream_t s);
 int bmc_pack_weight_t(const float* w, const int* kmap, int G, int Cout, int Cin, int taps,
                       int k0, int nk, int nkpad, int Coutpad16, float* out, bmc_stream_t s);
+/* Packed fp32 weights [nsteps][Coutpad][16] (nsteps = G * Kpad/16 * taps) -> `planes` bf16 planes
+ * [nsteps][planes][Coutpad][16] for bmc_conv with math = BMC_MATH_BF16 (planes 1) / BMC_MATH_BF16X6 (planes 3);
+ * `out` holds nsteps*planes*Coutpad*16 bf16 values (2 bytes each). */
+#define BMC_MATH_FP32 0
+#define BMC_MATH_BF16 1
+#define BMC_MATH_BF16X6 3
+int bmc_split_weight(const float* packed, void* out, long long nsteps, int Coutpad, int planes, bmc_stream_t s);
 
 /* ---- implicit-GEMM convolution (fp32 MFMA) -------------------------------
  * Replaces F.conv2d at models/submodules.py:25-26,33-34,44-53,63-67,75 and
@@ -96,7 +103,7 @@ int bmc_pack_weight_t(const float* w, const int* kmap, int G, int Cout, int Cin,
 typedef struct bmc_conv_args {
     int nsrc;
     bmc_src_t src[BMC_MAX_SRC];
-    const float* wpacked;       /* from bmc_pack_weight */
+    const void* wpacked;        /* from bmc_pack_weight (math 0) or bmc_split_weight of it (math 1, 3) */
     const float* bias;          /* [G][Cout] or NULL */
     long long w_group_stride;   /* floats between groups in wpacked */
     int bias_group_stride;
@@ -111,6 +118,10 @@ typedef struct bmc_conv_args {
     bmc_src_t residual;         /* ptr NULL -> none; nch ignored */
     bmc_src_t mask;             /* ptr NULL -> none; out = mask > 0 ? v : 0 (ReLU backward) */
     int accumulate;             /* out += v */
+    int math;                   /* BMC_MATH_FP32 (0): v_mfma_f32_32x32x2_f32 on the fp32 operands;
+                                   BMC_MATH_BF16 (1): operands rounded to bf16, fp32 accumulate (v_mfma_f32_32x32x16_bf16);
+                                   BMC_MATH_BF16X6 (3): each fp32 operand split exactly into three bf16 planes, six plane
+                                   products with fp32 accumulate -- fp32-equivalent (error <= one fp32 rounding per product) */
 } bmc_conv_args_t;
 int bmc_conv(const bmc_conv_args_t* host_args, bmc_stream_t s);
 
