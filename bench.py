@@ -29,6 +29,11 @@ import torch.distributed as dist
 # algorithmic work (measured on the reference with torch.utils.flop_counter, 2 FLOP/MAC)
 FLOP_PER_LRPX_FWD_BWD = 118_121_472      # BMCNet(4,128,5) one window forward+backward
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2516.6           # 16 x the fp32 rate (v_mfma_f32_32x32x16_bf16, dense, 2.4 GHz)
+# peak of the dominant kernel per arithmetic mode, in algorithmic (fp32-equivalent) FLOP/s: the bf16x6 split spends six
+# bf16 MFMAs per algorithmic product
+KERNEL_PEAK = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16": PEAK_BF16_MFMA_TFLOPS}
+KERNEL_NAME = {"fp32": "conv_kernel<9,128>", "bf16x6": "conv_bf_kernel<9,128,8,3>", "bf16": "conv_bf_kernel<9,128,8,1>"}
 
 
 def cpu_baseline(budget_hw=(180, 240), threads=16):
@@ -67,7 +72,7 @@ def cpu_baseline(budget_hw=(180, 240), threads=16):
                       "1 warm-up + 2 timed (best), %.2fs each, scaled by pixel count" % (H, W, frames, t)}
 
 
-def dominant_kernel_roofline(step_fn, iso):
+def dominant_kernel_roofline(step_fn, iso, math="fp32"):
     """roofline block for the dominant kernel, conv_kernel<9,128> (3x3 implicit GEMM: forward + data gradients,
     ~59 % of the step's algorithmic FLOPs).  One extra, untimed step runs with an event pair around every launch of
     that kernel on its launch stream (torch's current stream); achieved = sum of the launches' algorithmic FLOPs /
@@ -85,11 +90,12 @@ def dominant_kernel_roofline(step_fn, iso):
     ach = fl / (ms * 1e-3) / 1e12
     traffic = None      # HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), never computed here
     tj = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-    if os.path.exists(tj):
+    if os.path.exists(tj) and math == "fp32":
         traffic = json.load(open(tj))["conv_kernel<9,128>"]["hbm_bytes_per_launch"]
-    out = {"bound": "mfma", "kernel": "conv_kernel<9,128> (3x3 implicit GEMM fwd + dgrad, all %d launches of one step)" % n,
-           "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+    peak = KERNEL_PEAK[math]
+    out = {"bound": "mfma", "kernel": "%s (3x3 implicit GEMM fwd + dgrad, all %d launches of one step)" % (KERNEL_NAME[math], n),
+           "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+           "frac": round(ach / peak, 4), "traffic": traffic,
            "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n, "launches_per_step": n,
            "isolated_2B_128to128": iso,
            "other_kernels": {k: {"launches": v[0], "achieved_tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2),
@@ -134,6 +140,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the whole step in a HIP graph and replay it (single GPU; pays off when the step is launch-bound, i.e. small frames)")
     ap.add_argument("--recompute", action="store_true", help="per-window activation recompute (long sequences / big batches)")
+    ap.add_argument("--math", default=os.environ.get("BMC_MATH", "fp32"), choices=["fp32", "bf16x6", "bf16"],
+                    help="arithmetic of the MFMA kernels for the headline measurement (default fp32 = native fp32 MFMA)")
+    ap.add_argument("--no-bf16x6", action="store_true", help="skip the additional bf16x6-mode measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,8 +159,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from models.BMCNet import BMCNet
+    from bmc_hip import ops
     from bmc_hip.parallel import GradAllReducer
     from train_step import bptt_step, encode_sequence, synthetic_events
+    ops.set_math(args.math)
 
     scale, n_c, n_b = 4, args.n_c, args.n_b
     B, H, W, L = args.batch, args.height, args.width, args.seql
@@ -187,29 +198,43 @@ def main():
         def step():
             graph.replay()
             return g_loss, g_mse
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    def timed(fn, warmup, steps):
+        """W untimed + exactly K timed steps between barrier + synchronize pairs; max over ranks."""
+        loss = None
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, _ = fn()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt, loss
+
+    dt, loss = timed(step, args.warmup, args.steps)
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2**30
 
     # the instrumented extra step contains the gradient all-reduce: every rank has to take part in it
     iso = isolated_conv(dev, B, H, W, n_c) if rank == 0 else None
-    roof = dominant_kernel_roofline(eager_step, iso)
+    roof = dominant_kernel_roofline(eager_step, iso, args.math)
+    # second arithmetic mode of the same step (every rank takes part): the fp32-equivalent bf16x6 split -- reported
+    # beside the headline number, never as it
+    split = None
+    if args.math == "fp32" and not args.no_bf16x6 and not args.graph:
+        ops.set_math("bf16x6")
+        dt6, loss6 = timed(eager_step, 1, args.steps)
+        ops.set_math("fp32")
+        split = (dt6, float(loss6))
     if rank == 0:
         windows = L - 1
         frames_per_step = world * B * windows
@@ -217,12 +242,12 @@ def main():
         step_flops = FLOP_PER_LRPX_FWD_BWD * H * W * B * windows if (n_c, n_b) == (128, 5) else None
         if step_flops:
             roof["step_achieved_tflops_per_gpu"] = round(step_flops * args.steps / dt / 1e12, 2)
-            roof["step_frac_of_peak"] = round(step_flops * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+            roof["step_frac_of_peak"] = round(step_flops * args.steps / dt / 1e12 / KERNEL_PEAK[args.math], 4)
         out = {
             "metric": "LR-voxel-frames/sec x4 SR train step, NFS 180x240",
             "value": round(value, 3), "unit": "LR-voxel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x6": "f32 (3xbf16 split, 6 products)", "bf16": "bf16"}[args.math], "data": "synthetic",
             "config": {"workload": "BMCNet(scale=4, n_c=%d, n_b=%d) x4 NFS %dx%d->%dx%d, bs=%d/GPU fp32, SEQL=%d SEQN=2 (%d windows BPTT), "
                                    "event scatter + fwd + MSE + bwd + Adam(amsgrad)%s%s" %
                                    (n_c, n_b, H, W, scale * H, scale * W, B, L, windows, " + RCCL grad all-reduce" if use_dist else "",
@@ -232,6 +257,18 @@ def main():
                        "final_loss": round(float(loss), 6)},
             "roofline": roof,
         }
+        if split is not None:
+            dt6, loss6 = split
+            out["bf16x6_mode"] = {
+                "value": round(frames_per_step * args.steps / dt6, 3), "unit": "LR-voxel-frames/s",
+                "ms_per_step": round(dt6 / args.steps * 1e3, 2), "steps": args.steps, "warmup": 1,
+                "final_loss": round(loss6, 6),
+                "arithmetic": "every fp32 MFMA operand split exactly into 3 bf16 planes, 6 plane products on "
+                              "v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-equivalent (error vs float64 <= the "
+                              "native fp32 MFMA path's, tests/test_gpu_parity.py::test_math_modes_vs_float64); same "
+                              "workload, same step, `--math bf16x6` makes it the headline run"}
+            if step_flops:
+                out["bf16x6_mode"]["step_fp32_equivalent_tflops_per_gpu"] = round(step_flops * args.steps / dt6 / 1e12, 2)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -262,8 +262,9 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
     A operand (bias-gradient partials) for bmc_pgemm_reduce_weight."""
     G = B // bpg
     mpad, npad = round_up(M, 32), round_up(N, 32)
-    if taps == 9:       # LDS-DMA kernel: one 8-wave workgroup per CU, 64 columns per workgroup
-        n_nblk = (npad + 63) // 64
+    if taps == 9:       # one 8-wave workgroup per CU, 64 columns per workgroup (32 in the bf16x6 mode: pgemm_bf.hip)
+        cols = 32 if MATH == 3 else 64
+        n_nblk = (npad + cols - 1) // cols
         tiles = ((H + 3) // 4) * ((W + 15) // 16)
         target = 256
     else:               # same kernel family, 128 columns per workgroup
@@ -283,6 +284,7 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
     p.slabs = slabs.data_ptr()
     p.nsplit = nsplit
     p.zeros = _zeros(device).data_ptr()
+    p.math = MATH
     bslabs = None
     if want_bias:
         bslabs = torch.empty(nsplit * G * 4 * mpad, device=device, dtype=torch.float32)

@@ -18,6 +18,7 @@
 // fall on the same 8 bank slots.  Swapping the two halves of every row that lanes 16-31 read (weights: rows with bit 4
 // set; pixels: odd halo rows) makes all fragment reads conflict-free.
 #include "conv_k.h"
+#include "bf_split.h"
 
 #ifndef BMC_BF_ABL
 #define BMC_BF_ABL 0   // ablation bits for experiment builds (tools/): 4 no MFMAs, 8 no weight loads, 16 no activation loads, 32 no split
@@ -25,36 +26,9 @@
 
 namespace {
 
-typedef unsigned int u32;
-typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 constexpr int CK = BMC_CK;
 constexpr int TW = 16;
 constexpr int RD = 8;   // dwords per LDS row (16 bf16)
-
-__device__ __forceinline__ u32 pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: RNE, low half = a
-    return __builtin_bit_cast(u32, __builtin_convertvector(f32x2{a, b}, bf16x2));
-}
-__device__ __forceinline__ float lo_f(u32 p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float hi_f(u32 p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-
-// four fp32 values -> NP planes of four bf16 (two dwords per plane)
-template <int NP>
-__device__ __forceinline__ void split4(const f32x4 v, u32x2 (&pl)[NP]) {
-    f32x4 r = v;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const u32 a = pack_bf16(r[0], r[1]), b = pack_bf16(r[2], r[3]);
-        pl[p] = u32x2{a, b};
-        if (p + 1 < NP) {   // exact residual (Sterbenz: the bf16 value shares the leading bits of r)
-            r[0] -= lo_f(a); r[1] -= hi_f(a); r[2] -= lo_f(b); r[3] -= hi_f(b);
-        }
-    }
-}
 
 __device__ __forceinline__ int swz_w(int row, int half) { return row * RD + 4 * (half ^ ((row >> 4) & 1)); }
 __device__ __forceinline__ int swz_x(int hp, int hy, int half) { return hp * RD + 4 * (half ^ (hy & 1)); }

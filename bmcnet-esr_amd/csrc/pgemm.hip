@@ -8,25 +8,10 @@
 // constant LDS offsets.  Pixel tiles (4x16 / 64 flat pixels) are dealt round-robin to `nsplit` splits; partial sums
 // go to slabs and are summed by a second kernel in a fixed order (deterministic, no float atomics).
 #include "bmc_common.h"
+#include "pgemm_k.h"
 
 namespace {
 
-constexpr int PT_H = 4, PT_W = 16, PT = PT_H * PT_W;  // 64-pixel tile
-
-struct PgemmK {
-    SrcDev a;
-    int nsrc;
-    SrcDev src[BMC_MAX_SRC];
-    int B, H, W;
-    int batch_per_group;
-    float* slabs;
-    int nsplit;
-    const float* zeros;
-    float* bias_slabs;   // optional: per-workgroup column sums of the A tiles (bias gradient partials)
-    int M, Mpad, N, Npad;
-    int n_nblk, n_mblk, G;
-    int tiles_x, tiles_y, tiles_per_img;
-};
 
 // LDS-DMA pixel-reduction GEMM: ONE 8-wave workgroup per CU.
 //   TAPS = 9: 128 rows x 64 columns x 9 taps per workgroup (wave = 32 x 32 x 9 taps, 144 accumulator registers);
@@ -290,6 +275,20 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
     k.G = h->B / h->batch_per_group;
     k.n_mblk = (k.Mpad + 127) / 128;
     hipStream_t st = (hipStream_t)stream;
+    BMC_CHECK_ARG(h->math == BMC_MATH_FP32 || h->math == BMC_MATH_BF16 || h->math == BMC_MATH_BF16X6,
+                  "bmc_pgemm: unknown math mode %d", h->math);
+    if (h->math != BMC_MATH_FP32) {
+        const int cols = bmc_pgemm_cols(h->taps, h->math);
+        k.n_nblk = (k.Npad + cols - 1) / cols;
+        if (h->taps == 9) {
+            k.tiles_x = (h->W + PT_W - 1) / PT_W; k.tiles_y = (h->H + PT_H - 1) / PT_H;
+            k.tiles_per_img = k.tiles_x * k.tiles_y;
+        } else {
+            k.tiles_x = k.tiles_y = 0;
+            k.tiles_per_img = (h->H * h->W + PT - 1) / PT;
+        }
+        return bmc_pgemm_bf_launch(k, h->taps, h->math == BMC_MATH_BF16 ? 1 : 3, st);
+    }
     if (h->taps == 9) {
         k.n_nblk = (k.Npad + 63) / 64;
         k.tiles_x = (h->W + PT_W - 1) / PT_W; k.tiles_y = (h->H + PT_H - 1) / PT_H;

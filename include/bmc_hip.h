@@ -143,6 +143,8 @@ typedef struct bmc_pgemm_args {
     const float* zeros;         /* >= 64 bytes of zeros in device memory (source for out-of-image LDS-DMA lanes) */
     float* bias_slabs;          /* optional [nsplit][G][4][Mpad]: column sums of A (the bias gradient of the same conv),
                                    taken from the A tiles the kernel stages anyway; summed by bmc_pgemm_reduce_weight */
+    int math;                   /* BMC_MATH_* as for bmc_conv; bf16 modes: v_mfma_f32_32x32x16_bf16 on planes read
+                                   with the transposing LDS load */
 } bmc_pgemm_args_t;
 int bmc_pgemm(const bmc_pgemm_args_t* host_args, bmc_stream_t s);
 /* slabs -> dW[Cout][Cin][taps] (nn.Conv2d layout) through kmap; beta 0/1 = overwrite/accumulate */

@@ -29,6 +29,14 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
+@pytest.fixture(autouse=True)
+def _restore_math_mode():
+    """Tests that switch the convolution arithmetic (bmc_hip.ops.set_math) leave the process default behind."""
+    yield
+    from bmc_hip import ops
+    ops.set_math(os.environ.get("BMC_MATH", "fp32"))
+
+
 def rel_l2(a, b):
     a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, np.float64)
     b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, np.float64)
@@ -241,9 +249,14 @@ def test_shuffle_head_golden():
 
 
 # ------------------------------------------------------------------ full recurrent models (BPTT) vs golden
+@pytest.mark.parametrize("math", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("tag,plain", [("bmcnet_nc16", False), ("plain_nc16", True), ("bmcnet_nc32", False)])
-def test_full_model_bptt_golden(tag, plain):
+def test_full_model_bptt_golden(tag, plain, math):
+    """3-window BPTT of the reference (golden fixtures) in both fp32-class arithmetic modes: native fp32 MFMA and the
+    bf16x6 split (three exact bf16 planes per operand, six plane products) -- same tolerances."""
     dev = _gpu()
+    from bmc_hip import ops
+    ops.set_math(math)
     from models.BMCNet import BMCNet
     from models.BMCNet_plain import BMCNet_plain
     z = load(tag + ".npz")
@@ -458,14 +471,17 @@ def test_full_size_window_forward_vs_oracle():
             h, hp, hn, pred = O.bmcnet_forward(params, frames[:, i:i + 2].transpose(1, 2).double(), h, hp, hn, pred, i == 0, scale)
             ref.append(pred)
         m.to(dev)
+        from bmc_hip import ops
         zz = lambda c: torch.zeros(1, c, H, W, device=dev)
-        h, hp, hn, pred = zz(n_c), zz(n_c), zz(n_c), zz(2 * scale * scale)
-        for i in range(2):
-            h, hp, hn, pred = m(frames[:, i:i + 2].transpose(1, 2).to(dev), h, hp, hn, pred, i == 0)
-            assert pred.shape == (1, 2, 720, 960)
-            err = rel_l2(pred, ref[i])
-            print("full-size window %d: SR rel-L2 vs float64 oracle %.2e" % (i, err))
-            assert err < 1e-4, i
+        for math in ("fp32", "bf16x6"):
+            ops.set_math(math)
+            h, hp, hn, pred = zz(n_c), zz(n_c), zz(n_c), zz(2 * scale * scale)
+            for i in range(2):
+                h, hp, hn, pred = m(frames[:, i:i + 2].transpose(1, 2).to(dev), h, hp, hn, pred, i == 0)
+                assert pred.shape == (1, 2, 720, 960)
+                err = rel_l2(pred, ref[i])
+                print("full-size window %d (%s): SR rel-L2 vs float64 oracle %.2e" % (i, math, err))
+                assert err < 1e-4, (math, i)
 
 
 def test_quarter_frame_window_gradients_vs_oracle():
@@ -491,24 +507,29 @@ def test_quarter_frame_window_gradients_vs_oracle():
     loss_ref = F.mse_loss(pred, gt)
     loss_ref.backward()
     m.to(dev)
+    from bmc_hip import ops
     zz = lambda c: torch.zeros(1, c, H, W, device=dev)
-    _, _, _, pg = m(x.to(dev), zz(n_c), zz(n_c), zz(n_c), zz(32), True)
-    loss = F.mse_loss(pg, gt.to(dev))
-    loss.backward()
-    assert rel_l2(pg, pred) < 1e-4
-    assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
-    worst = 0.0
-    n = 0
-    for name, p in m.named_parameters():
-        if p.grad is None:
-            assert params[name].grad is None
-            continue
-        e = rel_l2(p.grad, params[name].grad)
-        worst = max(worst, e)
-        assert e < 1e-3, (name, e)
-        n += 1
-    assert n >= 40
-    print("quarter-frame: SR rel-L2 %.2e, worst parameter-gradient rel-L2 %.2e over %d tensors" % (rel_l2(pg, pred), worst, n))
+    for math in ("fp32", "bf16x6"):
+        ops.set_math(math)
+        m.zero_grad(set_to_none=True)
+        _, _, _, pg = m(x.to(dev), zz(n_c), zz(n_c), zz(n_c), zz(32), True)
+        loss = F.mse_loss(pg, gt.to(dev))
+        loss.backward()
+        assert rel_l2(pg, pred) < 1e-4, math
+        assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item()), math
+        worst = 0.0
+        n = 0
+        for name, p in m.named_parameters():
+            if p.grad is None:
+                assert params[name].grad is None
+                continue
+            e = rel_l2(p.grad, params[name].grad)
+            worst = max(worst, e)
+            assert e < 1e-3, (math, name, e)
+            n += 1
+        assert n >= 40
+        print("quarter-frame (%s): SR rel-L2 %.2e, worst parameter-gradient rel-L2 %.2e over %d tensors"
+              % (math, rel_l2(pg, pred), worst, n))
 
 
 def test_fused_twin_bie_matches_unfused_autograd_path():
@@ -652,21 +673,25 @@ def test_conv_fuzz_random_shapes_vs_torch():
         b = torch.randn(cout, generator=g) if bias else None
         r = torch.randn(B, cout, H, W, generator=g) if res else None
         go = torch.randn(B, cout, H, W, generator=g)
-        xs_c = [x.clone().requires_grad_() for x in xs]
-        w_c = w.clone().requires_grad_()
-        b_c = b.clone().requires_grad_() if bias else None
-        y = F.conv2d(torch.cat(xs_c, 1), w_c, b_c, padding=k // 2)
-        if res:
-            y = y + r
-        if relu:
-            y = torch.relu(y)
-        y.backward(go)
         xs_g = [_nhwc(x).to(dev).requires_grad_() for x in xs]
         w_g = w.to(dev).requires_grad_()
         b_g = b.to(dev).requires_grad_() if bias else None
         yg = ops.conv([View(x) for x in xs_g], w_g, b_g, ConvSpec.dense(*cins), relu=relu,
                       residual=View(_nhwc(r).to(dev)) if res else None)
         yg.backward(_nhwc(go).to(dev))
+        xs_c = [x.clone().requires_grad_() for x in xs]
+        w_c = w.clone().requires_grad_()
+        b_c = b.clone().requires_grad_() if bias else None
+        z = F.conv2d(torch.cat(xs_c, 1), w_c, b_c, padding=k // 2)
+        if res:
+            z = z + r
+        y = torch.relu(z) if relu else z
+        if relu:
+            # back-propagate through the ReLU mask the kernel actually applied: a pre-activation within rounding of
+            # zero may legitimately land on either side, and one flipped element would dominate the gradient check
+            (z * (yg.detach().permute(0, 3, 1, 2).cpu() > 0)).backward(go)
+        else:
+            y.backward(go)
         tag = (case, k, cins, cout, B, H, W, relu, res, bias)
         assert rel_l2(yg.permute(0, 3, 1, 2), y) < 2e-5, tag
         for xg, xc in zip(xs_g, xs_c):
@@ -689,3 +714,78 @@ def test_events_to_voxel_golden(tag):
     assert vox.shape == (bins, H, W)
     assert np.abs(vox.cpu().numpy() - z[f"{tag}/vox"]).max() <= 1e-5
     assert np.array_equal(xs.cpu().numpy(), z[f"{tag}/xs_after"]) and np.array_equal(ys.cpu().numpy(), z[f"{tag}/ys_after"])
+
+
+# ------------------------------------------------------------------ arithmetic modes of the MFMA kernels
+@pytest.mark.parametrize("B,H,W,cins,cout,k", [
+    (2, 45, 80, [128], 128, 3),          # 4x16x64 tiles
+    (3, 37, 53, [16, 128], 128, 3),      # two sources, ragged image
+    (2, 45, 80, [128, 128], 128, 1),     # 1x1, K = 256
+    (2, 45, 80, [128], 32, 3),           # narrow output (8x16x32 tiles)
+    (4, 90, 120, [128], 128, 3),         # 8x16x128 tiles, persistent workgroups
+])
+def test_math_modes_vs_float64(B, H, W, cins, cout, k):
+    """Convolution forward, weight and bias gradient in the three arithmetic modes against float64:
+      fp32   (v_mfma_f32_32x32x2_f32)                      : fp32 rounding error only;
+      bf16x6 (3 exact bf16 planes per operand, 6 products) : the same bar -- it is an fp32-equivalent arithmetic;
+      bf16   (operands rounded to bf16, fp32 accumulate)   : exact w.r.t. a float64 conv of the bf16-rounded operands,
+                                                             bf16-level (4e-3) w.r.t. the unrounded one."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from bmc_hip.ops import ConvSpec, View
+    g = torch.Generator().manual_seed(7)
+    cin = sum(cins)
+    xs = [torch.randn(B, H, W, c, generator=g).to(dev) for c in cins]
+    w0 = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
+    b0 = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    go = torch.randn(B, H, W, cout, generator=g).to(dev)
+    xcat = torch.cat(xs, -1).permute(0, 3, 1, 2)
+
+    def ref(rounded):
+        r = (lambda t: t.bfloat16().double()) if rounded else (lambda t: t.double())
+        wd, bd = r(w0).requires_grad_(), b0.double().requires_grad_()
+        y = F.conv2d(r(xcat), wd, bd, padding=k // 2)
+        # the weight gradient contracts the (rounded) output gradient with the (rounded) input
+        gr = r(go.permute(0, 3, 1, 2))
+        dw = torch.autograd.grad(F.conv2d(r(xcat), wd, None, padding=k // 2), wd, gr)[0]
+        return y.permute(0, 2, 3, 1), dw, go.double().sum((0, 1, 2))
+
+    exact, rounded = ref(False), ref(True)
+    spec = ConvSpec.dense(*cins)
+    for math in ("fp32", "bf16x6", "bf16"):
+        ops.set_math(math)
+        w = w0.clone().requires_grad_()
+        b = b0.clone().requires_grad_()
+        y = ops.conv([View(t) for t in xs], w, b, spec)
+        y.backward(go)
+        target = rounded if math == "bf16" else exact
+        e = (rel_l2(y, target[0]), rel_l2(w.grad, target[1]), rel_l2(b.grad, target[2]))
+        print("%-6s fwd %.2e  dW %.2e  db %.2e (rel-L2 vs float64)" % (math, *e))
+        assert max(e) < 3e-6, (math, e)
+        if math == "bf16":
+            assert rel_l2(y, exact[0]) < 4e-3 and rel_l2(w.grad, exact[1]) < 4e-3
+
+
+def test_bf16_mode_full_model_step():
+    """BMCNet(4,16,1) 3-window BPTT with bf16 operands / fp32 accumulation (BASELINE configs[3]'s arithmetic) against
+    the fp32 golden: bf16-level agreement of the SR tensors, loss and gradients (not the fp32 bar)."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from models.BMCNet import BMCNet
+    ops.set_math("bf16")
+    z = load("bmcnet_nc16.npz")
+    scale, n_c, n_b, B, H, W, nwin = (int(v) for v in z["meta"])
+    m = BMCNet(scale, n_c, n_b)
+    _load_sd(m, z); m.to(dev)
+    frames = torch.tensor(z["frames"]); gts = torch.tensor(z["gts"])
+    zz = lambda c: torch.zeros(B, c, H, W, device=dev)
+    h, hp, hn, pred = zz(n_c), zz(n_c), zz(n_c), zz(2 * scale * scale)
+    loss = 0
+    for i in range(nwin):
+        h, hp, hn, pred = m(frames[:, i:i + 2].transpose(1, 2).to(dev), h, hp, hn, pred, i == 0)
+        e = rel_l2(pred, z[f"pred{i}"])
+        assert 1e-6 < e < 3e-2, (i, e)      # visibly bf16 (not silently fp32), and not broken
+        loss = loss + F.mse_loss(pred, gts[:, i + 1].to(dev))
+    assert abs(loss.item() - float(z["loss"])) < 2e-2 * abs(float(z["loss"]))
+    loss.backward()
+    assert _check_grads(m, z, 0.15) >= 20
