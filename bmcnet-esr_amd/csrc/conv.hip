@@ -37,6 +37,7 @@ namespace {
 constexpr int CK = BMC_CK;  // channels per chunk
 constexpr int RS = 20;      // LDS row stride in floats (16 + 4 pad: conflict-free ds_read_b128)
 constexpr int TW = 16;      // tile width; the tile height TH (8 or 4 rows) is a kernel template parameter
+__device__ __attribute__((aligned(16))) const float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};   // source of out-of-image lanes
 
 
 // Tile shapes (4 waves): BN = 128: waves 2(px) x 2(ch), wave = (TH/2 rows x 16) px x 64 ch  [TH = 8: 2x2 MFMA tiles, TH = 4: 1x2]
@@ -111,8 +112,8 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
             const int e = tid + 256 * n, hp = e >> 2;
             const int hy = hp / HWD, hx = hp - hy * HWD;
             const int y = y0 - P + hy, x = x0 - P + hx;
-            xok[n] = hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W;
-            xpix[n] = xok[n] ? y * a.W + x : 0;   // out-of-image lanes load pixel 0 (valid memory) and are zeroed: no branch
+            xok[n] = hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W;   // out-of-image lanes read a zero buffer: no
+            xpix[n] = y * a.W + x;                                           // branch, and nothing to fix up after the load
         }
         s_idx = 0; c_in = 0; xl_chunk = 0;
         src_select();
@@ -123,10 +124,9 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
         const float* base = sbase + c_in + q4;
 #pragma unroll
         for (int n = 0; n < NXLD; ++n) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (!(BMC_DIAG_MODE & (2 | 16))) v = *reinterpret_cast<const f32x4*>(base + (long long)xpix[n] * spix);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) xr[slot][n][k] = xok[n] ? v[k] : 0.f;
+            const float* src = xok[n] ? base + (long long)xpix[n] * spix : g_zero4;
+            if (BMC_DIAG_MODE & (2 | 16)) src = g_zero4;
+            xr[slot][n] = *reinterpret_cast<const f32x4*>(src);
         }
         c_in += CK;
         if (++xl_chunk == a.nchunks) {

@@ -6,7 +6,8 @@
 //   NP = 1  operands rounded to bf16 (RNE) on their way into LDS: the "bf16 compute / fp32 accumulate" mode;
 //   NP = 3  every fp32 operand is split EXACTLY into three bf16 planes x = h + m + l (8 significand bits each) and the
 //           product is rebuilt from the six plane products of weight >= 2^-16: hh, hm, mh, hl, lh, mm.  The three
-//           dropped ones (ml, lm, ll) are <= 2^-24 |x w| together, the size of ONE fp32 rounding of the product;
+//           dropped ones (ml, lm, ll) are <= 2^-23 |x w| together in the worst case (~2^-26 rms), the size of ONE fp32
+//           rounding of the product;
 //           bf16 x bf16 products are exact in fp32 and the matrix core accumulates in fp32.  The bf16 pipe runs 16x
 //           the fp32 MFMA rate, so six products cost 6/16 of the native fp32 time.
 // The split happens once per element, when a tile goes from registers to LDS (activations), or once per step on the
@@ -29,6 +30,7 @@ namespace {
 constexpr int CK = BMC_CK;
 constexpr int TW = 16;
 constexpr int RD = 8;   // dwords per LDS row (16 bf16)
+__device__ __attribute__((aligned(16))) const float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};   // source of out-of-image lanes
 
 __device__ __forceinline__ int swz_w(int row, int half) { return row * RD + 4 * (half ^ ((row >> 4) & 1)); }
 __device__ __forceinline__ int swz_x(int hp, int hy, int half) { return hp * RD + 4 * (half ^ (hy & 1)); }
@@ -117,21 +119,23 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 2 : 3) void conv_bf_k
             const int e = xt + 128 * n, hp = e >> 2;
             const int hy = hp / HWD, hx = hp - hy * HWD;
             const int y = y0 - P + hy, x = x0 - P + hx;
-            xok[n] = hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W;
-            xpix[n] = xok[n] ? y * a.W + x : 0;   // out-of-image lanes load pixel 0 (valid memory) and are zeroed: no branch
+            xok[n] = hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W;   // out-of-image lanes read a zero buffer: no
+            xpix[n] = y * a.W + x;                                           // branch, and nothing to fix up after the load
         }
         s_idx = 0; c_in = 0; xl_chunk = 0;
         src_select();
     };
-    f32x4 xr[NXLD];
-    auto load_x = [&]() {
+    // TAPS = 1: a step is one 16-channel chunk straight from HBM, shorter than the memory latency, so the loads run XD
+    // steps ahead through a register ring (slots are static: the step loop is unrolled by XD)
+    constexpr int XD = TAPS == 1 ? 3 : 1;
+    f32x4 xr[XD][NXLD];
+    auto load_x = [&](int slot) {
         const float* base = sbase + c_in + q * 4;
 #pragma unroll
         for (int n = 0; n < NXLD; ++n) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (!(BMC_BF_ABL & 16)) v = *reinterpret_cast<const f32x4*>(base + (long long)xpix[n] * spix);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) xr[n][k] = xok[n] ? v[k] : 0.f;
+            const float* src = xok[n] ? base + (long long)xpix[n] * spix : g_zero4;
+            if (BMC_BF_ABL & 16) src = g_zero4;
+            xr[slot][n] = *reinterpret_cast<const f32x4*>(src);
         }
         c_in += CK;
         if (++xl_chunk == a.nchunks) {
@@ -142,13 +146,13 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 2 : 3) void conv_bf_k
             src_select();
         }
     };
-    auto store_x = [&](int buf) {
+    auto store_x = [&](int slot, int buf) {
 #pragma unroll
         for (int n = 0; n < NXLD; ++n) {
             const int e = xt + 128 * n, hp = e >> 2;
             if ((n + 1) * 128 <= NHALO * 4 || hp < NHALO) {
                 u32x2 pl[NP];
-                split4<NP>(xr[n], pl);
+                split4<NP>(xr[slot][n], pl);
                 u32* const dst = Xb + buf * XBUF + swz_x(hp, hp / HWD, q >> 1) + 2 * (q & 1);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(dst + p * XPL) = pl[p];
@@ -280,9 +284,13 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 2 : 3) void conv_bf_k
     // ---- prologue: halo of chunk 0 in LDS, weight slices 0 and 1 in flight, slice 0 landed
     if (xrole) {
         xl_setup(xl_tile);
-        load_x();
-        store_x(0);
-        if (TAPS == 1 && total_chunks > 1) load_x();
+        load_x(0);
+        store_x(0, 0);
+        if (TAPS == 1) {
+#pragma unroll
+            for (int j = 1; j <= XD; ++j)
+                if (j < total_chunks) load_x(j % XD);
+        }
     } else {
         wl_setup(wl_tile);
         dma_w();
@@ -295,34 +303,60 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 2 : 3) void conv_bf_k
     //             weight waves - issue the DMA of slice s+2 into ring stage (s+2) % 3
     //   all     : read this step's fragments, MFMAs
     //   weight waves: wait until slice s+1 has landed (slice s+2 may stay in flight); barrier
-    int gs = 0, gc = 0, stage = 0;
-    for (int tile = t_first; tile < t_hi; tile += t_stride) {
-        for (int c = 0; c < a.nchunks; ++c, ++gc) {
-            const u32* const xb = Xb + (gc & 1) * XBUF;
+    int stage = 0;
+    if constexpr (TAPS == 1) {
+        int tile = t_first, cc = 0;
+        for (int base = 0; base < total_steps; base += XD) {
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap, ++gs) {
-                const bool last_tap = tap == TAPS - 1;
-                if (xrole) {
-                    if (TAPS == 9) {
-                        if (tap == 0 && gc + 1 < total_chunks) load_x();
-                        if (last_tap && gc + 1 < total_chunks) store_x((gc + 1) & 1);
+            for (int d = 0; d < XD; ++d) {
+                const int s = base + d;     // chunk s: LDS buffer s & 1; chunk c >= 1 travels through ring slot c % XD
+                if (s < total_steps) {
+                    if (xrole) {
+                        if (s + 1 < total_steps) store_x((d + 1) % XD, (s + 1) & 1);
+                        if (s + 1 + XD < total_steps) load_x((d + 1) % XD);
                     } else {
-                        if (gc + 1 < total_chunks) store_x((gc + 1) & 1);
-                        if (gc + 2 < total_chunks) load_x();
+                        if (s + 2 < total_steps) dma_w();
                     }
-                } else {
-                    if (gs + 2 < total_steps) dma_w();
+                    read_frags(Xb + (s & 1) * XBUF, Wb + stage * WBUF, 0, 0);
+                    mma_all();
+                    if (!xrole) {
+                        if (s + 2 < total_steps) wait_older_slices(); else dma_wait<0>();
+                    }
+                    stage = stage == NSTG - 1 ? 0 : stage + 1;
+                    __syncthreads();
+                    if (++cc == a.nchunks) {
+                        epilogue(tile);
+                        tile += t_stride;
+                        cc = 0;
+                    }
                 }
-                read_frags(xb, Wb + stage * WBUF, tap_shift(tap), TAPS == 9 ? tap / 3 : 0);
-                mma_all();
-                if (!xrole) {
-                    if (gs + 2 < total_steps) wait_older_slices(); else dma_wait<0>();
-                }
-                stage = stage == NSTG - 1 ? 0 : stage + 1;
-                __syncthreads();
             }
         }
-        epilogue(tile);
+    } else {
+        int gs = 0, gc = 0;
+        for (int tile = t_first; tile < t_hi; tile += t_stride) {
+            for (int c = 0; c < a.nchunks; ++c, ++gc) {
+                const u32* const xb = Xb + (gc & 1) * XBUF;
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap, ++gs) {
+                    const bool last_tap = tap == TAPS - 1;
+                    if (xrole) {
+                        if (tap == 0 && gc + 1 < total_chunks) load_x(0);
+                        if (last_tap && gc + 1 < total_chunks) store_x(0, (gc + 1) & 1);
+                    } else {
+                        if (gs + 2 < total_steps) dma_w();
+                    }
+                    read_frags(xb, Wb + stage * WBUF, tap_shift(tap), tap / 3);
+                    mma_all();
+                    if (!xrole) {
+                        if (gs + 2 < total_steps) wait_older_slices(); else dma_wait<0>();
+                    }
+                    stage = stage == NSTG - 1 ? 0 : stage + 1;
+                    __syncthreads();
+                }
+            }
+            epilogue(tile);
+        }
     }
 }
 

@@ -67,10 +67,13 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
 
     // ---- tile loads: global -> registers (zero buffer for pixels outside the image / channels beyond M, N)
     const int ntiles = a.batch_per_group * a.tiles_per_img;
-    f32x4 ar[NAL], xr[NXL];
+    // 1x1: a 64-pixel tile's MFMAs are shorter than the HBM latency -> two tiles of loads in flight (register ring with
+    // static slots: the tile loop is unrolled by PD)
+    constexpr int PD = TAPS == 1 ? 2 : 1;
+    f32x4 ar[PD][NAL], xr[PD][NXL];
     // `vt` = tid behind an opaque barrier: keeps the compiler from hoisting the per-thread index arithmetic of the 8
     // loads / stores out of the tile loop into dozens of long-lived registers (the accumulators need them)
-    auto load_tile = [&](int tile) {
+    auto load_tile = [&](int tile, int slot) {
         int vt = tid;
         asm volatile("" : "+v"(vt));
         const int bb = tile / a.tiles_per_img, tin = tile - bb * a.tiles_per_img;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
             }
             ok = ok && m0 + c4 < a.M;
             const float* src = ok ? ab + pix * a.a.pix_stride + m0 + c4 : a.zeros;
-            ar[i] = *reinterpret_cast<const f32x4*>(src);
+            ar[slot][i] = *reinterpret_cast<const f32x4*>(src);
         }
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
@@ -117,22 +120,22 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
             for (int si = 1; si < BMC_MAX_SRC; ++si)
                 if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; }
             const float* src = ok ? src_batch_ptr(S, b) + pix * S.pix_stride + ch : a.zeros;
-            xr[i] = *reinterpret_cast<const f32x4*>(src);
+            xr[slot][i] = *reinterpret_cast<const f32x4*>(src);
         }
     };
     // bias gradient = column sums of A: a thread always holds the same 4 channels ((tid & 31) * 4), so it adds up its
     // own fp32 registers; 16 threads per channel quad are folded to 4 partial rows per workgroup at the end
     const bool do_bias = a.bias_slabs != nullptr && nb == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    auto store_tile = [&]() {
+    auto store_tile = [&](int slot) {
         int vt = tid;
         asm volatile("" : "+v"(vt));
 #pragma unroll
         for (int i = 0; i < NAL; ++i) {
             const int e = i * 512 + vt, p = e >> 5, c4 = (e & 31) * 4;
-            if (do_bias) bsum += ar[i];
+            if (do_bias) bsum += ar[slot][i];
             u32x2 pl[NP];
-            split4<NP>(ar[i], pl);
+            split4<NP>(ar[slot][i], pl);
 #pragma unroll
             for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(Al + q * APL + p * AST + c4 * 2) = pl[q];
         }
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
             const int e = i * 512 + vt, hp = e / XQ, c4 = (e % XQ) * 4;
             if ((i + 1) * 512 <= NHALO * XQ || hp < NHALO) {
                 u32x2 pl[NP];
-                split4<NP>(xr[i], pl);
+                split4<NP>(xr[slot][i], pl);
 #pragma unroll
                 for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(Xl + q * XPL + hp * XST + c4 * 2) = pl[q];
             }
@@ -198,13 +201,21 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
         }
     };
 
-    if (split < ntiles) load_tile(split);
-    for (int tile = split; tile < ntiles; tile += a.nsplit) {
-        __syncthreads();            // the previous tile's fragment reads are done
-        store_tile();
-        __syncthreads();
-        if (tile + a.nsplit < ntiles) load_tile(tile + a.nsplit);
-        if (wave_active) compute();
+#pragma unroll
+    for (int j = 0; j < PD; ++j)
+        if (split + j * a.nsplit < ntiles) load_tile(split + j * a.nsplit, j);
+    for (int base = split; base < ntiles; base += PD * a.nsplit) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int tile = base + d * a.nsplit;
+            if (tile < ntiles) {
+                __syncthreads();            // the previous tile's fragment reads are done
+                store_tile(d);
+                __syncthreads();
+                if (tile + PD * a.nsplit < ntiles) load_tile(tile + PD * a.nsplit, d);
+                if (wave_active) compute();
+            }
+        }
     }
 
     if (do_bias) {   // 16 per-thread partials per channel quad -> 4 partial rows (layout of pgemm.hip)

@@ -121,7 +121,7 @@ typedef struct bmc_conv_args {
     int math;                   /* BMC_MATH_FP32 (0): v_mfma_f32_32x32x2_f32 on the fp32 operands;
                                    BMC_MATH_BF16 (1): operands rounded to bf16, fp32 accumulate (v_mfma_f32_32x32x16_bf16);
                                    BMC_MATH_BF16X6 (3): each fp32 operand split exactly into three bf16 planes, six plane
-                                   products with fp32 accumulate -- fp32-equivalent (error <= one fp32 rounding per product) */
+                                   products with fp32 accumulate -- fp32-equivalent (dropped terms ~ one fp32 rounding per product) */
 } bmc_conv_args_t;
 int bmc_conv(const bmc_conv_args_t* host_args, bmc_stream_t s);
 
