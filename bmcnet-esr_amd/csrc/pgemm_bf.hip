@@ -73,9 +73,10 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
     f32x4 ar[PD][NAL], xr[PD][NXL];
     // `vt` = tid behind an opaque barrier: keeps the compiler from hoisting the per-thread index arithmetic of the 8
     // loads / stores out of the tile loop into dozens of long-lived registers (the accumulators need them)
+    constexpr bool NOHOIST = TAPS == 9 && !TSPLIT;     // 144 accumulator registers: no room for hoisted index math
     auto load_tile = [&](int tile, int slot) {
         int vt = tid;
-        asm volatile("" : "+v"(vt));
+        if (NOHOIST) asm volatile("" : "+v"(vt));
         const int bb = tile / a.tiles_per_img, tin = tile - bb * a.tiles_per_img;
         const int b = g * a.batch_per_group + bb;
         int y0 = 0, x0 = 0, p0 = 0;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     auto store_tile = [&](int slot) {
         int vt = tid;
-        asm volatile("" : "+v"(vt));
+        if (NOHOIST) asm volatile("" : "+v"(vt));
 #pragma unroll
         for (int i = 0; i < NAL; ++i) {
             const int e = i * 512 + vt, p = e >> 5, c4 = (e & 31) * 4;
