@@ -40,7 +40,7 @@ __device__ __forceinline__ int swz_x(int hp, int hy, int half) { return hp * RD 
 // ds_read and the ring could never run ahead.  Completion is waited for explicitly (dma_wait) before the barrier
 // that publishes the stage.
 __device__ __forceinline__ void dma16(const void* gptr, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory");   // m0: reserved, cannot be named as a clobber; nothing else in this kernel uses it
 }
 template <int N>
 __device__ __forceinline__ void dma_wait() {   // all but the newest N vector-memory operations of this wave are done
@@ -53,7 +53,7 @@ __device__ __forceinline__ void dma_wait() {   // all but the newest N vector-me
 //   waves 0-1: activation halo: global -> registers at a chunk's first tap, split into planes -> LDS at its last tap;
 //   waves 2-3: weight slices: LDS-DMA into a 3-stage ring, two steps ahead.
 template <int TAPS, int BN, int TH, int NP>
-__global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 2 : 3) void conv_bf_kernel(const ConvK a) {
+__global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) void conv_bf_kernel(const ConvK a) {
     static_assert((BN == 32 && TH == 8) || ((BN == 128 || BN == 64) && (TH == 8 || TH == 4)), "unsupported tile shape");
     static_assert(NP == 1 || NP == 3, "planes");
     constexpr int P = TAPS == 9 ? 1 : 0;
@@ -392,7 +392,7 @@ extern "C" int bmc_split_weight(const float* packed, void* out, long long nsteps
 }
 
 int bmc_conv_bf_launch(const ConvK& k, int taps, int BN, int TH, int planes, int cus, hipStream_t st) {
-    const int per_cu = (BN == 128 && TH == 8) ? 2 : 3;
+    const int per_cu = (BN == 128 && (TH == 8 || planes == 3)) ? 2 : 3;
     const long long max_blocks = (long long)cus * per_cu;
     dim3 grid((unsigned)(k.ntiles < max_blocks ? k.ntiles : max_blocks)), block(256);
 #define BMC_LAUNCH_BF(TAPS_, BN_, TH_)                                                                     \
