@@ -60,6 +60,7 @@ bmc_version = _sig("bmc_version", [])
 bmc_last_error = _sig("bmc_last_error", [], C.c_char_p)
 _events = _sig("bmc_events_to_channels", [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p])
 _voxel = _sig("bmc_events_to_voxel", [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p])
+_stack = _sig("bmc_events_to_stack", [_p, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p, _p, _i, _p])
 _enc_raw = _sig("bmc_encode_raw_events", [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p])
 _pack_w = _sig("bmc_pack_weight", [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p])
 _pack_wt = _sig("bmc_pack_weight_t", [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p])
@@ -78,7 +79,7 @@ _pack_in = _sig("bmc_pack_inputs", [_p, _ll, _ll, _ll, _ll, _ll, _i, _i, _i, _i,
 _unshuffle = _sig("bmc_unshuffle_to_nhwc", [_p, _i, _i, _i, _i, _i, _p, _p])
 _shuffle = _sig("bmc_shuffle_to_hr", [_p, _i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _ll, _p, _p])
 
-EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_events_to_voxel", "bmc_encode_raw_events", "bmc_pack_weight", "bmc_pack_weight_t", "bmc_split_weight", "bmc_conv",
+EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_events_to_voxel", "bmc_events_to_stack", "bmc_encode_raw_events", "bmc_pack_weight", "bmc_pack_weight_t", "bmc_split_weight", "bmc_conv",
            "bmc_pgemm", "bmc_pgemm_reduce_weight", "bmc_pgemm_reduce_plain", "bmc_colsum", "bmc_relu_bwd",
            "bmc_layernorm_fwd", "bmc_layernorm_bwd", "bmc_softmax_fwd", "bmc_softmax_bwd", "bmc_pack_inputs",
            "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr"]

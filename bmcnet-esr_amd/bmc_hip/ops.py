@@ -772,3 +772,21 @@ def events_to_voxel_batched(xs, ys, ts, ps, offsets, bins, H, W, mutate=True):
     lib.call(lib._voxel, "bmc_events_to_voxel", xs.data_ptr(), ys.data_ptr(), ts.data_ptr(), ps.data_ptr(),
              offsets.data_ptr(), nframes, bins, H, W, out.data_ptr(), int(mutate), _stream())
     return out
+
+
+def events_to_stack(xs, ys, ts, ps, bins, H, W, mutate=True):
+    """fp32 device vectors of ONE event window -> [bins, H, W] event stack (events_to_stack_no_polarity).  The bin
+    bounds are evaluated here with the reference's own float32 expressions (dataloader/encodings.py:224-229) on the
+    device; search + scatter + in-place masking run in libbmc_hip.so."""
+    _need_gpu(xs)
+    n = ts.numel()
+    dt = ts[-1] - ts[0] + 1e-6
+    delta_t = dt / bins
+    bi = torch.arange(bins, device=ts.device, dtype=torch.float32)
+    tstart = ts[0] + delta_t * bi
+    tend = tstart + delta_t
+    out = torch.empty((bins, H, W), device=xs.device, dtype=torch.float32)
+    ranges = torch.empty(2 * bins, device=xs.device, dtype=torch.int32)
+    lib.call(lib._stack, "bmc_events_to_stack", xs.data_ptr(), ys.data_ptr(), ts.data_ptr(), ps.data_ptr(), n,
+             tstart.data_ptr(), tend.data_ptr(), bins, H, W, out.data_ptr(), ranges.data_ptr(), int(mutate), _stream())
+    return out

@@ -86,6 +86,55 @@ __global__ void voxel_kernel(float* __restrict__ xs, float* __restrict__ ys, con
     }
 }
 
+// Event stack without polarity split (dataloader/encodings.py:202-238).  Three small kernels:
+//   stack_search : 2 threads per bin run the reference's hand-written binary search (:75-97, quirks included: the
+//                  first probe that EQUALS the bound wins, side 'right' returns r) on the float32 bounds the host
+//                  computed with the reference's own float32 expressions -> [beg, end) per bin;
+//   stack_scatter: bin b adds p at [(long) y, (long) x] (no vertical flip here) for its in-range events;
+//   stack_mutate : events_to_image_torch() works on views of the caller's arrays, so every out-of-range event that
+//                  falls in some bin's range ends up with xs = ys = ps = 0 (run after the scatter: the scatter reads
+//                  the original values; a masked event contributes nothing in any bin either way).
+__device__ int stack_bsearch(const float* __restrict__ t, int l, int r, float x, bool left) {
+    while (l <= r) {
+        if (t[l] == x) return l;
+        if (t[r] == x) return r;
+        const int mid = l + (r - l) / 2;
+        const float mv = t[mid];
+        if (mv == x) return mid;
+        if (mv < x) l = mid + 1; else r = mid - 1;
+    }
+    return left ? l : r;
+}
+__global__ void stack_search_kernel(const float* __restrict__ ts, long long n, const float* __restrict__ tstart,
+                                    const float* __restrict__ tend, int bins, int* __restrict__ ranges) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * bins) return;
+    const int b = i >> 1;
+    if (i & 1) ranges[i] = stack_bsearch(ts, 0, (int)n - 1, tend[b], false) + 1;
+    else ranges[i] = stack_bsearch(ts, 0, (int)n - 1, tstart[b], true);
+}
+__global__ void stack_scatter_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ ps,
+                                     const int* __restrict__ ranges, int H, int W, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int beg = ranges[2 * b], end = ranges[2 * b + 1];
+    float* const img = out + (long long)b * H * W;
+    for (int e = beg + blockIdx.x * blockDim.x + threadIdx.x; e < end; e += gridDim.x * blockDim.x) {
+        const float x = xs[e], y = ys[e], p = ps[e];
+        const bool oob = (x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f);
+        if (!oob && p != 0.f) atomicAdd(img + (long long)(int)y * W + (int)x, p);
+    }
+}
+__global__ void stack_mutate_kernel(float* __restrict__ xs, float* __restrict__ ys, float* __restrict__ ps,
+                                    const int* __restrict__ ranges, int H, int W) {
+    const int b = blockIdx.y;
+    const int beg = ranges[2 * b], end = ranges[2 * b + 1];
+    for (int e = beg + blockIdx.x * blockDim.x + threadIdx.x; e < end; e += gridDim.x * blockDim.x) {
+        const float x = xs[e], y = ys[e];
+        // a neighbouring bin may have zeroed this event already (ranges can overlap by an event): (0, 0) is in range
+        if ((x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f)) { xs[e] = 0.f; ys[e] = 0.f; ps[e] = 0.f; }
+    }
+}
+
 }  // namespace
 
 extern "C" int bmc_events_to_voxel(float* xs, float* ys, const float* ts, const float* ps, const long long* offsets,
@@ -121,5 +170,21 @@ extern "C" int bmc_events_to_channels(float* xs, float* ys, const float* ps, con
     if (e != hipSuccess) { bmc_set_error("bmc_events_to_channels: memset failed: %s", hipGetErrorString(e)); return -2; }
     hipLaunchKernelGGL(events_kernel, dim3(64, nframes), dim3(256), 0, st, xs, ys, ps, offsets, H, W, out, mutate);
     BMC_CHECK_LAUNCH("bmc_events_to_channels");
+    return 0;
+}
+
+extern "C" int bmc_events_to_stack(float* xs, float* ys, const float* ts, float* ps, long long n, const float* tstart,
+                                   const float* tend, int bins, int H, int W, float* out, int* ranges, int mutate,
+                                   bmc_stream_t s) {
+    BMC_CHECK_ARG(bins >= 1 && H > 0 && W > 0 && out && ranges && tstart && tend, "bmc_events_to_stack: bad arguments");
+    BMC_CHECK_ARG(n >= 0 && n < (1ll << 31), "bmc_events_to_stack: event count out of range");
+    hipStream_t st = (hipStream_t)s;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)bins * H * W * sizeof(float), st);
+    if (e != hipSuccess) { bmc_set_error("bmc_events_to_stack: memset failed: %s", hipGetErrorString(e)); return -2; }
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(stack_search_kernel, dim3((2 * bins + 63) / 64), dim3(64), 0, st, ts, n, tstart, tend, bins, ranges);
+    hipLaunchKernelGGL(stack_scatter_kernel, dim3(64, bins), dim3(256), 0, st, xs, ys, ps, ranges, H, W, out);
+    if (mutate) hipLaunchKernelGGL(stack_mutate_kernel, dim3(64, bins), dim3(256), 0, st, xs, ys, ps, ranges, H, W);
+    BMC_CHECK_LAUNCH("bmc_events_to_stack");
     return 0;
 }

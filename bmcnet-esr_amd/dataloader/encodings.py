@@ -31,6 +31,19 @@ def events_to_voxel(xs, ys, ts, ps, num_bins, sensor_size=(180, 240)):
     return ops.events_to_voxel_batched(xs, ys, ts, ps, off, int(num_bins), int(sensor_size[0]), int(sensor_size[1]))[0]
 
 
+def events_to_stack_no_polarity(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240)):
+    """Event stack [B,H,W]: B temporal bins, each the signed per-pixel sum of its events' polarities (reference:
+    dataloader/encodings.py:202-238, same signature).  On GPU tensors; like the reference it returns zeros for windows
+    of <= 3 events or all-zero timestamps, and zeroes the out-of-range events of the caller's xs / ys / ps in place."""
+    assert len(xs) == len(ys) and len(ys) == len(ts) and len(ts) == len(ps)
+    if not (xs.is_cuda and ys.is_cuda and ts.is_cuda and ps.is_cuda):
+        raise RuntimeError("events_to_stack_no_polarity: tensors must live on the MI355X (no CPU fallback in this build)")
+    H, W = int(sensor_size[0]), int(sensor_size[1])
+    if len(ts) <= 3 or ts.sum() == 0:
+        return torch.zeros([B, H, W], device=xs.device)
+    return ops.events_to_stack(xs, ys, ts, ps, int(B), H, W)
+
+
 def events_to_channels_batch(xs, ys, ps, offsets, sensor_size=(180, 240), mutate=True):
     """Many frames in one launch: frame f owns events [offsets[f], offsets[f+1]) -> [nframes,2,H,W]."""
     return ops.events_to_channels_batched(xs, ys, ps, offsets, int(sensor_size[0]), int(sensor_size[1]), mutate=mutate)

@@ -65,6 +65,15 @@ int bmc_events_to_channels(float* xs, float* ys, const float* ps, const long lon
 int bmc_events_to_voxel(float* xs, float* ys, const float* ts, const float* ps, const long long* offsets,
                         int nframes, int bins, int H, int W, float* out, int mutate, bmc_stream_t s);
 
+/* events_to_stack_no_polarity() (dataloader/encodings.py:202-238): `bins` temporal bins over one event window, each the
+ * signed per-pixel sum of the polarities of its events at [(long) y, (long) x] (no vertical flip).  tstart / tend [bins]:
+ * the float32 bin bounds ts[0] + delta_t*bi and tstart + delta_t, computed by the caller with the reference's float32
+ * expressions; the bins' event ranges come from the reference's own binary search (:75-97, quirks included) run on
+ * the device, into `ranges` [2*bins] ints.  If mutate != 0, out-of-range events covered by a bin get xs = ys = ps = 0 in
+ * place, as the reference does to its caller's tensors.  Exact for +-1 polarities (integer-valued sums). */
+int bmc_events_to_stack(float* xs, float* ys, const float* ts, float* ps, long long n, const float* tstart,
+                        const float* tend, int bins, int H, int W, float* out, int* ranges, int mutate, bmc_stream_t s);
+
 /* Sequence encoder on raw dataset columns: what H5Dataset.__getitem__ does per frame on the CPU
  * (dataloader/h5dataset.py:261-316: get_events :407-414 -> augment_event :559-578 -> event_formatting
  * base_dataset.py:24-31 -> events_to_channels), for all frames of a batch in one launch.

@@ -88,6 +88,59 @@ def events_to_voxel_np(xs, ys, ts, ps, num_bins, sensor_size=(180, 240)):
     return out, xs, ys
 
 
+def binary_search_f32(t, l, r, x, side="left"):
+    """The reference's hand-written search on a sorted float32 array (dataloader/encodings.py:75-97), quirks included:
+    it returns the first probe that EQUALS x (either end or the midpoint), not the leftmost / rightmost equal element,
+    and with side != 'left' it returns r (one before the insertion point)."""
+    while l <= r:
+        if t[l] == x:
+            return l
+        if t[r] == x:
+            return r
+        mid = l + (r - l) // 2
+        if t[mid] == x:
+            return mid
+        elif t[mid] < x:
+            l = mid + 1
+        else:
+            r = mid - 1
+    return l if side == "left" else r
+
+
+def events_to_stack_no_polarity_np(xs, ys, ts, ps, B, sensor_size=(180, 240)):
+    """Event stack without polarity split, numpy restatement of dataloader/encodings.py:202-238: B temporal bins of
+    equal width over [ts[0], ts[-1] + 1e-6), each the signed sum of the polarities of its events per pixel
+    (events_to_image_torch :16-73 with clip_out_of_range=False, interpolation=None: NO vertical flip).  The bin's event
+    range comes from the quirky search above on float32 bounds computed exactly as the reference does
+    (ts[0] + delta_t * bi, then + delta_t), so neighbouring bins can overlap by an event.  events_to_image_torch works
+    on VIEWS of the caller's arrays: out-of-range events get xs = ys = ps = 0 in place (so an event masked in one bin is
+    dead in every later bin).  Returns (stack[B,H,W], xs_after, ys_after, ps_after)."""
+    H, W = int(sensor_size[0]), int(sensor_size[1])
+    xs = np.array(xs, dtype=np.float32, copy=True)
+    ys = np.array(ys, dtype=np.float32, copy=True)
+    ps = np.array(ps, dtype=np.float32, copy=True)
+    ts = np.asarray(ts, dtype=np.float32)
+    out = np.zeros((B, H, W), dtype=np.float32)
+    n = len(ts)
+    if n <= 3 or np.float32(ts.sum(dtype=np.float32)) == 0:        # :219-220
+        return out, xs, ys, ps
+    dt = np.float32(np.float32(ts[-1] - ts[0]) + np.float32(1e-6))
+    delta_t = np.float32(dt / np.float32(B))
+    for bi in range(B):
+        tstart = np.float32(ts[0] + np.float32(delta_t * np.float32(bi)))
+        tend = np.float32(tstart + delta_t)
+        beg = binary_search_f32(ts, 0, n - 1, tstart)
+        end = binary_search_f32(ts, 0, n - 1, tend, side="right") + 1
+        sl = slice(beg, end)
+        x, y, p = xs[sl], ys[sl], ps[sl]                          # views, as in the reference
+        oob = (x >= W) | (x < 0) | (y >= H) | (y < 0)
+        x[oob] = 0
+        y[oob] = 0
+        p[oob] = 0
+        np.add.at(out[bi], (y.astype(np.int64), x.astype(np.int64)), p)
+    return out, xs, ys, ps
+
+
 def encode_raw_frame_np(xs_i16, ys_i16, ps_f64, flags, sensor_size):
     """One dataset item's count image from raw HDF5 columns: get_events (dataloader/h5dataset.py:407-414, the
     int16/float64 columns are concatenated into ONE float64 array), augment_event (:559-578, flips in float64),

@@ -290,7 +290,42 @@ def gen_voxel():
     np.savez_compressed(os.path.join(OUT, "voxel.npz"), **out)
 
 
+# ---------------------------------------------------------------- event stack (temporal bins, no polarity split)
+def gen_stack():
+    from dataloader.encodings import events_to_stack_no_polarity
+    rng = np.random.default_rng(9)
+    out = {}
+    # (tag, sensor, events, bins, timestamp style)
+    cases = [("a", (17, 23), 900, 5, "uniform"), ("b", (45, 80), 2048, 3, "uniform"), ("c", (8, 9), 3, 4, "uniform"),
+             ("d", (12, 10), 300, 1, "uniform"), ("e", (20, 31), 1500, 7, "ties"), ("f", (9, 11), 64, 4, "zeros"),
+             ("g", (16, 16), 700, 6, "grid")]
+    for tag, (H, W), n, bins, style in cases:
+        xs = rng.uniform(-1.5, W + 1.5, n).astype(np.float32)
+        ys = rng.uniform(-1.5, H + 1.5, n).astype(np.float32)
+        if style == "uniform":
+            ts = np.sort(rng.uniform(0, 1, n))
+        elif style == "ties":                      # many equal timestamps: exercises the first-equal-probe returns
+            ts = np.sort(rng.integers(0, 40, n) / 40.0)
+        elif style == "grid":                      # timestamps that hit bin boundaries exactly
+            ts = np.sort(rng.integers(0, 13, n) / 12.0)
+        else:
+            ts = np.zeros(n)
+        ts = ts.astype(np.float32)
+        if style != "zeros":                       # event_formatting's normalisation (dataloader/base_dataset.py:30)
+            ts = ((ts - ts[0]) / (ts[-1] - ts[0] + np.float32(1e-6))).astype(np.float32)
+        ps = rng.choice([-1.0, 1.0], n).astype(np.float32)
+        xt, yt, tt, pt = (torch.tensor(a) for a in (xs, ys, ts, ps))
+        st = events_to_stack_no_polarity(xt, yt, tt, pt, bins, sensor_size=(H, W))
+        for k, v in (("xs", xs), ("ys", ys), ("ts", ts), ("ps", ps), ("stack", st.numpy()), ("xs_after", xt.numpy()),
+                     ("ys_after", yt.numpy()), ("ps_after", pt.numpy()), ("meta", np.asarray([H, W, bins]))):
+            out[f"{tag}/{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "stack.npz"), **out)
+
+
 if __name__ == "__main__":
+    if os.environ.get("BMC_GOLDEN_ONLY") == "stack":
+        gen_stack()
+        sys.exit(0)
     if os.environ.get("BMC_GOLDEN_ONLY") == "voxel":
         gen_voxel()
         sys.exit(0)
@@ -300,6 +335,7 @@ if __name__ == "__main__":
     gen_events()
     gen_raw_events()
     gen_voxel()
+    gen_stack()
     gen_layers()
     gen_model("bmcnet_nc16", BMCNet, 16, 2, 2, 10, 12, 3, seed=21, plain=False, wscale=0.6)
     gen_model("plain_nc16", BMCNet_plain, 16, 2, 2, 9, 7, 3, seed=22, plain=True)

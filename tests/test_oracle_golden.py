@@ -206,3 +206,16 @@ def test_events_to_voxel_oracle(tag):
     vox, xa, ya = O.events_to_voxel_np(z[f"{tag}/xs"], z[f"{tag}/ys"], z[f"{tag}/ts"], z[f"{tag}/ps"], bins, (H, W))
     assert np.array_equal(vox, z[f"{tag}/vox"])
     assert np.array_equal(xa, z[f"{tag}/xs_after"]) and np.array_equal(ya, z[f"{tag}/ys_after"])
+
+
+@pytest.mark.parametrize("tag", list("abcdefg"))
+def test_events_to_stack_oracle(tag):
+    """Event stack (dataloader/encodings.py:202-238) incl. the hand-written binary search's quirks (ties, bounds that
+    hit a timestamp exactly), the <= 3 events / all-zero-timestamps early return and the in-place masking of the
+    caller's xs / ys / ps: bit-exact against outputs of the reference itself."""
+    z = load("stack.npz")
+    H, W, bins = (int(v) for v in z[f"{tag}/meta"])
+    st, xa, ya, pa = O.events_to_stack_no_polarity_np(z[f"{tag}/xs"], z[f"{tag}/ys"], z[f"{tag}/ts"], z[f"{tag}/ps"], bins, (H, W))
+    assert np.array_equal(st, z[f"{tag}/stack"])
+    assert np.array_equal(xa, z[f"{tag}/xs_after"]) and np.array_equal(ya, z[f"{tag}/ys_after"])
+    assert np.array_equal(pa, z[f"{tag}/ps_after"])
