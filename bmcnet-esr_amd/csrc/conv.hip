@@ -228,7 +228,13 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
     };
     auto tap_off = [](int tap) { return TAPS == 9 ? ((tap / 3) * HWD + (tap % 3)) * RS : 0; };
 
-    auto epilogue = [&](int tile) {   // bias / residual / ReLU / mask, 16-byte stores, then clear the accumulators
+    // Epilogue: bias / residual / ReLU / mask / accumulate, 16-byte accesses, then clear the accumulators.
+    // MFMA rows = output channels (registers), cols = pixels (lanes): each lane owns, for ITS pixel, four consecutive
+    // channels per register quad.  ALL loads of the epilogue come before ALL its stores: vmcnt completes in order and
+    // counts stores, so a load issued after a store waits for that store's round trip to HBM -- the former
+    // (load, wait, store) per quad serialised 16 store round trips per tile.  Pass 1 finishes the values in place, one
+    // 32x32 MFMA tile (4 quads = 4 independent loads per operand) at a time; pass 2 is nothing but stores.
+    auto epilogue = [&](int tile) {
         int b, y0, x0, nt;
         decode(tile, b, y0, x0, nt);
         const int g = b / a.batch_per_group;
@@ -236,41 +242,87 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
         float* const outb = a.out + (long long)b * a.out_batch_stride;
         const float* const resb = a.residual.ptr ? src_batch_ptr(a.residual, b) : nullptr;
         const float* const maskb = a.mask.ptr ? src_batch_ptr(a.mask, b) : nullptr;
-        // MFMA rows = output channels (registers), cols = pixels (lanes): each lane owns, for ITS pixel, four
-        // consecutive channels per register quad -> 16-byte stores / residual loads (4x fewer VMEM instructions)
+        const int co0 = nt * BN + cobase + 4 * lh;       // + 32 u + 8 rq
+        bool pok[MT];
+        int pix[MT];      // pixel index inside one image: 32-bit offsets from the (uniform) per-image base pointers
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int y = y0 + rowbase + 2 * t + (li >> 4), x = x0 + (li & 15);
-            const bool pok = y < a.H && x < a.W;
-            const long long pix = (long long)y * a.W + x;
+            pok[t] = y < a.H && x < a.W;
+            pix[t] = y * a.W + x;
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
+                f32x4 v[4];
+                bool ok[4];
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
-                    const int co = nt * BN + cobase + 32 * u + 8 * rq + 4 * lh;
-                    if ((BMC_DIAG_MODE & 1) && acc[t][u][4 * rq] != 12345.678f) continue;   // ablation: no stores
-                    if (pok && co < a.Cout) {      // Cout is a multiple of 4: a quad is all-in or all-out
+                    ok[rq] = pok[t] && co0 + 32 * u + 8 * rq < a.Cout;     // Cout is a multiple of 4: a quad is all-in or all-out
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[rq][k] = acc[t][u][4 * rq + k];
+                }
+                auto fetch = [&](const float* base, int off, f32x4 (&d)[4], float fill) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        d[rq] = f32x4{fill, fill, fill, fill};
+                        if (ok[rq]) d[rq] = *reinterpret_cast<const f32x4*>(base + off + co0 + 32 * u + 8 * rq);
+                    }
+                };
+                if (biasg) {
+                    f32x4 d[4];
+                    fetch(biasg, 0, d, 0.f);
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) v[rq] += d[rq];
+                }
+                if (resb) {
+                    f32x4 d[4];
+                    fetch(resb, pix[t] * a.residual.pix_stride, d, 0.f);
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) v[rq] += d[rq];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[rq][k] = fmaxf(v[rq][k], 0.f);
+                }
+                if (maskb) {
+                    f32x4 d[4];
+                    fetch(maskb, pix[t] * a.mask.pix_stride, d, 1.f);
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[rq][k] = d[rq][k] > 0.f ? v[rq][k] : 0.f;
+                }
+                if (a.accumulate) {
+                    f32x4 d[4];
+                    fetch(outb, pix[t] * a.out_pix_stride, d, 0.f);
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) v[rq] += d[rq];
+                }
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[t][u][4 * rq + k] = v[rq][k];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int co = co0 + 32 * u + 8 * rq;
+                    if ((BMC_DIAG_MODE & 1) && acc[t][u][4 * rq] != 12345.678f) continue;
+                    if (pok[t] && co < a.Cout) {
                         f32x4 v;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = acc[t][u][4 * rq + k];
-                        if (biasg) v += *reinterpret_cast<const f32x4*>(biasg + co);
-                        if (resb) v += *reinterpret_cast<const f32x4*>(resb + pix * a.residual.pix_stride + co);
-                        if (a.relu) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-                        }
-                        if (maskb) {
-                            const f32x4 m = *reinterpret_cast<const f32x4*>(maskb + pix * a.mask.pix_stride + co);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) v[k] = m[k] > 0.f ? v[k] : 0.f;
-                        }
-                        f32x4* o = reinterpret_cast<f32x4*>(outb + pix * a.out_pix_stride + co);
-                        if (a.accumulate) v += *o;
-                        *o = v;
+                        *reinterpret_cast<f32x4*>(outb + pix[t] * a.out_pix_stride + co) = v;
                     }
                 }
-            }
-        }
         zero_acc();
     };
 

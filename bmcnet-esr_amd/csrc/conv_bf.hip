@@ -22,7 +22,7 @@
 #include "bf_split.h"
 
 #ifndef BMC_BF_ABL
-#define BMC_BF_ABL 0   // ablation bits for experiment builds (tools/): 4 no MFMAs, 8 no weight loads, 16 no activation loads, 32 no split
+#define BMC_BF_ABL 0   // ablation bits for experiment builds (tools/): 1 no epilogue stores, 4 no MFMAs, 8 no weight loads, 16 no activation loads
 #endif
 
 namespace {
@@ -127,7 +127,10 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
     };
     // TAPS = 1: a step is one 16-channel chunk straight from HBM, shorter than the memory latency, so the loads run XD
     // steps ahead through a register ring (slots are static: the step loop is unrolled by XD)
+    // The ring's loads are issued through inline asm and waited for by hand (wait_x): left to the compiler, the wait in
+    // front of a slot's ds_write comes out as vmcnt(0) (it cannot count across this loop's branches), i.e. a ring of depth 1.
     constexpr int XD = TAPS == 1 ? 3 : 1;
+    constexpr bool ASMX = TAPS == 1;
     f32x4 xr[XD][NXLD];
     auto load_x = [&](int slot) {
         const float* base = sbase + c_in + q * 4;
@@ -135,7 +138,8 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
         for (int n = 0; n < NXLD; ++n) {
             const float* src = xok[n] ? base + (long long)xpix[n] * spix : g_zero4;
             if (BMC_BF_ABL & 16) src = g_zero4;
-            xr[slot][n] = *reinterpret_cast<const f32x4*>(src);
+            if constexpr (ASMX) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[slot][n]) : "v"(src) : "memory");
+            else xr[slot][n] = *reinterpret_cast<const f32x4*>(src);
         }
         c_in += CK;
         if (++xl_chunk == a.nchunks) {
@@ -145,6 +149,10 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
             c_in = 0; ++s_idx;
             src_select();
         }
+    };
+    auto pin_x = [&](int slot) {   // nothing that reads the slot may be scheduled above this point
+#pragma unroll
+        for (int n = 0; n < NXLD; ++n) asm volatile("" : "+v"(xr[slot][n]));
     };
     auto store_x = [&](int slot, int buf) {
 #pragma unroll
@@ -238,6 +246,12 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
     };
     auto tap_shift = [](int tap) { return TAPS == 9 ? (tap / 3) * HWD + (tap % 3) : 0; };
 
+    // Epilogue: bias / residual / ReLU / mask / accumulate, 16-byte accesses, then clear the accumulators.
+    // MFMA rows = output channels (registers), cols = pixels (lanes): each lane owns, for ITS pixel, four consecutive
+    // channels per register quad.  ALL loads of the epilogue come before ALL its stores: vmcnt completes in order and
+    // counts stores, so a load issued after a store waits for that store's round trip to HBM -- the former
+    // (load, wait, store) per quad serialised 16 store round trips per tile.  Pass 1 finishes the values in place, one
+    // 32x32 MFMA tile (4 quads = 4 independent loads per operand) at a time; pass 2 is nothing but stores.
     auto epilogue = [&](int tile) {
         int b, y0, x0, nt;
         decode(tile, b, y0, x0, nt);
@@ -246,38 +260,87 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
         float* const outb = a.out + (long long)b * a.out_batch_stride;
         const float* const resb = a.residual.ptr ? src_batch_ptr(a.residual, b) : nullptr;
         const float* const maskb = a.mask.ptr ? src_batch_ptr(a.mask, b) : nullptr;
+        const int co0 = nt * BN + cobase + 4 * lh;       // + 32 u + 8 rq
+        bool pok[MT];
+        int pix[MT];      // pixel index inside one image: 32-bit offsets from the (uniform) per-image base pointers
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int y = y0 + rowbase + 2 * t + (li >> 4), x = x0 + (li & 15);
-            const bool pok = y < a.H && x < a.W;
-            const long long pix = (long long)y * a.W + x;
+            pok[t] = y < a.H && x < a.W;
+            pix[t] = y * a.W + x;
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
+                f32x4 v[4];
+                bool ok[4];
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
-                    const int co = nt * BN + cobase + 32 * u + 8 * rq + 4 * lh;
-                    if (pok && co < a.Cout) {
+                    ok[rq] = pok[t] && co0 + 32 * u + 8 * rq < a.Cout;     // Cout is a multiple of 4: a quad is all-in or all-out
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[rq][k] = acc[t][u][4 * rq + k];
+                }
+                auto fetch = [&](const float* base, int off, f32x4 (&d)[4], float fill) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        d[rq] = f32x4{fill, fill, fill, fill};
+                        if (ok[rq]) d[rq] = *reinterpret_cast<const f32x4*>(base + off + co0 + 32 * u + 8 * rq);
+                    }
+                };
+                if (biasg) {
+                    f32x4 d[4];
+                    fetch(biasg, 0, d, 0.f);
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) v[rq] += d[rq];
+                }
+                if (resb) {
+                    f32x4 d[4];
+                    fetch(resb, pix[t] * a.residual.pix_stride, d, 0.f);
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) v[rq] += d[rq];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[rq][k] = fmaxf(v[rq][k], 0.f);
+                }
+                if (maskb) {
+                    f32x4 d[4];
+                    fetch(maskb, pix[t] * a.mask.pix_stride, d, 1.f);
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[rq][k] = d[rq][k] > 0.f ? v[rq][k] : 0.f;
+                }
+                if (a.accumulate) {
+                    f32x4 d[4];
+                    fetch(outb, pix[t] * a.out_pix_stride, d, 0.f);
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) v[rq] += d[rq];
+                }
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[t][u][4 * rq + k] = v[rq][k];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int co = co0 + 32 * u + 8 * rq;
+                    if ((BMC_BF_ABL & 1) && acc[t][u][4 * rq] != 12345.678f) continue;
+                    if (pok[t] && co < a.Cout) {
                         f32x4 v;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = acc[t][u][4 * rq + k];
-                        if (biasg) v += *reinterpret_cast<const f32x4*>(biasg + co);
-                        if (resb) v += *reinterpret_cast<const f32x4*>(resb + pix * a.residual.pix_stride + co);
-                        if (a.relu) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-                        }
-                        if (maskb) {
-                            const f32x4 m = *reinterpret_cast<const f32x4*>(maskb + pix * a.mask.pix_stride + co);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) v[k] = m[k] > 0.f ? v[k] : 0.f;
-                        }
-                        f32x4* o = reinterpret_cast<f32x4*>(outb + pix * a.out_pix_stride + co);
-                        if (a.accumulate) v += *o;
-                        *o = v;
+                        *reinterpret_cast<f32x4*>(outb + pix[t] * a.out_pix_stride + co) = v;
                     }
                 }
-            }
-        }
         zero_acc();
     };
 
@@ -285,6 +348,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
     if (xrole) {
         xl_setup(xl_tile);
         load_x(0);
+        if (ASMX) { dma_wait<0>(); pin_x(0); }
         store_x(0, 0);
         if (TAPS == 1) {
 #pragma unroll
@@ -305,26 +369,44 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
     //   weight waves: wait until slice s+1 has landed (slice s+2 may stay in flight); barrier
     int stage = 0;
     if constexpr (TAPS == 1) {
-        int tile = t_first, cc = 0;
+        int tile = t_first, cc = 0, landed = 0;   // landed: upcoming steps whose ring slot is known to be complete
         for (int base = 0; base < total_steps; base += XD) {
 #pragma unroll
             for (int d = 0; d < XD; ++d) {
                 const int s = base + d;     // chunk s: LDS buffer s & 1; chunk c >= 1 travels through ring slot c % XD
                 if (s < total_steps) {
                     if (xrole) {
-                        if (s + 1 < total_steps) store_x((d + 1) % XD, (s + 1) & 1);
+                        if (s + 1 < total_steps) {
+                            // chunk s+1 sits in slot (d+1) % XD; younger loads in flight: chunks s+2 .. s+XD.  After a
+                            // tile's epilogue (which drained everything) the next XD-1 steps need no wait at all, and
+                            // by the first real wait the epilogue's stores (older, counted by vmcnt) have long drained.
+                            if (landed > 0) --landed;
+                            else if (s + XD < total_steps) dma_wait<NXLD * (XD - 1)>();
+                            else dma_wait<0>();
+                            pin_x((d + 1) % XD);
+                            store_x((d + 1) % XD, (s + 1) & 1);
+                        }
                         if (s + 1 + XD < total_steps) load_x((d + 1) % XD);
                     } else {
                         if (s + 2 < total_steps) dma_w();
                     }
                     read_frags(Xb + (s & 1) * XBUF, Wb + stage * WBUF, 0, 0);
                     mma_all();
+                    const bool tile_end = cc + 1 == a.nchunks;
                     if (!xrole) {
-                        if (s + 2 < total_steps) wait_older_slices(); else dma_wait<0>();
+                        // vmcnt completes in order and counts the epilogue's global stores: a wait for a slice issued
+                        // AFTER them would sit out the whole store drain.  So a tile's last step waits for everything
+                        // (slice s+2 included) before the stores go out, and the next step has nothing to wait for.
+                        if (tile_end || s + 2 >= total_steps) dma_wait<0>();
+                        else if (cc != 0 || s == 0) wait_older_slices();
                     }
                     stage = stage == NSTG - 1 ? 0 : stage + 1;
                     __syncthreads();
                     if (++cc == a.nchunks) {
+                        // same for the halo waves: their ring loads are older than the stores about to be issued, but
+                        // the compiler's static vmcnt for the next ds_write must also hold on the no-epilogue path and
+                        // would sit out half the stores; draining the (nearly landed) loads first costs less
+                        if (xrole) { dma_wait<0>(); landed = XD - 1; }
                         epilogue(tile);
                         tile += t_stride;
                         cc = 0;
@@ -348,8 +430,10 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
                     }
                     read_frags(xb, Wb + stage * WBUF, tap_shift(tap), tap / 3);
                     mma_all();
-                    if (!xrole) {
-                        if (gs + 2 < total_steps) wait_older_slices(); else dma_wait<0>();
+                    if (!xrole) {   // (see the 1x1 loop: no wait may straddle the epilogue's stores)
+                        const bool tile_end = last_tap && c + 1 == a.nchunks, tile_begin = tap == 0 && c == 0 && gs != 0;
+                        if (tile_end || gs + 2 >= total_steps) dma_wait<0>();
+                        else if (!tile_begin) wait_older_slices();
                     }
                     stage = stage == NSTG - 1 ? 0 : stage + 1;
                     __syncthreads();
