@@ -561,11 +561,14 @@ def test_fused_twin_bie_matches_unfused_autograd_path():
         assert rel_l2(ga, gb) < 5e-5
 
 
-def test_training_reduces_loss_and_matches_oracle_trajectory():
+@pytest.mark.parametrize("math", ["fp32", "bf16x6"])
+def test_training_reduces_loss_and_matches_oracle_trajectory(math):
     """Three optimizer steps of the reference's recipe (Adam lr=1e-4, wd=1e-5, amsgrad; train.py:647-656) on the HIP
     path vs the same three steps of the CPU oracle + torch.optim.Adam: losses agree step by step (the trajectory, not
-    only one gradient), and the loss goes down."""
+    only one gradient), and the loss goes down.  Both fp32-class arithmetic modes."""
     dev = _gpu()
+    from bmc_hip import ops
+    ops.set_math(math)
     from models.BMCNet_plain import BMCNet_plain
     from oracle import bmc_oracle as O
     from train_step import bptt_step
