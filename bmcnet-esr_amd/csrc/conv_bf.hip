@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
     // The ring's loads are issued through inline asm and waited for by hand (wait_x): left to the compiler, the wait in
     // front of a slot's ds_write comes out as vmcnt(0) (it cannot count across this loop's branches), i.e. a ring of depth 1.
     constexpr int XD = TAPS == 1 ? 3 : 1;
-    constexpr bool ASMX = TAPS == 1;
+    constexpr bool ASMX = TAPS == 1;    // 3x3: ordinary loads; the compiler's wait (everything, at the first store) comes 3+ steps after the issue
     f32x4 xr[XD][NXLD];
     auto load_x = [&](int slot) {
         const float* base = sbase + c_in + q * 4;
@@ -154,18 +154,19 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
 #pragma unroll
         for (int n = 0; n < NXLD; ++n) asm volatile("" : "+v"(xr[slot][n]));
     };
+    auto store_x_item = [&](int slot, int buf, int n) {
+        const int e = xt + 128 * n, hp = e >> 2;
+        if ((n + 1) * 128 <= NHALO * 4 || hp < NHALO) {
+            u32x2 pl[NP];
+            split4<NP>(xr[slot][n], pl);
+            u32* const dst = Xb + buf * XBUF + swz_x(hp, hp / HWD, q >> 1) + 2 * (q & 1);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(dst + p * XPL) = pl[p];
+        }
+    };
     auto store_x = [&](int slot, int buf) {
 #pragma unroll
-        for (int n = 0; n < NXLD; ++n) {
-            const int e = xt + 128 * n, hp = e >> 2;
-            if ((n + 1) * 128 <= NHALO * 4 || hp < NHALO) {
-                u32x2 pl[NP];
-                split4<NP>(xr[slot][n], pl);
-                u32* const dst = Xb + buf * XBUF + swz_x(hp, hp / HWD, q >> 1) + 2 * (q & 1);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(dst + p * XPL) = pl[p];
-            }
-        }
+        for (int n = 0; n < NXLD; ++n) store_x_item(slot, buf, n);
     };
     // ---- W loader (waves 2-3): the packed planes are already the LDS image (swizzle included): linear 1 KB pieces
     const int w2 = wave & 1;
@@ -423,8 +424,13 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
                 for (int tap = 0; tap < TAPS; ++tap, ++gs) {
                     const bool last_tap = tap == TAPS - 1;
                     if (xrole) {
+                        // the next chunk's halo: loads go out at the first tap; its NXLD items are split + stored ONE PER
+                        // STEP over the last NXLD taps (VALU issued beside a saturated matrix pipe costs ~5x its nominal
+                        // cycles: all six items at the last tap made that step several times longer than the others,
+                        // with every wave waiting at its barrier).
                         if (tap == 0 && gc + 1 < total_chunks) load_x(0);
-                        if (last_tap && gc + 1 < total_chunks) store_x(0, (gc + 1) & 1);
+                        constexpr int FIRST = TAPS - NXLD;
+                        if (tap >= FIRST && gc + 1 < total_chunks) store_x_item(0, (gc + 1) & 1, tap - FIRST);
                     } else {
                         if (gs + 2 < total_steps) dma_w();
                     }

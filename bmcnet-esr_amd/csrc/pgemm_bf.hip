@@ -354,7 +354,10 @@ __global__ __launch_bounds__(768, 1) void pgemm_bf9x3_kernel(const PgemmK a) {
                 t.xb[si] = src_batch_ptr(a.src[si], b) + ((long long)(t.y0 - 1) * a.W + (t.x0 - 1)) * a.src[si].pix_stride;
             return t;
         };
-        // Loads are inline asm, waited for by hand (the compiler cannot count vmcnt across this loop).  The common case
+        // Loads are inline asm, waited for by hand (the compiler cannot count vmcnt across this loop).  Hazard of the
+        // idiom: the compiler believes the register is written AT the asm; were it ever to copy the value elsewhere before
+        // the wait (it does not: the `+v` pin after the wait keeps def and use in one register), the copy would be stale --
+        // the parity tests would show garbage, not a small error.  The common case
         // costs no VALU: uniform base (SGPR pair) + the item's 32-bit byte offset; lanes of the last, partial X item
         // beyond the halo read a few in-image bytes that are never stored.
         auto load_item = [&](const TileP& t, int it) {
