@@ -21,6 +21,16 @@
 #include "conv_k.h"
 #include "bf_split.h"
 
+#ifdef BMC_BF_STAMP
+// experiment builds only (tools/): cycle totals of the 1x1 kernel's step phases, wave 0 (halo role) and wave 2 (weight role)
+__device__ unsigned long long g_cstamp[16 * 1024];
+extern "C" int bmc_cstamp_read(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cstamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#define ST(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define ST(v)
+#endif
 #ifndef BMC_BF_ABL
 #define BMC_BF_ABL 0   // ablation bits for experiment builds (tools/): 1 no epilogue stores, 4 no MFMAs, 8 no weight loads, 16 no activation loads
 #endif
@@ -92,28 +102,59 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
     if (my_tiles == 0) return;
     const long long wstep = (long long)NP * a.Coutpad * RD;   // dwords per step in the packed planes
 
-    auto decode = [&](int tile, int& b, int& y0, int& x0, int& nt) {
-        nt = tile % a.ntn; tile /= a.ntn;
-        x0 = (tile % a.tiles_x) * TW; tile /= a.tiles_x;
-        y0 = (tile % a.tiles_y) * TH;
-        b = tile / a.tiles_y;
+    // Tile index -> (channel tile, tile column, tile row, image) is a mixed-radix decode = three integer divisions, ~100
+    // VALU instructions that three users (halo loader, weight loader, epilogue) would pay per tile beside the MFMAs.
+    // A workgroup visits t_first, t_first + t_stride, ...: decode once, then advance digit-wise with carries.
+    struct TileIt { int nt, tx, ty, b; };
+    TileIt it0;
+    {
+        int t = t_first;
+        it0.nt = t % a.ntn; t /= a.ntn;
+        it0.tx = t % a.tiles_x; t /= a.tiles_x;
+        it0.ty = t % a.tiles_y;
+        it0.b = t / a.tiles_y;
+    }
+    int d_nt, d_tx, d_ty, d_b;
+    {
+        int t = t_stride;
+        d_nt = t % a.ntn; t /= a.ntn;
+        d_tx = t % a.tiles_x; t /= a.tiles_x;
+        d_ty = t % a.tiles_y;
+        d_b = t / a.tiles_y;
+    }
+    auto it_next = [&](TileIt& it) {
+        it.nt += d_nt;
+        int c = 0;
+        if (it.nt >= a.ntn) { it.nt -= a.ntn; c = 1; }
+        it.tx += d_tx + c; c = 0;
+        if (it.tx >= a.tiles_x) { it.tx -= a.tiles_x; c = 1; }
+        it.ty += d_ty + c; c = 0;
+        if (it.ty >= a.tiles_y) { it.ty -= a.tiles_y; c = 1; }
+        it.b += d_b + c;
     };
+    TileIt xl_it = it0, wl_it = it0, ep_it = it0;
 
     // ---- X loader (waves 0-1): fp32 from HBM into registers; split into planes when written to LDS
     const int xt = tid & 127, q = tid & 3;
     int xl_tile = t_first, xl_chunk = 0, xl_b = 0, s_idx = 0, c_in = 0;
     const float* sbase = nullptr;
     int spix = 0, snch = 0;
+    int xpix[NXLD];
+    bool xok[NXLD];
+    // Fast path (interior tiles: every halo pixel this wave stages lies in the image): the load address is a uniform
+    // base + a per-lane 32-bit byte offset that is fixed for the (tile, source) -> no per-load VALU at all.  Lanes past
+    // the halo (their data is never stored) read pixel 0.
+    unsigned xoffb[NXLD];
+    bool x_fast = false, xneed[NXLD];
     auto src_select = [&]() {
         const SrcDev S = tab[s_idx];
         sbase = src_batch_ptr(S, xl_b); spix = S.pix_stride; snch = S.nch;
+#pragma unroll
+        for (int n = 0; n < NXLD; ++n) xoffb[n] = TAPS == 1 ? (unsigned)(((xneed[n] ? xpix[n] * spix : 0) + q * 4) * 4) : 0u;
     };
-    int xpix[NXLD];
-    bool xok[NXLD];
-    auto xl_setup = [&](int tile) {
-        int b, y0, x0, nt;
-        decode(tile, b, y0, x0, nt);
-        xl_b = b;
+    auto xl_setup = [&]() {      // for the tile xl_it points at
+        const int y0 = xl_it.ty * TH, x0 = xl_it.tx * TW;
+        xl_b = xl_it.b;
 #pragma unroll
         for (int n = 0; n < NXLD; ++n) {
             const int e = xt + 128 * n, hp = e >> 2;
@@ -121,7 +162,14 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
             const int y = y0 - P + hy, x = x0 - P + hx;
             xok[n] = hp < NHALO && y >= 0 && y < a.H && x >= 0 && x < a.W;   // out-of-image lanes read a zero buffer: no
             xpix[n] = y * a.W + x;                                           // branch, and nothing to fix up after the load
+            xneed[n] = hp < NHALO;
         }
+        bool allin = true;
+#pragma unroll
+        for (int n = 0; n < NXLD; ++n) allin = allin && (xok[n] || !xneed[n]);
+        // (1x1 only: there a step is short and the halo waves' instruction count is what limits it; the 3x3 kernel measured
+        //  slower with the second code path, 0.556 -> 0.587 ms)
+        x_fast = TAPS == 1 && __all(allin) && (long long)a.H * a.W * a.Cout < (1ll << 28);   // one image's offsets fit 32 bits with room
         s_idx = 0; c_in = 0; xl_chunk = 0;
         src_select();
     };
@@ -133,18 +181,32 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
     constexpr bool ASMX = TAPS == 1;    // 3x3: ordinary loads; the compiler's wait (everything, at the first store) comes 3+ steps after the issue
     f32x4 xr[XD][NXLD];
     auto load_x = [&](int slot) {
-        const float* base = sbase + c_in + q * 4;
+        if (TAPS == 1 && x_fast && !(BMC_BF_ABL & 16)) {
+            // uniform, but it came through LDS (the source table): tell the compiler, so that it can live in SGPRs
+            const unsigned long long sbv = reinterpret_cast<unsigned long long>(sbase + c_in);
+            const unsigned sb_lo = __builtin_amdgcn_readfirstlane((unsigned)sbv), sb_hi = __builtin_amdgcn_readfirstlane((unsigned)(sbv >> 32));
+            const float* const sb = reinterpret_cast<const float*>(((unsigned long long)sb_hi << 32) | sb_lo);
 #pragma unroll
-        for (int n = 0; n < NXLD; ++n) {
-            const float* src = xok[n] ? base + (long long)xpix[n] * spix : g_zero4;
-            if (BMC_BF_ABL & 16) src = g_zero4;
-            if constexpr (ASMX) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[slot][n]) : "v"(src) : "memory");
-            else xr[slot][n] = *reinterpret_cast<const f32x4*>(src);
+            for (int n = 0; n < NXLD; ++n) {
+                // (s_nop: a VALU-written SGPR -- the readfirstlane above -- needs 5 wait states before a VMEM instruction may
+                //  use it as its scalar base, and the hazard recognizer does not look inside inline asm)
+                if constexpr (ASMX) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(xr[slot][n]) : "v"(xoffb[n]), "s"(sb) : "memory");
+                else xr[slot][n] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sb) + xoffb[n]);
+            }
+        } else {
+            const float* base = sbase + c_in + q * 4;
+#pragma unroll
+            for (int n = 0; n < NXLD; ++n) {
+                const float* src = xok[n] ? base + (long long)xpix[n] * spix : g_zero4;
+                if (BMC_BF_ABL & 16) src = g_zero4;
+                if constexpr (ASMX) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[slot][n]) : "v"(src) : "memory");
+                else xr[slot][n] = *reinterpret_cast<const f32x4*>(src);
+            }
         }
         c_in += CK;
         if (++xl_chunk == a.nchunks) {
             xl_tile += t_stride;
-            if (xl_tile < t_hi) xl_setup(xl_tile);
+            if (xl_tile < t_hi) { it_next(xl_it); xl_setup(); }
         } else if (c_in >= snch) {
             c_in = 0; ++s_idx;
             src_select();
@@ -172,10 +234,9 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
     const int w2 = wave & 1;
     int wl_tile = t_first, wl_step = 0, wl_stage = 0;
     const u32* wl_base = nullptr;
-    auto wl_setup = [&](int tile) {
-        int b, y0, x0, nt;
-        decode(tile, b, y0, x0, nt);
-        wl_base = static_cast<const u32*>(a.w) + (long long)(b / a.batch_per_group) * a.w_group_stride + (long long)nt * BN * RD;
+    auto wl_setup = [&]() {      // for the tile wl_it points at
+        const int grp = a.batch_per_group >= a.B ? 0 : wl_it.b / a.batch_per_group;
+        wl_base = static_cast<const u32*>(a.w) + (long long)grp * a.w_group_stride + (long long)wl_it.nt * BN * RD;
         wl_step = 0;
     };
     const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Wb;
@@ -193,7 +254,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
         wl_stage = wl_stage == NSTG - 1 ? 0 : wl_stage + 1;
         if (++wl_step == nsteps) {
             wl_tile += t_stride;
-            if (wl_tile < t_hi) wl_setup(wl_tile);
+            if (wl_tile < t_hi) { it_next(wl_it); wl_setup(); }
         }
     };
     constexpr int DMA_W0 = (NDMA + 1) / 2, DMA_W1 = NDMA / 2;   // pieces per slice issued by loader wave 0 / 1
@@ -211,6 +272,15 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
 #pragma unroll
     for (int u = 0; u < NT; ++u) boff[u] = swz_w(cobase + 32 * u + li, lh);
 
+    // one weight group and one channel tile (the usual case): this lane's bias values never change -> registers, once
+    const bool bias_pre = a.bias != nullptr && a.batch_per_group >= a.B && a.ntn == 1;
+    f32x4 bias_r[NT * 4];
+#pragma unroll
+    for (int i = 0; i < NT * 4; ++i) {
+        const int co = cobase + 4 * lh + 32 * (i >> 2) + 8 * (i & 3);
+        bias_r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias_pre && co < a.Cout) bias_r[i] = *reinterpret_cast<const f32x4*>(a.bias + co);
+    }
     f32x16 acc[MT][NT];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -253,10 +323,10 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
     // counts stores, so a load issued after a store waits for that store's round trip to HBM -- the former
     // (load, wait, store) per quad serialised 16 store round trips per tile.  Pass 1 finishes the values in place, one
     // 32x32 MFMA tile (4 quads = 4 independent loads per operand) at a time; pass 2 is nothing but stores.
-    auto epilogue = [&](int tile) {
-        int b, y0, x0, nt;
-        decode(tile, b, y0, x0, nt);
-        const int g = b / a.batch_per_group;
+    auto epilogue = [&](int) {    // for the tile ep_it points at; advances it
+        const int b = ep_it.b, y0 = ep_it.ty * TH, x0 = ep_it.tx * TW, nt = ep_it.nt;
+        it_next(ep_it);
+        const int g = a.batch_per_group >= a.B ? 0 : b / a.batch_per_group;
         const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
         float* const outb = a.out + (long long)b * a.out_batch_stride;
         const float* const resb = a.residual.ptr ? src_batch_ptr(a.residual, b) : nullptr;
@@ -289,7 +359,10 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
                         if (ok[rq]) d[rq] = *reinterpret_cast<const f32x4*>(base + off + co0 + 32 * u + 8 * rq);
                     }
                 };
-                if (biasg) {
+                if (bias_pre) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) v[rq] += bias_r[u * 4 + rq];
+                } else if (biasg) {
                     f32x4 d[4];
                     fetch(biasg, 0, d, 0.f);
 #pragma unroll
@@ -347,7 +420,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
 
     // ---- prologue: halo of chunk 0 in LDS, weight slices 0 and 1 in flight, slice 0 landed
     if (xrole) {
-        xl_setup(xl_tile);
+        xl_setup();
         load_x(0);
         if (ASMX) { dma_wait<0>(); pin_x(0); }
         store_x(0, 0);
@@ -357,7 +430,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
                 if (j < total_chunks) load_x(j % XD);
         }
     } else {
-        wl_setup(wl_tile);
+        wl_setup();
         dma_w();
         if (total_steps > 1) { dma_w(); wait_older_slices(); } else dma_wait<0>();
     }
@@ -371,11 +444,15 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
     int stage = 0;
     if constexpr (TAPS == 1) {
         int tile = t_first, cc = 0, landed = 0;   // landed: upcoming steps whose ring slot is known to be complete
+#ifdef BMC_BF_STAMP
+        unsigned long long st_stage = 0, st_mma = 0, st_wait = 0, st_bar = 0, st_epi = 0;
+#endif
         for (int base = 0; base < total_steps; base += XD) {
 #pragma unroll
             for (int d = 0; d < XD; ++d) {
                 const int s = base + d;     // chunk s: LDS buffer s & 1; chunk c >= 1 travels through ring slot c % XD
                 if (s < total_steps) {
+                    ST(c0);
                     if (xrole) {
                         if (s + 1 < total_steps) {
                             // chunk s+1 sits in slot (d+1) % XD; younger loads in flight: chunks s+2 .. s+XD.  After a
@@ -391,8 +468,10 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
                     } else {
                         if (s + 2 < total_steps) dma_w();
                     }
+                    ST(c1);
                     read_frags(Xb + (s & 1) * XBUF, Wb + stage * WBUF, 0, 0);
                     mma_all();
+                    ST(c2);
                     const bool tile_end = cc + 1 == a.nchunks;
                     if (!xrole) {
                         // vmcnt completes in order and counts the epilogue's global stores: a wait for a slice issued
@@ -402,7 +481,9 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
                         else if (cc != 0 || s == 0) wait_older_slices();
                     }
                     stage = stage == NSTG - 1 ? 0 : stage + 1;
+                    ST(c3);
                     __syncthreads();
+                    ST(c4);
                     if (++cc == a.nchunks) {
                         // same for the halo waves: their ring loads are older than the stores about to be issued, but
                         // the compiler's static vmcnt for the next ds_write must also hold on the no-epilogue path and
@@ -412,9 +493,19 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
                         tile += t_stride;
                         cc = 0;
                     }
+#ifdef BMC_BF_STAMP
+                    { const unsigned long long c5 = __builtin_amdgcn_s_memtime();
+                      st_stage += c1 - c0; st_mma += c2 - c1; st_wait += c3 - c2; st_bar += c4 - c3; st_epi += c5 - c4; }
+#endif
                 }
             }
         }
+#ifdef BMC_BF_STAMP
+        if ((tid == 0 || tid == 128) && blockIdx.x < 1024) {
+            unsigned long long* o = g_cstamp + (blockIdx.x * 2 + (tid >> 7)) * 8;
+            o[0] = st_stage; o[1] = st_mma; o[2] = st_wait; o[3] = st_bar; o[4] = st_epi; o[5] = total_steps; o[6] = my_tiles;
+        }
+#endif
     } else {
         int gs = 0, gc = 0;
         for (int tile = t_first; tile < t_hi; tile += t_stride) {

@@ -359,12 +359,13 @@ __global__ __launch_bounds__(768, 1) void pgemm_bf9x3_kernel(const PgemmK a) {
         // the wait (it does not: the `+v` pin after the wait keeps def and use in one register), the copy would be stale --
         // the parity tests would show garbage, not a small error.  The common case
         // costs no VALU: uniform base (SGPR pair) + the item's 32-bit byte offset; lanes of the last, partial X item
-        // beyond the halo read a few in-image bytes that are never stored.
+        // beyond the halo read a few in-image bytes that are never stored.  (s_nop 4: the scalar base may have been produced
+        // by a VALU readfirstlane; 5 wait states are required before VMEM uses it and inline asm is opaque to the hazard pass.)
         auto load_item = [&](const TileP& t, int it) {
             if (it < NAL) {
                 const int i2 = it;
                 if (t.fast) {
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ar[0][i2]) : "v"(a_off[i2]), "s"(t.ab) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(ar[0][i2]) : "v"(a_off[i2]), "s"(t.ab) : "memory");
                 } else {
                     const bool ok = t.live && a_cok[i2] && t.y0 + (a_yx[i2] >> 16) < a.H && t.x0 + (a_yx[i2] & 0xffff) < a.W;
                     const float* src = ok ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(t.ab) + a_off[i2]) : a.zeros;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(768, 1) void pgemm_bf9x3_kernel(const PgemmK a) {
             } else {
                 const int i2 = it - NAL;
                 if (t.fast) {
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xr[0][i2]) : "v"(x_off[i2]), "s"(t.xb[0]) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(xr[0][i2]) : "v"(x_off[i2]), "s"(t.xb[0]) : "memory");
                 } else {
                     const int y = t.y0 - 1 + (x_yx[i2] >> 16), x = t.x0 - 1 + (x_yx[i2] & 0xffff);
                     const bool ok = t.live && x_cok[i2] && y >= 0 && y < a.H && x >= 0 && x < a.W;
