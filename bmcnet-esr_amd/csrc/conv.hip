@@ -85,12 +85,37 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
     if (my_tiles == 0) return;   // block-uniform
     const long long wstep = (long long)a.Coutpad * CK;
 
-    auto decode = [&](int tile, int& b, int& y0, int& x0, int& nt) {
-        nt = tile % a.ntn; tile /= a.ntn;
-        x0 = (tile % a.tiles_x) * TW; tile /= a.tiles_x;
-        y0 = (tile % a.tiles_y) * TH;
-        b = tile / a.tiles_y;
+    // Tile index -> (channel tile, tile column, tile row, image) is a mixed-radix decode = three integer divisions, ~100
+    // VALU instructions that three users (X loader, W loader, epilogue) would pay per tile beside the MFMAs.  A
+    // workgroup visits t_first, t_first + t_stride, ...: decode once, then advance digit-wise with carries.
+    struct TileIt { int nt, tx, ty, b; };
+    TileIt it0;
+    {
+        int t = t_first;
+        it0.nt = t % a.ntn; t /= a.ntn;
+        it0.tx = t % a.tiles_x; t /= a.tiles_x;
+        it0.ty = t % a.tiles_y;
+        it0.b = t / a.tiles_y;
+    }
+    int d_nt, d_tx, d_ty, d_b;
+    {
+        int t = t_stride;
+        d_nt = t % a.ntn; t /= a.ntn;
+        d_tx = t % a.tiles_x; t /= a.tiles_x;
+        d_ty = t % a.tiles_y;
+        d_b = t / a.tiles_y;
+    }
+    auto it_next = [&](TileIt& it) {
+        it.nt += d_nt;
+        int c = 0;
+        if (it.nt >= a.ntn) { it.nt -= a.ntn; c = 1; }
+        it.tx += d_tx + c; c = 0;
+        if (it.tx >= a.tiles_x) { it.tx -= a.tiles_x; c = 1; }
+        it.ty += d_ty + c; c = 0;
+        if (it.ty >= a.tiles_y) { it.ty -= a.tiles_y; c = 1; }
+        it.b += d_b + c;
     };
+    TileIt xl_it = it0, wl_it = it0, ep_it = it0;
     const int q4 = (tid & 3) * 4;
 
     // ---- X loader: walks (tile, chunk) in consumption order
@@ -103,10 +128,9 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
     };
     int xpix[NXLD];
     bool xok[NXLD];
-    auto xl_setup = [&](int tile) {
-        int b, y0, x0, nt;
-        decode(tile, b, y0, x0, nt);
-        xl_b = b;
+    auto xl_setup = [&]() {      // for the tile xl_it points at
+        const int y0 = xl_it.ty * TH, x0 = xl_it.tx * TW;
+        xl_b = xl_it.b;
 #pragma unroll
         for (int n = 0; n < NXLD; ++n) {
             const int e = tid + 256 * n, hp = e >> 2;
@@ -131,7 +155,7 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
         c_in += CK;
         if (++xl_chunk == a.nchunks) {
             xl_tile += t_stride;
-            if (xl_tile < t_hi) xl_setup(xl_tile);
+            if (xl_tile < t_hi) { it_next(xl_it); xl_setup(); }
         } else if (c_in >= snch) {
             c_in = 0; ++s_idx;
             src_select();
@@ -147,10 +171,9 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
     // ---- W loader: walks (tile, step)
     int wl_tile = t_first, wl_step = 0;
     const float* wl_base = nullptr;
-    auto wl_setup = [&](int tile) {
-        int b, y0, x0, nt;
-        decode(tile, b, y0, x0, nt);
-        wl_base = static_cast<const float*>(a.w) + (long long)(b / a.batch_per_group) * a.w_group_stride + (long long)nt * BN * CK;
+    auto wl_setup = [&]() {      // for the tile wl_it points at
+        const int grp = a.batch_per_group >= a.B ? 0 : wl_it.b / a.batch_per_group;
+        wl_base = static_cast<const float*>(a.w) + (long long)grp * a.w_group_stride + (long long)wl_it.nt * BN * CK;
         wl_step = 0;
     };
     auto load_w = [&]() {
@@ -166,7 +189,7 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
         }
         if (++wl_step == nsteps) {
             wl_tile += t_stride;
-            if (wl_tile < t_hi) wl_setup(wl_tile);
+            if (wl_tile < t_hi) { it_next(wl_it); wl_setup(); }
         }
     };
     auto store_w = [&](int buf) {
@@ -234,10 +257,10 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
     // counts stores, so a load issued after a store waits for that store's round trip to HBM -- the former
     // (load, wait, store) per quad serialised 16 store round trips per tile.  Pass 1 finishes the values in place, one
     // 32x32 MFMA tile (4 quads = 4 independent loads per operand) at a time; pass 2 is nothing but stores.
-    auto epilogue = [&](int tile) {
-        int b, y0, x0, nt;
-        decode(tile, b, y0, x0, nt);
-        const int g = b / a.batch_per_group;
+    auto epilogue = [&](int) {    // for the tile ep_it points at; advances it
+        const int b = ep_it.b, y0 = ep_it.ty * TH, x0 = ep_it.tx * TW, nt = ep_it.nt;
+        it_next(ep_it);
+        const int g = a.batch_per_group >= a.B ? 0 : b / a.batch_per_group;
         const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
         float* const outb = a.out + (long long)b * a.out_batch_stride;
         const float* const resb = a.residual.ptr ? src_batch_ptr(a.residual, b) : nullptr;
@@ -326,8 +349,8 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
         zero_acc();
     };
 
-    xl_setup(xl_tile);
-    wl_setup(wl_tile);
+    xl_setup();
+    wl_setup();
     load_x(0);
     load_w();
     store_x(0, 0);
