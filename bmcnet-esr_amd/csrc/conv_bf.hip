@@ -49,8 +49,10 @@ __device__ __forceinline__ int swz_x(int hp, int hy, int half) { return hp * RD 
 // Inline asm on purpose: the compiler must not track this as an LDS store, or it drains vmcnt(0) before every later
 // ds_read and the ring could never run ahead.  Completion is waited for explicitly (dma_wait) before the barrier
 // that publishes the stage.
-__device__ __forceinline__ void dma16(const void* gptr, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory");   // m0: reserved, cannot be named as a clobber; nothing else in this kernel uses it
+// Address = uniform base (SGPR pair) + this lane's 32-bit byte offset: no per-piece VALU.  (m0 is reserved and cannot be
+// named as a clobber; nothing else in this kernel uses it.  s_nop 4: wait states for a VALU-written SGPR base / m0.)
+__device__ __forceinline__ void dma16(const void* gbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase), "s"(lds_addr) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void dma_wait() {   // all but the newest N vector-memory operations of this wave are done
@@ -240,16 +242,24 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
         wl_step = 0;
     };
     const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Wb;
-    auto dma_w = [&]() {   // one slice into ring stage wl_stage; this wave issues the pieces j = w2, w2 + 2, ...
-        const u32* p = wl_base + (long long)wl_step * wstep;
+    // this wave issues the pieces j = w2, w2 + 2, ... of a slice; a piece's offset inside the slice never changes
+    constexpr int PWMAX = (NDMA + 1) / 2;
+    unsigned dma_off[PWMAX];
 #pragma unroll
-        for (int j = 0; j < NDMA; ++j) {
-            if ((j & 1) != w2 && NDMA > 1) continue;
-            if (NDMA == 1 && w2) continue;
-            const int e = j * 64 + lane;
-            const int pl = e / (BN * 2), within = e - pl * (BN * 2);
-            if (!(BMC_BF_ABL & 8))
-                dma16(p + (long long)pl * a.Coutpad * RD + within * 4, wb_lds + (unsigned)((wl_stage * WBUF + j * 256) * 4));
+    for (int i = 0; i < PWMAX; ++i) {
+        const int j = 2 * i + w2, e = (j < NDMA ? j : 0) * 64 + lane;
+        const int pl = e / (BN * 2), within = e - pl * (BN * 2);
+        dma_off[i] = (unsigned)((pl * a.Coutpad * RD + within * 4) * 4);
+    }
+    auto dma_w = [&]() {   // one slice into ring stage wl_stage
+        const unsigned long long pv = reinterpret_cast<unsigned long long>(wl_base + (long long)wl_step * wstep);
+        const unsigned p_lo = __builtin_amdgcn_readfirstlane((unsigned)pv), p_hi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
+        const void* const p = reinterpret_cast<const void*>(((unsigned long long)p_hi << 32) | p_lo);
+#pragma unroll
+        for (int i = 0; i < PWMAX; ++i) {
+            const int j = 2 * i + w2;
+            if (j < NDMA && !(BMC_BF_ABL & 8) && !(NDMA == 1 && w2))
+                dma16(p, dma_off[i], wb_lds + (unsigned)((wl_stage * WBUF + j * 256) * 4));
         }
         wl_stage = wl_stage == NSTG - 1 ? 0 : wl_stage + 1;
         if (++wl_step == nsteps) {
