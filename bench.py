@@ -90,8 +90,9 @@ def dominant_kernel_roofline(step_fn, iso, math="fp32"):
     ach = fl / (ms * 1e-3) / 1e12
     traffic = None      # HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), never computed here
     tj = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-    if os.path.exists(tj) and math == "fp32":
-        traffic = json.load(open(tj))["conv_kernel<9,128>"]["hbm_bytes_per_launch"]
+    if os.path.exists(tj):
+        entry = json.load(open(tj)).get({"fp32": "conv_kernel<9,128>", "bf16x6": "conv_bf_kernel<9,128,8,3>"}.get(math, ""))
+        traffic = entry["hbm_bytes_per_launch"] if entry else None
     peak = KERNEL_PEAK[math]
     out = {"bound": "mfma", "kernel": "%s (3x3 implicit GEMM fwd + dgrad, all %d launches of one step)" % (KERNEL_NAME[math], n),
            "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
