@@ -211,9 +211,6 @@ def _packed_weight_t(w4: torch.Tensor, spec: ConvSpec, src_index: int, owner):
     return out
 
 
-def clear_pack_cache():
-    pass    # caches live on the ConvSpec objects and die with them
-
 
 # --------------------------------------------------------------------------
 # raw launches
