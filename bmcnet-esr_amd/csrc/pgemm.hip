@@ -50,13 +50,71 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int ntiles = a.batch_per_group * a.tiles_per_img;
-    auto issue = [&](int tile, int buf) {
-        const int bb = tile / a.tiles_per_img, tin = tile - bb * a.tiles_per_img;
-        const int b = g * a.batch_per_group + bb;
+    // ---- tile fill by LDS-DMA.  Instructions issued beside the MFMAs cost matrix-pipe time about 1:1 (in-kernel stamps:
+    // the fill of one tile took 4 000 cycles per wave = 9 % of a 3x3 tile, 21 % of a 1x1 tile, nearly all of it address
+    // arithmetic), so everything that does not depend on the tile is computed ONCE per piece here -- byte offset from
+    // the tile's first (halo) pixel, pixel coordinates inside the tile -- and interior tiles whose channels all exist in
+    // ONE source are filled with "uniform base (SGPR pair) + per-lane 32-bit offset" DMA: no VALU per piece.
+    // the source that holds this workgroup's block of columns [n0, n0 + XCH) -- if one source holds all of it
+    SrcDev xs = a.src[0];
+    int xch0 = n0;
+#pragma unroll
+    for (int si = 1; si < BMC_MAX_SRC; ++si)
+        if (xch0 >= xs.nch && si < a.nsrc) { xch0 -= xs.nch; xs = a.src[si]; }
+    const bool x_one_src = xch0 + XCH <= xs.nch;
+    int a_off[4], x_off[4], a_yx[4], x_yx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = i * 512 + tid, p = e >> 5, c4 = (e & 31) * 4;
+        a_yx[i] = TAPS == 9 ? ((p >> 4) << 16) | (p & 15) : p;
+        a_off[i] = ((TAPS == 9 ? (p >> 4) * a.W + (p & 15) : p) * a.a.pix_stride + m0 + c4) * 4;
+        const int hp = e >> XSH, xc4 = (e & ((1 << XSH) - 1)) * 4;
+        const int hy = TAPS == 9 ? hp / HWD : 0, hx = TAPS == 9 ? hp - hy * HWD : hp;
+        x_yx[i] = TAPS == 9 ? (hy << 16) | hx : hp;
+        // lanes beyond the halo (3x3: hp >= NHALO) read the tile's first pixel; their LDS rows are never used
+        x_off[i] = ((TAPS == 9 ? (hp < NHALO ? hy * a.W + hx : 0) : hp) * xs.pix_stride + xch0 + xc4) * 4;
+    }
+    const bool all_ch = m0 + 128 <= a.M && n0 + XCH <= a.N && x_one_src &&
+                        (long long)a.H * a.W * (a.a.pix_stride > xs.pix_stride ? a.a.pix_stride : xs.pix_stride) < (1ll << 28);
+    // (image, tile row, tile column) of the next tile to fill, advanced incrementally (tiles are visited in order)
+    const int step_img = a.nsplit / a.tiles_per_img, step_rem = a.nsplit - step_img * a.tiles_per_img;
+    const int step_ty = TAPS == 9 ? step_rem / a.tiles_x : 0, step_tx = TAPS == 9 ? step_rem - step_ty * a.tiles_x : step_rem;
+    int nx_bb = split / a.tiles_per_img, nx_ty, nx_tx;
+    {
+        const int tin = split - nx_bb * a.tiles_per_img;
+        nx_ty = TAPS == 9 ? tin / a.tiles_x : 0; nx_tx = TAPS == 9 ? tin - nx_ty * a.tiles_x : tin;
+    }
+    auto dma = [&](const void* sbase, unsigned voff, float* ldst) {
+        const unsigned long long pv = reinterpret_cast<unsigned long long>(sbase);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pv), hi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
+        const void* const sb = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+        const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ldst);
+        // (s_nop 4: wait states between the VALU-written SGPRs / m0 and the VMEM instruction; inline asm is opaque to the
+        //  hazard recognizer.  m0 is reserved and cannot be named as a clobber; nothing else in this kernel uses it.)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(la) : "memory");
+    };
+    auto issue = [&](int tile, int buf) {      // must be called for tiles split, split + nsplit, ... in order
+        const int b = g * a.batch_per_group + nx_bb;
         int y0 = 0, x0 = 0, p0 = 0;
-        if (TAPS == 9) { y0 = (tin / a.tiles_x) * PT_H; x0 = (tin % a.tiles_x) * PT_W; }
-        else p0 = tin * PT;
+        if (TAPS == 9) { y0 = nx_ty * PT_H; x0 = nx_tx * PT_W; }
+        else p0 = nx_tx * PT;
+        nx_bb += step_img; nx_ty += step_ty; nx_tx += step_tx;
+        if (TAPS == 9) {
+            if (nx_tx >= a.tiles_x) { nx_tx -= a.tiles_x; ++nx_ty; }
+            if (nx_ty >= a.tiles_y) { nx_ty -= a.tiles_y; ++nx_bb; }
+        } else if (nx_tx >= a.tiles_per_img) { nx_tx -= a.tiles_per_img; ++nx_bb; }
         const float* ab = src_batch_ptr(a.a, b);
+        const bool interior = TAPS == 9 ? (y0 >= 1 && x0 >= 1 && y0 + PT_H + 1 <= a.H && x0 + PT_W + 1 <= a.W) : (p0 + PT <= HWp);
+        if (interior && all_ch) {
+            const float* const abt = ab + (TAPS == 9 ? (long long)y0 * a.W + x0 : (long long)p0) * a.a.pix_stride;
+            const float* const xbt = src_batch_ptr(xs, b) +
+                                     (TAPS == 9 ? (long long)(y0 - 1) * a.W + (x0 - 1) : (long long)p0) * xs.pix_stride;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma(abt, (unsigned)a_off[i], lds + buf * BUF + (i * 512 + wave * 64) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma(xbt, (unsigned)x_off[i], lds + (2 + buf) * BUF + (i * 512 + wave * 64) * 4);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {            // A tile: [64 px][128 ch]
             const int e = i * 512 + tid, p = e >> 5, c4 = (e & 31) * 4;
@@ -106,6 +164,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
     };
 
     if (split < ntiles) issue(split, 0);
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // vmcnt(0): the asm DMA is invisible to the compiler's own waits
     __syncthreads();
     // bias gradient = column sums of A over pixels: the first n-block adds up its A tiles straight from LDS
     // (thread -> channel tid & 127, rows (tid >> 7) * 16 .. + 16); 4 partial rows per workgroup go to bias_slabs
@@ -138,7 +197,8 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
                     }
             }
         }
-        __syncthreads();    // drains the DMA of the next tile (vmcnt) and fences this tile's LDS reads
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // vmcnt(0): the next tile's DMA has landed
+        __syncthreads();    // publishes it and fences this tile's LDS reads
     }
 
     if (do_bias && m0 + (tid & 127) < a.Mpad)
