@@ -83,6 +83,32 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
     // `vt` = tid behind an opaque barrier: keeps the compiler from hoisting the per-thread index arithmetic of the 8
     // loads / stores out of the tile loop into dozens of long-lived registers (the accumulators need them)
     constexpr bool NOHOIST = TAPS == 9 && !TSPLIT;     // 144 accumulator registers: no room for hoisted index math
+    // Fast path (as in pgemm.hip): interior tiles whose columns lie in ONE source load with a uniform base + a per-item
+    // 32-bit byte offset computed once per kernel -- instructions issued beside the MFMAs cost matrix-pipe time ~1:1.
+    SrcDev xs = a.src[0];
+    int xch0 = n0;
+#pragma unroll
+    for (int si = 1; si < BMC_MAX_SRC; ++si)
+        if (xch0 >= xs.nch && si < a.nsrc) { xch0 -= xs.nch; xs = a.src[si]; }
+    const bool all_ch = m0 + 128 <= a.M && n0 + XCH <= a.N && xch0 + XCH <= xs.nch &&
+                        (long long)a.H * a.W * (a.a.pix_stride > xs.pix_stride ? a.a.pix_stride : xs.pix_stride) < (1ll << 28);
+    unsigned fa_off[NAL], fx_off[NXL];
+#pragma unroll
+    for (int i = 0; i < NAL; ++i) {
+        const int e = i * 512 + tid, p = e >> 5, c4 = (e & 31) * 4;
+        fa_off[i] = (unsigned)(((TAPS == 9 ? (p >> 4) * a.W + (p & 15) : p) * a.a.pix_stride + m0 + c4) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+        const int e = i * 512 + tid, hp = e / XQ, c4 = (e % XQ) * 4;
+        const int hy = TAPS == 9 ? hp / HWD : 0, hx = TAPS == 9 ? hp - hy * HWD : hp;
+        fx_off[i] = (unsigned)(((TAPS == 9 ? (hp < NHALO ? hy * a.W + hx : 0) : hp) * xs.pix_stride + xch0 + c4) * 4);
+    }
+    auto uniform_ptr = [](const float* p) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+    };
     auto load_tile = [&](int tile, int slot) {
         int vt = tid;
         if (NOHOIST) asm volatile("" : "+v"(vt));
@@ -92,6 +118,17 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
         if (TAPS == 9) { y0 = (tin / a.tiles_x) * PT_H; x0 = (tin % a.tiles_x) * PT_W; }
         else p0 = tin * PT;
         const float* ab = src_batch_ptr(a.a, b);
+        const bool interior = TAPS == 9 ? (y0 >= 1 && x0 >= 1 && y0 + PT_H + 1 <= a.H && x0 + PT_W + 1 <= a.W) : (p0 + PT <= HWp);
+        if (interior && all_ch) {
+            const char* const abt = uniform_ptr(ab + (TAPS == 9 ? (long long)y0 * a.W + x0 : (long long)p0) * a.a.pix_stride);
+            const char* const xbt = uniform_ptr(src_batch_ptr(xs, b) +
+                                                (TAPS == 9 ? (long long)(y0 - 1) * a.W + (x0 - 1) : (long long)p0) * xs.pix_stride);
+#pragma unroll
+            for (int i = 0; i < NAL; ++i) ar[slot][i] = *reinterpret_cast<const f32x4*>(abt + fa_off[i]);
+#pragma unroll
+            for (int i = 0; i < NXL; ++i) xr[slot][i] = *reinterpret_cast<const f32x4*>(xbt + fx_off[i]);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NAL; ++i) {
             const int e = i * 512 + vt, p = e >> 5, c4 = (e & 31) * 4;
