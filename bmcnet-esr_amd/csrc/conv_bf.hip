@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
         for (int n = 0; n < NXLD; ++n) allin = allin && (xok[n] || !xneed[n]);
         // (1x1 only: there a step is short and the halo waves' instruction count is what limits it; the 3x3 kernel measured
         //  slower with the second code path, 0.556 -> 0.587 ms)
-        x_fast = TAPS == 1 && __all(allin) && (long long)a.H * a.W * a.Cout < (1ll << 28);   // one image's offsets fit 32 bits with room
+        x_fast = TAPS == 1 && __all(allin);
         s_idx = 0; c_in = 0; xl_chunk = 0;
         src_select();
     };
@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
     constexpr bool ASMX = TAPS == 1;    // 3x3: ordinary loads; the compiler's wait (everything, at the first store) comes 3+ steps after the issue
     f32x4 xr[XD][NXLD];
     auto load_x = [&](int slot) {
-        if (TAPS == 1 && x_fast && !(BMC_BF_ABL & 16)) {
+        // (the byte offsets of one image of this source must fit the instruction's unsigned 32-bit lane offset)
+        if (TAPS == 1 && x_fast && (long long)a.H * a.W * spix < (1ll << 29) && !(BMC_BF_ABL & 16)) {
             // uniform, but it came through LDS (the source table): tell the compiler, so that it can live in SGPRs
             const unsigned long long sbv = reinterpret_cast<unsigned long long>(sbase + c_in);
             const unsigned sb_lo = __builtin_amdgcn_readfirstlane((unsigned)sbv), sb_hi = __builtin_amdgcn_readfirstlane((unsigned)(sbv >> 32));

@@ -362,7 +362,8 @@ __global__ __launch_bounds__(768, 1) void pgemm_bf9x3_kernel(const PgemmK a) {
             x_lds[i2] = NP * APL + hp * XST + c4 * 2;
         }
         // every channel of this workgroup's blocks exists and its 32 columns lie in the first source: no per-lane select
-        const bool all_ch = m0 + 128 <= a.M && n0 + XCH <= a.N && n0 + XCH <= a.src[0].nch;
+        const bool all_ch = m0 + 128 <= a.M && n0 + XCH <= a.N && n0 + XCH <= a.src[0].nch &&
+                            (long long)a.H * a.W * (a.a.pix_stride > a.src[0].pix_stride ? a.a.pix_stride : a.src[0].pix_stride) < (1ll << 28);   // 32-bit byte offsets
         constexpr int NIT = NAL + NXL;
         struct TileP { const float* ab; const float* xb[BMC_MAX_SRC]; int y0, x0; bool live, fast; };
         // Tiles are visited in order split, split + nsplit, ...: the (image, tile row, tile column) decode is advanced
