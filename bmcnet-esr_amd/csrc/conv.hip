@@ -52,16 +52,23 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
     constexpr int NXLD = (NHALO * 4 + 255) / 256;
     constexpr int NWLD = (BN * 4 + 255) / 256;
     constexpr int XBUF = NHALO * RS, WBUF = BN * RS;
-    __shared__ __attribute__((aligned(16))) float lds[2 * XBUF + 2 * WBUF + BMC_MAX_SRC * 8];
+    __shared__ __attribute__((aligned(16))) float lds[2 * XBUF + 2 * WBUF + BMC_MAX_SRC * 8 + BN];
     float* const Xb = lds;
     float* const Wb = lds + 2 * XBUF;
     SrcDev* const tab = reinterpret_cast<SrcDev*>(lds + 2 * XBUF + 2 * WBUF);   // source table (runtime-indexed)
+    // Accumulator start values: the bias when it is the same for every tile of the launch (one weight group, one
+    // channel tile -- the usual case), zeros otherwise.  A tile's accumulators are (re)initialised with 16 LDS reads
+    // straight into the accumulator registers: that replaces 64 v_mov + 64 bias adds + the bias loads of the epilogue,
+    // and VALU instructions issued beside the other workgroups' MFMAs cost 20-30 cycles each (in-kernel stamps).
+    float* const init_lds = lds + 2 * XBUF + 2 * WBUF + BMC_MAX_SRC * 8;
+    const bool bias_pre = a.bias != nullptr && a.batch_per_group >= a.B && a.ntn == 1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < BMC_MAX_SRC; ++i)
         if (tid == i) tab[i] = a.src[i];
+    if (tid < BN) init_lds[tid] = (bias_pre && tid < a.Cout) ? a.bias[tid] : 0.f;
     __syncthreads();
 #ifdef BMC_DIAG
     const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
@@ -210,15 +217,19 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
     for (int u = 0; u < NT; ++u) boff[u] = (cobase + 32 * u + li) * RS + 4 * lh;
 
     f32x16 acc[MT][NT];
-    auto zero_acc = [&]() {
+    auto init_acc = [&]() {     // see init_lds above
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+        for (int u = 0; u < NT; ++u)
 #pragma unroll
-            for (int u = 0; u < NT; ++u)
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(init_lds + cobase + 4 * lh + 32 * u + 8 * rq);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[t][u][4 * rq + k] = v[k];
+            }
     };
-    zero_acc();
+    init_acc();
 
     // Software pipeline (one barrier per step, MFMA work queued on both sides of it):
     //   top of step s : read fragments (s, k-half 1); write W(s+1) [and the next chunk's X on a chunk's last tap] to
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
                         if (ok[rq]) d[rq] = *reinterpret_cast<const f32x4*>(base + off + co0 + 32 * u + 8 * rq);
                     }
                 };
-                if (biasg) {
+                if (biasg && !bias_pre) {     // (otherwise the accumulators started from the bias)
                     f32x4 d[4];
                     fetch(biasg, 0, d, 0.f);
 #pragma unroll
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
                         *reinterpret_cast<f32x4*>(outb + pix[t] * a.out_pix_stride + co) = v;
                     }
                 }
-        zero_acc();
+        init_acc();
     };
 
     xl_setup();

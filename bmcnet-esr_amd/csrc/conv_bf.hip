@@ -75,10 +75,13 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
     constexpr int NDMA = NP * BN * 2 / 64;               // 1 KB wave-instructions per weight slice
     constexpr int XPL = NHALO * RD, WPL = BN * RD;       // dwords per plane
     constexpr int XBUF = NP * XPL, WBUF = NP * WPL, NSTG = 3;
-    __shared__ __attribute__((aligned(16))) u32 lds[2 * XBUF + NSTG * WBUF + BMC_MAX_SRC * 8];
+    __shared__ __attribute__((aligned(16))) u32 lds[2 * XBUF + NSTG * WBUF + BMC_MAX_SRC * 8 + BN];
     u32* const Xb = lds;
     u32* const Wb = lds + 2 * XBUF;
     SrcDev* const tab = reinterpret_cast<SrcDev*>(lds + 2 * XBUF + NSTG * WBUF);
+    // accumulator start values (bias when it is the same for every tile of the launch, else zeros): see conv.hip
+    float* const init_lds = reinterpret_cast<float*>(lds + 2 * XBUF + NSTG * WBUF + BMC_MAX_SRC * 8);
+    const bool bias_pre = a.bias != nullptr && a.batch_per_group >= a.B && a.ntn == 1;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,6 +90,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
 #pragma unroll
     for (int i = 0; i < BMC_MAX_SRC; ++i)
         if (tid == i) tab[i] = a.src[i];
+    if (tid < BN) init_lds[tid] = (bias_pre && tid < a.Cout) ? a.bias[tid] : 0.f;
     __syncthreads();
 
     // persistent workgroups with the XCD-aware tile walk of conv.hip
@@ -283,25 +287,20 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
 #pragma unroll
     for (int u = 0; u < NT; ++u) boff[u] = swz_w(cobase + 32 * u + li, lh);
 
-    // one weight group and one channel tile (the usual case): this lane's bias values never change -> registers, once
-    const bool bias_pre = a.bias != nullptr && a.batch_per_group >= a.B && a.ntn == 1;
-    f32x4 bias_r[NT * 4];
-#pragma unroll
-    for (int i = 0; i < NT * 4; ++i) {
-        const int co = cobase + 4 * lh + 32 * (i >> 2) + 8 * (i & 3);
-        bias_r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (bias_pre && co < a.Cout) bias_r[i] = *reinterpret_cast<const f32x4*>(a.bias + co);
-    }
     f32x16 acc[MT][NT];
-    auto zero_acc = [&]() {
+    auto init_acc = [&]() {     // 16 LDS reads straight into the accumulator registers (no v_mov, no bias adds later)
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+        for (int u = 0; u < NT; ++u)
 #pragma unroll
-            for (int u = 0; u < NT; ++u)
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(init_lds + cobase + 4 * lh + 32 * u + 8 * rq);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[t][u][4 * rq + k] = v[k];
+            }
     };
-    zero_acc();
+    init_acc();
 
     u32x4 xf[NP][MT], wf[NP][NT];
     auto read_frags = [&](const u32* xb, const u32* wb, int tapshift, int taprow) {
@@ -370,10 +369,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
                         if (ok[rq]) d[rq] = *reinterpret_cast<const f32x4*>(base + off + co0 + 32 * u + 8 * rq);
                     }
                 };
-                if (bias_pre) {
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) v[rq] += bias_r[u * 4 + rq];
-                } else if (biasg) {
+                if (biasg && !bias_pre) {     // (otherwise the accumulators started from the bias)
                     f32x4 d[4];
                     fetch(biasg, 0, d, 0.f);
 #pragma unroll
@@ -426,7 +422,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
                         *reinterpret_cast<f32x4*>(outb + pix[t] * a.out_pix_stride + co) = v;
                     }
                 }
-        zero_acc();
+        init_acc();
     };
 
     // ---- prologue: halo of chunk 0 in LDS, weight slices 0 and 1 in flight, slice 0 landed
