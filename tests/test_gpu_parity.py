@@ -653,14 +653,18 @@ def test_other_model_shapes_vs_oracle(cls_name, scale, n_c, n_b, H, W):
     assert n >= 15
 
 
-def test_conv_fuzz_random_shapes_vs_torch():
-    """40 random convolution problems (1x1 / 3x3, 1-5 sources of 16..64 channels, Cout 16..160, odd image sizes up to
+@pytest.mark.parametrize("math", ["fp32", "bf16x6"])
+def test_conv_fuzz_random_shapes_vs_torch(math):
+    """(both fp32-class arithmetic modes: the bf16-plane kernels have their own slow paths -- several sources per column
+    block, channel counts that are not multiples of the block, border tiles, the tap-split weight gradient)
+    40 random convolution problems (1x1 / 3x3, 1-5 sources of 16..64 channels, Cout 16..160, odd image sizes up to
     70x90, batch 1..5, bias / ReLU / residual on or off): forward, data, weight and bias gradients vs F.conv2d.
     Exercises every tile shape of the size-adaptive dispatcher (8x16x128, 4x16x128, 4x16x64, 8x16x32)."""
     dev = _gpu()
     import random
     from bmc_hip import ops
     from bmc_hip.ops import ConvSpec, View
+    ops.set_math(math)
     rnd = random.Random(1234)
     g = torch.Generator().manual_seed(99)
     for case in range(40):
