@@ -94,7 +94,8 @@ int bmc_pack_weight_t(const float* w, const int* kmap, int G, int Cout, int Cin,
                       int k0, int nk, int nkpad, int Coutpad16, float* out, bmc_stream_t s);
 /* Packed fp32 weights [nsteps][Coutpad][16] (nsteps = G * Kpad/16 * taps) -> `planes` bf16 planes
  * [nsteps][planes][Coutpad][16] for bmc_conv with math = BMC_MATH_BF16 (planes 1) / BMC_MATH_BF16X6 (planes 3);
- * `out` holds nsteps*planes*Coutpad*16 bf16 values (2 bytes each). */
+ * `out` holds nsteps*planes*Coutpad*16 bf16 values (2 bytes each); inside a 32-byte row the two 16-byte halves are
+ * swapped when (row & 16), the kernel's conflict-free LDS image (the weight stream is a linear LDS-DMA copy of it). */
 #define BMC_MATH_FP32 0
 #define BMC_MATH_BF16 1
 #define BMC_MATH_BF16X6 3
@@ -114,7 +115,7 @@ typedef struct bmc_conv_args {
     bmc_src_t src[BMC_MAX_SRC];
     const void* wpacked;        /* from bmc_pack_weight (math 0) or bmc_split_weight of it (math 1, 3) */
     const float* bias;          /* [G][Cout] or NULL */
-    long long w_group_stride;   /* floats between groups in wpacked */
+    long long w_group_stride;   /* 32-bit words between groups in wpacked (math 0: floats; math 1 / 3: floats * planes / 2) */
     int bias_group_stride;
     int batch_per_group;        /* >= 1 */
     float* out;
