@@ -285,8 +285,11 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
             pok[t] = y < a.H && x < a.W;
             pix[t] = y * a.W + x;
         }
+        // the usual case -- bias already in the accumulators, nothing to read back -- is one pass: ReLU on the way out
+        const bool simple = !resb && !maskb && !a.accumulate && (bias_pre || !biasg);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
+            if (simple) break;
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
                 f32x4 v[4];
@@ -354,6 +357,10 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
                         f32x4 v;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = acc[t][u][4 * rq + k];
+                        if (simple && a.relu) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                        }
                         *reinterpret_cast<f32x4*>(outb + pix[t] * a.out_pix_stride + co) = v;
                     }
                 }

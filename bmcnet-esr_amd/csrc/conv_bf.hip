@@ -350,8 +350,11 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
             pok[t] = y < a.H && x < a.W;
             pix[t] = y * a.W + x;
         }
+        // the usual case -- bias already in the accumulators, nothing to read back -- is one pass: ReLU on the way out
+        const bool simple = !resb && !maskb && !a.accumulate && (bias_pre || !biasg);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
+            if (simple) break;
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
                 f32x4 v[4];
@@ -419,6 +422,10 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
                         f32x4 v;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = acc[t][u][4 * rq + k];
+                        if (simple && a.relu) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                        }
                         *reinterpret_cast<f32x4*>(outb + pix[t] * a.out_pix_stride + co) = v;
                     }
                 }
