@@ -146,11 +146,30 @@ def main():
     ap.add_argument("--no-bf16x6", action="store_true", help="skip the additional bf16x6-mode measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (importing
+        # torch does not), and it never will: the N ranks are CHILD processes of torch.distributed.run, one per GPU,
+        # rank 0 prints the JSON line to the shared stdout, and this process exits with the launcher's code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the BMCNet HIP path has no CPU fallback")
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks requested but only %d GPUs visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or bool(os.environ.get("BMC_FORCE_DIST"))      # BMC_FORCE_DIST: exercise RCCL with 1 rank
@@ -158,6 +177,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus or os.environ.get("BMC_FORCE_DIST")
 
     from models.BMCNet import BMCNet
     from bmc_hip import ops
@@ -245,7 +265,7 @@ def main():
             roof["step_achieved_tflops_per_gpu"] = round(step_flops * args.steps / dt / 1e12, 2)
             roof["step_frac_of_peak"] = round(step_flops * args.steps / dt / 1e12 / KERNEL_PEAK[args.math], 4)
         out = {
-            "metric": "LR-voxel-frames/sec x4 SR train step, NFS 180x240",
+            "metric": "LR-voxel-frames/sec x4 SR train step, %s %dx%d" % ("NFS" if (H, W) == (180, 240) else "synthetic", H, W),
             "value": round(value, 3), "unit": "LR-voxel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x6": "f32 (3xbf16 split, 6 products)", "bf16": "bf16"}[args.math], "data": "synthetic",
@@ -254,7 +274,8 @@ def main():
                                    (n_c, n_b, H, W, scale * H, scale * W, B, L, windows, " + RCCL grad all-reduce" if use_dist else "",
                                     " [per-window recompute]" if args.recompute else "") + (" [HIP graph replay]" if args.graph else ""),
                        "global_batch": world * B, "frames_per_step": frames_per_step,
-                       "parallelism": "dp%d" % world, "peak_mem_GiB": round(peak_mem, 1),
+                       "parallelism": "dp%d" % world, "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                       "peak_mem_GiB": round(peak_mem, 1),
                        "final_loss": round(float(loss), 6)},
             "roofline": roof,
         }

@@ -6,7 +6,7 @@ reference including its out-of-range quirk and its in-place reset of the caller'
 are rejected: there is no CPU fallback."""
 import torch
 
-from bmc_hip import ops
+from . import ops
 
 
 def events_to_channels(xs, ys, ps, sensor_size=(180, 240)):

@@ -78,11 +78,13 @@ _sm_bwd = _sig("bmc_softmax_bwd", [_p, _p, _ll, _i, _f, _p, _p])
 _pack_in = _sig("bmc_pack_inputs", [_p, _ll, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _p, _p, _p])
 _unshuffle = _sig("bmc_unshuffle_to_nhwc", [_p, _i, _i, _i, _i, _i, _p, _p])
 _shuffle = _sig("bmc_shuffle_to_hr", [_p, _i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _ll, _p, _p])
+_bicubic_fwd = _sig("bmc_bicubic_resize_fwd", [_p, _ll, _i, _i, _i, _i, _p, _p])
+_bicubic_bwd = _sig("bmc_bicubic_resize_bwd", [_p, _ll, _i, _i, _i, _i, _p, _p])
 
 EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_events_to_voxel", "bmc_events_to_stack", "bmc_encode_raw_events", "bmc_pack_weight", "bmc_pack_weight_t", "bmc_split_weight", "bmc_conv",
            "bmc_pgemm", "bmc_pgemm_reduce_weight", "bmc_pgemm_reduce_plain", "bmc_colsum", "bmc_relu_bwd",
            "bmc_layernorm_fwd", "bmc_layernorm_bwd", "bmc_softmax_fwd", "bmc_softmax_bwd", "bmc_pack_inputs",
-           "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr"]
+           "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr", "bmc_bicubic_resize_fwd", "bmc_bicubic_resize_bwd"]
 
 
 def check(rc, what):

@@ -28,6 +28,11 @@ def _need_gpu(t: torch.Tensor):
         raise RuntimeError("bmc_hip: tensor is on %s -- the BMCNet MI355X path has no CPU fallback" % t.device)
     if t.dtype != torch.float32:
         raise RuntimeError("bmc_hip: fp32 tensors only (got %s)" % t.dtype)
+    if t.device.index != torch.cuda.current_device():
+        # launches go to the CURRENT device's current stream (_stream()): a tensor of another device would be
+        # touched from the wrong device / stream
+        raise RuntimeError("bmc_hip: tensor lives on %s but the current device is cuda:%d -- call torch.cuda.set_device "
+                           "(one process per GPU)" % (t.device, torch.cuda.current_device()))
 
 
 def round_up(v, m):
@@ -728,6 +733,36 @@ def pixel_unshuffle_nhwc(hr, r):
 
 def head(xo, base, r):
     return HeadFn.apply(xo, base, r)
+
+
+class BicubicResizeFn(torch.autograd.Function):
+    """F.interpolate(x, size=size, mode='bicubic', align_corners=False) on NCHW tensors (train.py:227-231)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        _need_gpu(x)
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        y = torch.empty((B, Cc, Ho, Wo), device=x.device, dtype=torch.float32)
+        lib.call(lib._bicubic_fwd, "bmc_bicubic_resize_fwd", x.data_ptr(), B * Cc, H, W, Ho, Wo, y.data_ptr(), _stream())
+        ctx.shape = (B, Cc, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, Cc, H, W = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty((B, Cc, H, W), device=gy.device, dtype=torch.float32)
+        lib.call(lib._bicubic_bwd, "bmc_bicubic_resize_bwd", gy.data_ptr(), B * Cc, H, W, gy.shape[2], gy.shape[3],
+                 gx.data_ptr(), _stream())
+        return gx, None, None
+
+
+def bicubic_resize(x, size):
+    """x [B,C,H,W] -> [B,C,size[0],size[1]]; identity (no launch) when the sizes already agree."""
+    if tuple(x.shape[-2:]) == (int(size[0]), int(size[1])):
+        return x
+    return BicubicResizeFn.apply(x, int(size[0]), int(size[1]))
 
 
 # --------------------------------------------------------------------------

@@ -43,6 +43,8 @@ class GradAllReducer:
                 off += p.numel()
         self.pending = [len(b) for b in self.buckets]
         self.works = [None] * len(self.buckets)
+        self.seen = set()            # parameters whose hook fired since the last finish()
+        self.deferred = False        # a second backward before step() was detected (gradient accumulation)
         self.cuda = dev.type == "cuda"
         self.side = torch.cuda.Stream(device=dev) if self.cuda else None
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -51,11 +53,28 @@ class GradAllReducer:
 
     # -- called by autograd once per parameter per backward, after all its uses have been accumulated
     def _on_grad(self, p):
+        if p in self.seen and not self.deferred:
+            # second backward() before optimizer.step(): p.grad now holds the ACCUMULATED local gradient and the
+            # buckets already in flight carry stale sums.  Let them land (so nothing is overwritten under a running
+            # all-reduce), then stop launching from hooks: finish() re-stages every gradient and reduces once.
+            self._join()
+            self.deferred = True
+        self.seen.add(p)
+        if self.deferred:
+            return
         bi, off = self.slot[p]
         self.flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
             self._launch(bi)
+
+    def _join(self):
+        for i, w in enumerate(self.works):
+            if w is not None:
+                w.wait()
+                self.works[i] = None
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def _launch(self, bi):
         if not dist.is_initialized():
@@ -71,19 +90,25 @@ class GradAllReducer:
         """Join outstanding all-reduces, average, and expose the result as .grad (views of the flat buckets).
         Every rank runs the same graph, so which parameters received a gradient is the same on every rank."""
         nb = len(self.buckets)
-        active = [self.pending[bi] != len(self.buckets[bi]) for bi in range(nb)]
+        active = [any(p in self.seen for p in self.buckets[bi]) for bi in range(nb)]
         for bi in range(nb):
-            if active[bi] and self.pending[bi] != 0:      # bucket holds parameters the loss did not reach
+            if not active[bi]:
+                continue
+            if self.deferred:                              # gradient accumulation: stage the accumulated gradients now
+                for p in self.buckets[bi]:
+                    o = self.slot[p][1]
+                    if p.grad is None:
+                        self.flat[bi][o:o + p.numel()].zero_()
+                    elif p.grad.data_ptr() != self.flat[bi][o:].data_ptr():
+                        self.flat[bi][o:o + p.numel()].copy_(p.grad.reshape(-1))
+                self._launch(bi)
+            elif self.pending[bi] != 0:                    # bucket holds parameters the loss did not reach
                 for p in self.buckets[bi]:
                     if p.grad is None:
                         o = self.slot[p][1]
                         self.flat[bi][o:o + p.numel()].zero_()
                 self._launch(bi)
-        for w in self.works:
-            if w is not None:
-                w.wait()
-        if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.side)
+        self._join()
         for bi in range(nb):
             if not active[bi]:
                 continue
@@ -95,6 +120,8 @@ class GradAllReducer:
                     p.grad = self.flat[bi][o:o + p.numel()].view_as(p)
         self.pending = [len(b) for b in self.buckets]
         self.works = [None] * nb
+        self.seen = set()
+        self.deferred = False
 
 
 def reduce_tensor(t: torch.Tensor, group=None) -> torch.Tensor:

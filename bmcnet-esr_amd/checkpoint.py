@@ -28,7 +28,15 @@ def save_checkpoint(path, model, optimizer=None, lr_scheduler=None, iteration=0,
     """Bare state_dict at `path` (reference format) + full training state at `path + '.train'`."""
     if rank != 0:
         return
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}      # alias keys kept (torch.save de-duplicates storage)
+    # alias keys kept; ONE host copy per device tensor, so that torch.save de-duplicates the aliases' storage as it does
+    # for the reference's CPU-resident state_dict (a per-key .cpu() would write every shared tensor once per alias)
+    host = {}
+    sd = {}
+    for k, v in model.state_dict().items():
+        key = (v.data_ptr(), tuple(v.shape), tuple(v.stride()))
+        if key not in host:
+            host[key] = v.detach().cpu()
+        sd[k] = host[key]
     _atomic_save(sd, path)
     if optimizer is None:
         return

@@ -24,6 +24,17 @@ def synthetic_events(B, seql, H, W, scale, n_lr, device, seed=3407):
     return out
 
 
+def shard_sequences(inp_cnt, gt_cnt, rank, world):
+    """Sequence-batch sharding: rank r of `world` owns sequences [r*B/world, (r+1)*B/world) of the global
+    batch -- what DistributedSampler does for the reference's loader (dataloader/h5dataloader.py:191-201); every rank
+    then runs the full BPTT on its own sequences and GradAllReducer averages the gradients."""
+    B = inp_cnt.shape[0]
+    if B % world:
+        raise ValueError("global batch %d is not divisible by %d ranks" % (B, world))
+    n = B // world
+    return inp_cnt[rank * n:(rank + 1) * n], gt_cnt[rank * n:(rank + 1) * n]
+
+
 def encode_sequence(ev, B, seql, H, W, scale):
     """events -> inp_cnt [B,seql,2,H,W], gt_cnt [B,seql,2,sH,sW] on the GPU (two batched scatter launches);
     what the reference's DataLoader workers do per frame with events_to_channels (dataloader/h5dataset.py:518-526)."""
@@ -65,7 +76,9 @@ def bptt_step(model, optimizer, inp_cnt, gt_cnt, n_c, scale, seqn=2, plain=False
             h, hp, hn, pred = checkpoint(model, x, h, hp, hn, pred, False, use_reentrant=False)
         else:
             h, hp, hn, pred = model(x, h, hp, hn, pred, False)
-        mse = loss_fn(pred, gt)
+        # size-mismatch branch of train.py:227-231 (EventZoom: 124x224 prediction vs 124x222 ground truth); the
+        # UNRESIZED prediction is what recurs into the next window (train.py:224)
+        mse = loss_fn(ops.bicubic_resize(pred, gt.shape[-2:]), gt)
         loss = loss + mse
     loss.backward()
     optimizer.step()

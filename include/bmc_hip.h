@@ -200,6 +200,15 @@ int bmc_unshuffle_to_nhwc(const float* hr, int B, int C, int H, int W, int r, fl
 int bmc_shuffle_to_hr(const float* lr, int B, int C, int H, int W, int r, const float* base,
                       long long sb, long long sc, long long sy, long long sx, float* hr, bmc_stream_t s);
 
+/* ---- loss-side resize ------------------------------------------------------
+ * F.interpolate(prediction, size=gt.size()[-2:], mode='bicubic', align_corners=False): train.py:227-231,
+ * infer_BMCNet.py:77-78 (taken when scale * round(sensor / scale) != sensor, dataloader/h5dataset.py:88-100; EventZoom:
+ * 124x224 -> 124x222).  x: `planes` contiguous [H][W] planes (NCHW with planes = B*C) -> y [planes][Ho][Wo].
+ * ATen semantics (A = -0.75, source coordinate fma(in/out, dst + 0.5, -0.5), clamped tap indices).  bwd is the transposed
+ * operator as a gather: gx[planes][H][W] is OVERWRITTEN, deterministic. */
+int bmc_bicubic_resize_fwd(const float* x, long long planes, int H, int W, int Ho, int Wo, float* y, bmc_stream_t s);
+int bmc_bicubic_resize_bwd(const float* gy, long long planes, int H, int W, int Ho, int Wo, float* gx, bmc_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,6 +141,73 @@ def events_to_stack_no_polarity_np(xs, ys, ts, ps, B, sensor_size=(180, 240)):
     return out, xs, ys, ps
 
 
+def events_to_stack_polarity_np(xs, ys, ts, ps, B, sensor_size=(180, 240)):
+    """Event stack with polarity split, numpy restatement of dataloader/encodings.py:151-199: per temporal bin (same
+    float32 bounds and quirky search as events_to_stack_no_polarity) two count images, [2,B,H,W] = (positives, negatives),
+    each events_to_image_torch(xs[beg:end], ys[beg:end], ps[beg:end] * mask, clip_out_of_range=False): no vertical flip,
+    weights p*p.  The coordinate VIEWS are reset in place by the first (positive) call of the first bin that covers an
+    event; its weights are a temporary, so the caller's ps stays intact -- every later call sees the event in range
+    at (0, 0): an out-of-range NEGATIVE event counts at [0, 0] of the negative image, and an event that a later,
+    overlapping bin covers again counts there whatever its sign.  Early return (<= 3 events or all-zero timestamps) is
+    [B,H,W] zeros, as in the reference (:165-166).  Returns (stack, xs_after, ys_after)."""
+    H, W = int(sensor_size[0]), int(sensor_size[1])
+    xs = np.array(xs, dtype=np.float32, copy=True)
+    ys = np.array(ys, dtype=np.float32, copy=True)
+    ps = np.asarray(ps, dtype=np.float32)
+    ts = np.asarray(ts, dtype=np.float32)
+    n = len(ts)
+    if n <= 3 or np.float32(ts.sum(dtype=np.float32)) == 0:
+        return np.zeros((B, H, W), dtype=np.float32), xs, ys
+    out = np.zeros((2, B, H, W), dtype=np.float32)
+    dt = np.float32(np.float32(ts[-1] - ts[0]) + np.float32(1e-6))
+    delta_t = np.float32(dt / np.float32(B))
+    for bi in range(B):
+        tstart = np.float32(ts[0] + np.float32(delta_t * np.float32(bi)))
+        tend = np.float32(tstart + delta_t)
+        beg = binary_search_f32(ts, 0, n - 1, tstart)
+        end = binary_search_f32(ts, 0, n - 1, tend, side="right") + 1
+        sl = slice(beg, end)
+        x, y, p = xs[sl], ys[sl], ps[sl]
+        for ch in range(2):
+            wgt = (p * (np.where(p < 0, 0, p) if ch == 0 else np.where(p > 0, 0, p))).astype(np.float32)
+            oob = (x >= W) | (x < 0) | (y >= H) | (y < 0)
+            x[oob] = 0
+            y[oob] = 0
+            wgt[oob] = 0
+            np.add.at(out[ch, bi], (y.astype(np.int64), x.astype(np.int64)), wgt)
+    return out, xs, ys
+
+
+def events_to_mask_np(xs, ys, ps, sensor_size=(180, 240)):
+    """Binary event mask, numpy restatement of dataloader/encodings.py:308-332: out-of-range events get
+    xs = ys = ps = 0 IN PLACE (all three belong to the caller), then mask[(long) y, (long) x] = |p| with
+    index_put_(accumulate=False): no vertical flip, and for duplicate pixels the LAST event in order wins (the
+    sequential semantics of index_put_; a zeroed out-of-range event can therefore clear [0, 0]).
+    Returns (mask[H,W], xs_after, ys_after, ps_after)."""
+    H, W = int(sensor_size[0]), int(sensor_size[1])
+    xs = np.array(xs, dtype=np.float32, copy=True)
+    ys = np.array(ys, dtype=np.float32, copy=True)
+    ps = np.array(ps, dtype=np.float32, copy=True)
+    oob = (xs >= W) | (xs < 0) | (ys >= H) | (ys < 0)
+    xs[oob] = 0
+    ys[oob] = 0
+    ps[oob] = 0
+    mask = np.zeros((H, W), dtype=np.float32)
+    xi, yi = xs.astype(np.int64), ys.astype(np.int64)
+    for e in range(len(xs)):
+        mask[yi[e], xi[e]] = abs(ps[e])
+    return mask, xs, ys, ps
+
+
+def collate_windows(frames_inp, frames_gt, seqn=2):
+    """The batch layout the trainer iterates over -- HDF5DataLoaderSequence.custom_collate + concat_dict
+    (dataloader/h5dataloader.py:213-250): per time step the items of the batch are stacked on a new dim 0, then every
+    run of `seqn` consecutive time steps is stacked on dim 1.  frames_* [B,L,2,H,W] -> list of L-seqn+1 dicts
+    {'inp_cnt': [B,seqn,2,H,W], 'gt_cnt': [B,seqn,2,sH,sW]}."""
+    L = frames_inp.shape[1]
+    return [{"inp_cnt": frames_inp[:, i:i + seqn], "gt_cnt": frames_gt[:, i:i + seqn]} for i in range(L - seqn + 1)]
+
+
 def encode_raw_frame_np(xs_i16, ys_i16, ps_f64, flags, sensor_size):
     """One dataset item's count image from raw HDF5 columns: get_events (dataloader/h5dataset.py:407-414, the
     int16/float64 columns are concatenated into ONE float64 array), augment_event (:559-578, flips in float64),
@@ -250,6 +317,35 @@ def bilinear_up(x: torch.Tensor, r: int) -> torch.Tensor:
     x0, x1, lx = axis(w)
     rows = x[:, :, y0, :] * (1 - ly).view(1, 1, -1, 1) + x[:, :, y1, :] * ly.view(1, 1, -1, 1)
     return rows[:, :, :, x0] * (1 - lx).view(1, 1, 1, -1) + rows[:, :, :, x1] * lx.view(1, 1, 1, -1)
+
+
+def bicubic_resize(x: torch.Tensor, size) -> torch.Tensor:
+    """F.interpolate(x, size=size, mode='bicubic', align_corners=False) written out -- the size-mismatch branch of the
+    training loop (train.py:227-231) and of inference (infer_BMCNet.py:77-78).  ATen semantics: per axis
+    scale = in/out, src = fma(scale, dst + 0.5, -0.5) (NOT clamped; in x's dtype, one rounding), i0 = floor(src), t = src - i0, four taps
+    i0-1 .. i0+2 with the cubic-convolution weights for A = -0.75, tap indices clamped to [0, in-1].  Differentiable
+    (index_select + weighted sums), so autograd provides the transposed operator."""
+    A = -0.75
+
+    def axis(n_in, n_out):      # index arithmetic in the tensor's own precision, as ATen does (opmath_t)
+        dst = torch.arange(n_out, dtype=x.dtype)
+        scale = torch.tensor(float(n_in), dtype=x.dtype) / n_out
+        # one rounding, as the fused multiply-add of ATen's float kernels gives: fl(scale * (dst + 0.5) - 0.5)
+        src = (scale.double() * (dst.double() + 0.5) - 0.5).to(x.dtype)
+        i0 = torch.floor(src)
+        t = src - i0
+        c1 = lambda v: ((A + 2) * v - (A + 3)) * v * v + 1            # |v| <= 1
+        c2 = lambda v: ((A * v - 5 * A) * v + 8 * A) * v - 4 * A      # 1 < |v| < 2
+        w = torch.stack([c2(t + 1), c1(t), c1(1 - t), c2(2 - t)], 0)                 # [4, n_out]
+        idx = torch.stack([torch.clamp(i0.to(torch.int64) - 1 + k, 0, n_in - 1) for k in range(4)], 0)
+        return idx, w
+
+    H, W = x.shape[-2:]
+    Ho, Wo = int(size[0]), int(size[1])
+    iy, wy = axis(H, Ho)
+    ix, wx = axis(W, Wo)
+    rows = sum(x[..., iy[k], :] * wy[k].view(-1, 1) for k in range(4))               # [..., Ho, W]
+    return sum(rows[..., ix[k]] * wx[k] for k in range(4))                           # [..., Ho, Wo]
 
 
 # --------------------------------------------------------------------------
@@ -362,7 +458,10 @@ def bptt_loss(p: Params, inp_windows: Sequence[torch.Tensor], gt_windows: Sequen
         else:
             h, hp, hn, pred = bmcnet_forward(p, x, h, hp, hn, pred, i == 0, scale)
         preds.append(pred)
-        loss = loss + F.mse_loss(pred, gt)
+        sp = pred                                      # the UNRESIZED prediction is what recurs (train.py:224)
+        if pred.shape[-2:] != gt.shape[-2:]:          # train.py:227-231
+            sp = bicubic_resize(pred, gt.shape[-2:])
+        loss = loss + F.mse_loss(sp, gt)
     return loss, preds, (h, hp, hn)
 
 
@@ -392,3 +491,31 @@ def unique_params(p: Params):
     for k, v in p.items():
         seen.setdefault(v.data_ptr(), []).append(k)
     return {ks[0]: ks for ks in seen.values()}
+
+
+def canonical_key(k: str) -> str:
+    """The name named_parameters() reports for the tensor behind state-dict key k: the reference registers one module
+    object under several names (models/BMCNet.py:7,9,41,43,46; models/BMCNet_plain.py:9,13; models/submodules.py:45,49)
+    and every alias shows up as a key of its own."""
+    import re
+    k = re.sub(r"para_reschunk\.\d+\.", "para_reschunk.0.", k)
+    for a, b in (("neuro.conv_fnst.", "neuro.conv_fpst."), ("neuro.conv_fns.", "neuro.conv_fps."),
+                 ("neuro.conv_f2.", "neuro.conv_f1.")):
+        if k.startswith(a):
+            k = b + k[len(a):]
+    parts = k.split(".")
+    # module-level aliases: <blk>.conv2 == <blk>.conv1 (a ResidualBlock_noBN, i.e. followed by its own conv1/conv2),
+    # <blk>.conv2_st == <blk>.conv1_st, <bie>.convf2 == <bie>.convf1
+    for i, q in enumerate(parts):
+        if q == "convf2":
+            parts[i] = "convf1"
+        elif q == "conv2_st":
+            parts[i] = "conv1_st"
+        elif q == "conv2" and i + 1 < len(parts) and parts[i + 1] in ("conv1", "conv2"):
+            parts[i] = "conv1"
+    return ".".join(parts)
+
+
+def expand_aliases(unique: Params, keys) -> Params:
+    """{named_parameters() name: tensor} -> full state-dict mapping over `keys` with the reference's aliasing."""
+    return {k: unique[canonical_key(k)] for k in keys}

@@ -92,7 +92,7 @@ def test_no_cpu_fallback():
     m = BMCNet_plain(4, 16, 1)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 2, 2, 4, 4), torch.zeros(1, 16, 4, 4), torch.zeros(1, 32, 4, 4), True)
-    from dataloader.encodings import events_to_channels
+    from bmc_hip.encodings import events_to_channels
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         events_to_channels(torch.zeros(3), torch.zeros(3), torch.ones(3), (4, 4))
 

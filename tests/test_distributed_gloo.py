@@ -95,3 +95,115 @@ def test_single_process_reducer_is_transparent():
     g0 = net.a.grad.clone()
     opt.step()
     assert torch.equal(net.a.grad, g0) and net.unused.grad is None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The real training step, sharded: models.BMCNet's own parameter containers (real names, real aliasing), the real
+# train_step.bptt_step + shard_sequences + GradAllReducer; only the arithmetic of a window comes from the CPU oracle
+# (there is no CPU path in the product, and no GPU here).
+class OracleBackedBMCNet(torch.nn.Module):
+    def __init__(self, scale, n_c, n_b):
+        super().__init__()
+        sys.path[:0] = [ROOT, os.path.join(ROOT, "bmcnet-esr_amd")]
+        from models.BMCNet import BMCNet
+        self.net = BMCNet(scale, n_c, n_b)           # parameters only; its forward needs the MI355X
+        self.scale = scale
+
+    def forward(self, x, h, hp, hn, o, init):
+        from oracle import bmc_oracle as O
+        params = {k: v for k, v in self.net.state_dict(keep_vars=True).items()}
+        return O.bmcnet_forward(params, x, h, hp, hn, o, init, self.scale)
+
+
+def _bmc_worker(rank, world, port, q, accumulate):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "bmcnet-esr_amd")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bmc_hip.parallel import GradAllReducer
+    from train_step import bptt_step, shard_sequences
+    scale, n_c, n_b, B, L, H, W = 4, 16, 1, 4, 3, 6, 8
+    torch.manual_seed(3)
+    net = OracleBackedBMCNet(scale, n_c, n_b)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, amsgrad=True)
+    GradAllReducer(net, opt, bucket_mb=0.02)
+    g = torch.Generator().manual_seed(4)
+    inp = torch.poisson(torch.full((B, L, 2, H, W), 0.4), generator=g)
+    gt = torch.poisson(torch.full((B, L, 2, scale * H, scale * W), 0.4), generator=g)
+    si, sg = shard_sequences(inp, gt, rank, world)
+    if accumulate:      # two backward() calls before one step(): the reducer must reduce the ACCUMULATED gradient once
+        opt.zero_grad()
+        from oracle import bmc_oracle as O
+        for half in (slice(0, 1), slice(1, 2)):
+            z = lambda c: torch.zeros(1, c, H, W)
+            h, hp, hn, pred = net(si[half, 0:2].transpose(1, 2), z(n_c), z(n_c), z(n_c), z(2 * scale * scale), True)
+            torch.nn.functional.mse_loss(pred, sg[half, 1]).backward()
+        opt.step()
+    else:
+        for _ in range(2):
+            bptt_step(net, opt, si, sg, n_c, scale)
+    q.put((rank, [p.detach().numpy().copy() for p in net.parameters()]))
+    dist.destroy_process_group()
+
+
+def _run_bmc(accumulate):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bmc_worker, args=(r, 2, port, q, accumulate)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_rank_sharded_bmcnet_bptt_matches_full_batch():
+    res = _run_bmc(False)
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "bmcnet-esr_amd")]
+    from train_step import bptt_step
+    scale, n_c, n_b, B, L, H, W = 4, 16, 1, 4, 3, 6, 8
+    torch.manual_seed(3)
+    net = OracleBackedBMCNet(scale, n_c, n_b)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, amsgrad=True)
+    g = torch.Generator().manual_seed(4)
+    inp = torch.poisson(torch.full((B, L, 2, H, W), 0.4), generator=g)
+    gt = torch.poisson(torch.full((B, L, 2, scale * H, scale * W), 0.4), generator=g)
+    for _ in range(2):
+        bptt_step(net, opt, inp, gt, n_c, scale)          # full batch, one process
+    ref = [p.detach().numpy() for p in net.parameters()]
+    assert len(ref) == 54
+    for r in range(2):
+        for a, b in zip(res[r][1], ref):
+            assert np.allclose(a, b, rtol=2e-4, atol=2e-6)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b)                       # ranks in lock-step, bit for bit
+
+
+def test_two_rank_gradient_accumulation_is_reduced_once():
+    """Two backward() calls before step(): hooks fire twice per parameter; the reducer must fall back to one
+    reduction of the accumulated gradients at step time instead of racing / double-launching."""
+    res = _run_bmc(True)
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "bmcnet-esr_amd")]
+    scale, n_c, n_b, B, L, H, W = 4, 16, 1, 4, 3, 6, 8
+    torch.manual_seed(3)
+    net = OracleBackedBMCNet(scale, n_c, n_b)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, amsgrad=True)
+    g = torch.Generator().manual_seed(4)
+    inp = torch.poisson(torch.full((B, L, 2, H, W), 0.4), generator=g)
+    gt = torch.poisson(torch.full((B, L, 2, scale * H, scale * W), 0.4), generator=g)
+    opt.zero_grad()
+    z = lambda c: torch.zeros(1, c, H, W)
+    total = 0
+    for b in range(4):       # gradient of the mean over ranks of (sum over each rank's two single-sequence losses)
+        h, hp, hn, pred = net(inp[b:b + 1, 0:2].transpose(1, 2), z(n_c), z(n_c), z(n_c), z(2 * scale * scale), True)
+        total = total + torch.nn.functional.mse_loss(pred, gt[b:b + 1, 1])
+    (total / 2).backward()
+    opt.step()
+    ref = [p.detach().numpy() for p in net.parameters()]
+    for r in range(2):
+        for a, b in zip(res[r][1], ref):
+            assert np.allclose(a, b, rtol=2e-4, atol=2e-6)

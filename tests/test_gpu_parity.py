@@ -47,7 +47,7 @@ def rel_l2(a, b):
 @pytest.mark.parametrize("tag", ["tiny", "nfs_lr", "oob_float", "empty", "hot", "c2_lr"])
 def test_events_bit_exact(tag):
     dev = _gpu()
-    from dataloader.encodings import events_to_channels
+    from bmc_hip.encodings import events_to_channels
     z = load("events.npz")
     xs, ys, ps = (torch.tensor(z[f"{tag}/{k}"], device=dev) for k in ("xs", "ys", "ps"))
     H, W = (int(v) for v in z[f"{tag}/size"])
@@ -60,7 +60,7 @@ def test_events_bit_exact(tag):
 def test_events_batched_vs_oracle_full_size():
     """C2-size frames (LR 24 576 events, HR 393 216 events) in one batched launch vs the numpy oracle."""
     dev = _gpu()
-    from dataloader.encodings import events_to_channels_batch
+    from bmc_hip.encodings import events_to_channels_batch
     from oracle.bmc_oracle import events_to_channels_np
     rng = np.random.default_rng(0)
     H, W = 720, 960
@@ -397,7 +397,7 @@ def test_raw_column_sequence_encoder_bit_exact():
     """bmc_encode_raw_events (int16/int16/float64 columns + flip flags, all frames in one launch) vs the reference's
     CPU chain get_events -> augment_event -> event_formatting -> events_to_channels (golden) -- bit-exact."""
     dev = _gpu()
-    from dataloader.encodings import augment_flags, raw_events_to_channels_batch
+    from bmc_hip.encodings import augment_flags, raw_events_to_channels_batch
     z = load("events_raw.npz")
     n = int(z["n"])
     by_size = {}
@@ -713,7 +713,7 @@ def test_events_to_voxel_golden(tag):
     """GPU voxel encoder vs the reference's output.  Float weights + atomics: equal up to summation order
     (abs 1e-5 on values of O(1..10)); the in-place reset of out-of-range coordinates is exact."""
     dev = _gpu()
-    from dataloader.encodings import events_to_voxel
+    from bmc_hip.encodings import events_to_voxel
     z = load("voxel.npz")
     H, W, bins = (int(v) for v in z[f"{tag}/meta"])
     xs, ys, ts, ps = (torch.tensor(z[f"{tag}/{k}"], device=dev) for k in ("xs", "ys", "ts", "ps"))
@@ -803,7 +803,7 @@ def test_events_to_stack_golden(tag):
     """GPU event stack vs the reference's output: bit-exact (+-1 polarities: integer-valued sums), including the
     caller-visible zeroing of out-of-range events."""
     dev = _gpu()
-    from dataloader.encodings import events_to_stack_no_polarity
+    from bmc_hip.encodings import events_to_stack_no_polarity
     z = load("stack.npz")
     H, W, bins = (int(v) for v in z[f"{tag}/meta"])
     xs, ys, ts, ps = (torch.tensor(z[f"{tag}/{k}"], device=dev) for k in ("xs", "ys", "ts", "ps"))
@@ -817,7 +817,7 @@ def test_events_to_stack_golden(tag):
 def test_events_to_stack_full_size_vs_oracle():
     """A C2-sized HR window (393 216 events, 720x960, 5 bins) against the numpy oracle: bit-exact."""
     dev = _gpu()
-    from dataloader.encodings import events_to_stack_no_polarity
+    from bmc_hip.encodings import events_to_stack_no_polarity
     from oracle import bmc_oracle as O
     rng = np.random.default_rng(3)
     n, H, W, bins = 393216, 720, 960, 5

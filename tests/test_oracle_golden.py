@@ -190,7 +190,7 @@ def test_raw_column_encoder_and_augmentation_flags():
 
 
 def test_product_augment_flags_match_reference_seeding():
-    from dataloader.encodings import augment_flags
+    from bmc_hip.encodings import augment_flags
     z = load("events_raw.npz")
     for i in range(int(z["n"])):
         assert augment_flags(int(z[f"c{i}/seed"])) == int(z[f"c{i}/flags"])
