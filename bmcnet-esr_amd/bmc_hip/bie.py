@@ -10,13 +10,99 @@ out_2 + Res(x_1)) are batch-rotated operand reads -- no roll / cat copies.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+import weakref
+
 import torch
 
-from . import lib
-from .ops import (CK, ConvSpec, _dense_spec, _need_gpu, _packed_weight, _packed_weight_t, _src, _stream, conv_raw,
-                  coutpad, pgemm_raw, round_up)
+from . import lib, ops
+from .ops import (CK, ConvSpec, _dense_spec, _need_gpu, _null_src, _packed_weight, _packed_weight_t, _src, _stream,
+                  conv_raw, coutpad, pgemm_raw, round_up)
 
 _SPEC2 = {}
+
+# Fused centre chain (csrc/chain.hip): convf -> LayerNorm2d -> clustering in one launch per direction.  fp32 MFMA only
+# (the bf16-plane modes keep the unfused launches); BMC_FUSE_CHAIN=0 switches it off (A/B measurements, cross-checks).
+FUSE_CHAIN = os.environ.get("BMC_FUSE_CHAIN", "1") != "0"
+_CHAIN_CACHE = {}
+
+
+def chain_supported(Cn):
+    return FUSE_CHAIN and ops.MATH == 0 and Cn in (32, 64, 128)
+
+
+def _chain_streams(wf, wc, Cn):
+    """Weight streams of bmc_chain_fwd / bmc_chain_bwd for (convf.weight, clustering.weight), cached per parameter
+    version: the forward stream is pack(W_f) | pack(W_c); the backward stream is T(W_c) T1(W_f) T0(W_f) T(W_c) T0(W_f)
+    T1(W_f) (include/bmc_hip.h)."""
+    key = (id(wf), id(wc))
+    hit = _CHAIN_CACHE.get(key)
+    if hit is not None and hit[0]() is wf and hit[1]() is wc and hit[2] == (wf._version, wc._version):
+        return hit[3], hit[4]
+    dev = wf.device
+    s1, s2 = _dense_spec(Cn), _spec2(Cn)
+    st = _stream()
+
+    def pack(w, spec, cin):
+        out = torch.empty(spec.kpad * Cn, device=dev, dtype=torch.float32)
+        lib.call(lib._pack_w, "bmc_pack_weight", w.data_ptr(), spec.kmap(dev).data_ptr(), 1, Cn, cin, 1, spec.kpad, Cn,
+                 out.data_ptr(), st)
+        return out
+
+    def pack_t(w, spec, cin, src_index):
+        out = torch.empty(Cn * Cn, device=dev, dtype=torch.float32)
+        lib.call(lib._pack_wt, "bmc_pack_weight_t", w.data_ptr(), spec.kmap(dev).data_ptr(), 1, Cn, cin, 1,
+                 src_index * Cn, Cn, Cn, Cn, out.data_ptr(), st)
+        return out
+
+    wfd, wcd = wf.detach().contiguous(), wc.detach().contiguous()
+    fwd = torch.cat([pack(wfd, s2, 2 * Cn), pack(wcd, s1, Cn)])
+    tc, t0, t1 = pack_t(wcd, s1, Cn, 0), pack_t(wfd, s2, 2 * Cn, 0), pack_t(wfd, s2, 2 * Cn, 1)
+    bwd = torch.cat([tc, t1, t0, tc, t0, t1])
+    if len(_CHAIN_CACHE) > 64:
+        for k in [k for k, v in _CHAIN_CACHE.items() if v[0]() is None or v[1]() is None]:
+            del _CHAIN_CACHE[k]
+    _CHAIN_CACHE[key] = (weakref.ref(wf), weakref.ref(wc), (wf._version, wc._version), fwd, bwd)
+    return fwd, bwd
+
+
+def chain_fwd(s0, s1, wf, bf, gamma, beta, wc, bc, eps, B, H, W, Cn, dev):
+    """-> (yhat [B,H,W,C], rstd [B*H*W], centre [B,H,W,C]); s0 / s1: lib.Src of C channels each."""
+    fwd, _ = _chain_streams(wf, wc, Cn)
+    yhat = torch.empty((B, H, W, Cn), device=dev, dtype=torch.float32)
+    centre = torch.empty((B, H, W, Cn), device=dev, dtype=torch.float32)
+    rstd = torch.empty(B * H * W, device=dev, dtype=torch.float32)
+    a = lib.ChainFwdArgs()
+    a.s0, a.s1 = s0, s1
+    a.wstream = fwd.data_ptr()
+    a.bias_f, a.bias_c, a.gamma, a.beta = bf.data_ptr(), bc.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    a.eps = eps
+    a.yhat, a.rstd, a.centre = yhat.data_ptr(), rstd.data_ptr(), centre.data_ptr()
+    a.B, a.C, a.H, a.W = B, Cn, H, W
+    e0 = ops._prof_begin()
+    lib.call(lib._chain_fwd, "bmc_chain_fwd", C.byref(a), _stream())
+    ops._prof_end(e0, "chain_kernel<fwd>", 2.0 * B * H * W * Cn * 3 * Cn)
+    return yhat, rstd, centre
+
+
+def chain_bwd(dc, yhat, rstd, gamma, wf, wc, add, n, H, W, Cn, dev):
+    """-> (dz [2n,H,W,C], ds1 [2n,H,W,C], ds0 [n,H,W,C]); dc: lib.Src over 2n launch batches, add: lib.Src or None."""
+    _, bwd = _chain_streams(wf, wc, Cn)
+    dz = torch.empty((2 * n, H, W, Cn), device=dev, dtype=torch.float32)
+    ds1 = torch.empty((2 * n, H, W, Cn), device=dev, dtype=torch.float32)
+    ds0 = torch.empty((n, H, W, Cn), device=dev, dtype=torch.float32)
+    a = lib.ChainBwdArgs()
+    a.dcentre = dc
+    a.wstream = bwd.data_ptr()
+    a.gamma, a.yhat, a.rstd = gamma.data_ptr(), yhat.data_ptr(), rstd.data_ptr()
+    a.dz, a.ds1, a.ds0 = dz.data_ptr(), ds1.data_ptr(), ds0.data_ptr()
+    a.ds0_add = add if add is not None else _null_src()
+    a.n, a.C, a.H, a.W = n, Cn, H, W
+    e0 = ops._prof_begin()
+    lib.call(lib._chain_bwd, "bmc_chain_bwd", C.byref(a), _stream())
+    ops._prof_end(e0, "chain_kernel<bwd>", 2.0 * 2 * n * H * W * Cn * 3 * Cn)
+    return dz, ds1, ds0
 
 
 def _spec2(c):
@@ -49,16 +135,14 @@ def _dgrad(g_src, w4, spec, src_index, owner, out, B, residual=None, mask=None, 
              flops=2.0 * B * H * W * spec.real_nch[src_index] * taps * Cout)
 
 
-def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, G=1):
-    """-> (dW flat [G*Cout*Cin*taps], db [G,Cout]): weight gradient + bias gradient (column sums of the same A operand,
-    taken from the tiles the pixel-reduction GEMM stages anyway)."""
+def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, w_param, b_param, G=1, w_shape=None):
+    """Weight gradient + bias gradient (column sums of the same A operand, taken from the tiles the pixel-reduction
+    GEMM stages anyway) -> (dW, db) for autograd; None where the sums went straight into the leaf parameters' .grad
+    (ops.reduce_wgrad).  G > 1 (stacked per-group weights): w_param None, result [G, ...]."""
     slabs, nsplit, _, bsl = pgemm_raw(a_src, x_srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
                                       flops=2.0 * B * H * W * Cout * taps * spec.cin, want_bias=True)
-    dw = torch.empty(G * Cout * spec.cin * taps, device=dev, dtype=torch.float32)
-    db = torch.empty((G, Cout), device=dev, dtype=torch.float32)
-    lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, G, taps, Cout, spec.kpad,
-             spec.kmap(dev).data_ptr(), spec.cin, dw.data_ptr(), 0, bsl.data_ptr(), db.data_ptr(), _stream())
-    return dw, db
+    return ops.reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bsl, w_param, b_param,
+                            w_shape if w_shape is not None else w_param.shape)
 
 
 class BIETwinFn(torch.autograd.Function):
@@ -82,12 +166,18 @@ class BIETwinFn(torch.autograd.Function):
         _conv([X(x12)], d(rw1).reshape(1, Cn, Cn, 9), s1, rw1, d(rb1), t12, B2, relu=True)
         _conv([X(t12)], d(rw2).reshape(1, Cn, Cn, 9), s1, rw2, d(rb2), r12, B2, residual=X(x12))
         # centres: clustering(LN(convf(cat[xs, other half])))
-        z12, y12, c12 = new(B2), new(B2), new(B2)
-        _conv([X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], d(wf).reshape(1, Cn, 2 * Cn, 1), s2, wf, d(bf), z12, B2)
-        stats = torch.empty(B2 * H * W * 2, device=dev, dtype=torch.float32)
-        lib.call(lib._ln_fwd, "bmc_layernorm_fwd", z12.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B2 * H * W, Cn, eps,
-                 y12.data_ptr(), stats.data_ptr(), _stream())
-        _conv([X(y12)], d(wc).reshape(1, Cn, Cn, 1), s1, wc, d(bc), c12, B2)
+        fused = chain_supported(Cn)
+        if fused:       # one launch; saved for backward: yhat (normalised, before the affine) and rstd
+            z12, stats, c12 = chain_fwd(X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2), wf, d(bf), d(gamma), d(beta), wc, d(bc),
+                                        eps, B2, H, W, Cn, dev)
+            y12 = z12
+        else:
+            z12, y12, c12 = new(B2), new(B2), new(B2)
+            _conv([X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], d(wf).reshape(1, Cn, 2 * Cn, 1), s2, wf, d(bf), z12, B2)
+            stats = torch.empty(B2 * H * W * 2, device=dev, dtype=torch.float32)
+            lib.call(lib._ln_fwd, "bmc_layernorm_fwd", z12.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B2 * H * W, Cn, eps,
+                     y12.data_ptr(), stats.data_ptr(), _stream())
+            _conv([X(y12)], d(wc).reshape(1, Cn, Cn, 1), s1, wc, d(bc), c12, B2)
         # values: v1 on the first half, v2 on the second (two weight groups)
         v12 = new(B2)
         wv = torch.stack([d(wv1).reshape(Cn, Cn, 1), d(wv2).reshape(Cn, Cn, 1)])
@@ -104,15 +194,18 @@ class BIETwinFn(torch.autograd.Function):
         # shared stream: unclustering(cat[c1, c2]) + xs
         xs_new = new(n)
         _conv([X(c12, b0=0, B=n), X(c12, b0=n, B=n)], d(wu).reshape(1, Cn, 2 * Cn, 1), s2, wu, d(bu), xs_new, n, residual=X(xs))
-        ctx.save_for_backward(x12, xs, t12, z12, stats, y12, c12, v12, p, rw1, rw2, wf, gamma, wc, wu, wv1, wv2)
+        ctx.save_for_backward(x12, xs, t12, z12, stats, y12, c12, v12, p, rw1, rw2, wf, gamma, wc, wu, wv1, wv2, beta)
         ctx.owners = (rw1, rw2, wf, wc, wu)
+        ctx.params = (rw1, rb1, rw2, rb2, wf, bf, gamma, beta, wc, bc, wu, bu)     # the caller's objects (gradient sinks)
         ctx.scale = scale
+        ctx.fused = fused
         return o12, xs_new
 
     @staticmethod
     def backward(ctx, do12, dxs_new):
-        x12, xs, t12, z12, stats, y12, c12, v12, p, rw1, rw2, wf, gamma, wc, wu, wv1, wv2 = ctx.saved_tensors
+        x12, xs, t12, z12, stats, y12, c12, v12, p, rw1, rw2, wf, gamma, wc, wu, wv1, wv2, beta = ctx.saved_tensors
         o_rw1, o_rw2, o_wf, o_wc, o_wu = ctx.owners
+        p_rw1, p_rb1, p_rw2, p_rb2, p_wf, p_bf, p_gamma, p_beta, p_wc, p_bc, p_wu, p_bu = ctx.params
         B2, H, W, Cn = x12.shape
         n = B2 // 2
         dev = x12.device
@@ -139,39 +232,65 @@ class BIETwinFn(torch.autograd.Function):
         _conv([X(c12)], da.transpose(1, 2).contiguous().view(B2, Cn, Cn, 1), s1, None, None, dv12, B2, bpg=1,
               accumulate=True)                                                                           # dv +=
         # ---- unclustering(cat[c1, c2]) + xs
-        dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev)
+        dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu)
         _dgrad(X(g_x), w_u, s2, 0, o_wu, dc12, n, accumulate=True, out_b0=0)
         _dgrad(X(g_x), w_u, s2, 1, o_wu, dc12, n, accumulate=True, out_b0=n)
         # ---- value convs (two weight groups)
-        dwv, dbv = _wgrad(X(dv12), [X(x12)], s1, B2, H, W, 1, Cn, dev, G=2)
-        dwv = dwv.view(2, Cn, Cn, 1, 1)
-        dx12 = new(B2)
-        _dgrad(X(dv12), w_v, s1, 0, None, dx12, B2, bpg=n)                                               # dx12  =
-        # ---- clustering, LayerNorm, convf
-        dwc, dbc = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev)
-        dy12 = new(B2)
-        _dgrad(X(dc12), w_c, s1, 0, o_wc, dy12, B2)
-        dz12 = new(B2)
-        ws = torch.empty(2 * 1024 * Cn, device=dev, dtype=torch.float32)
-        dgamma = torch.empty(Cn, device=dev, dtype=torch.float32)
-        dbeta = torch.empty(Cn, device=dev, dtype=torch.float32)
-        lib.call(lib._ln_bwd, "bmc_layernorm_bwd", dy12.data_ptr(), z12.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
-                 B2 * H * W, Cn, dz12.data_ptr(), ws.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, _stream())
-        dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev)
-        dxs = new(n)
-        _dgrad(X(dz12, b0=0, B=n), w_f, s2, 0, o_wf, dxs, n, residual=X(g_x))                            # dxs  = skip + half 0
-        _dgrad(X(dz12, b0=n, B=n), w_f, s2, 0, o_wf, dxs, n, accumulate=True)                            # dxs += half 1
-        _dgrad(X(dz12, shift=n, mod=B2), w_f, s2, 1, o_wf, dx12, B2, accumulate=True)                    # dx12 += (rotated)
+        dwv, dbv = _wgrad(X(dv12), [X(x12)], s1, B2, H, W, 1, Cn, dev, None, None, G=2, w_shape=(2, Cn, Cn, 1, 1))
+        if ctx.fused:
+            # ---- clustering, LayerNorm, convf: ONE data-gradient launch (csrc/chain.hip); y12 holds yhat, stats rstd.
+            # dx12 = conv_f^T (second half of its inputs), dxs = skip + conv_f^T (first half) summed over both halves.
+            dz12, dx12, dxs = chain_bwd(X(dc12), y12, stats, gamma.detach(), wf, wc, X(g_x), n, H, W, Cn, dev)
+            # G = dc^T yhat and the clustering bias gradient (temporaries: dW_c, dgamma, dbeta follow from them)
+            Gm, dbc_t = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev, None, None, w_shape=(Cn, Cn))
+            sg = ops.sink_group([p_wc, p_bc, p_gamma, p_beta])
+            if sg is not None:
+                (o_w, o_b, o_g, o_bt), acc = sg
+                dwc = dbc = dgamma = dbeta = None
+            else:
+                o_w, o_b, acc = Gm, None, 0
+                o_g = dgamma = torch.empty(Cn, device=dev, dtype=torch.float32)
+                o_bt = dbeta = torch.empty(Cn, device=dev, dtype=torch.float32)
+                dwc, dbc = Gm, dbc_t
+            lib.call(lib._chain_affine, "bmc_chain_affine_grads", Gm.data_ptr(), dbc_t.data_ptr(), wc.detach().data_ptr(),
+                     gamma.detach().data_ptr(), beta.detach().data_ptr(), Cn, o_w.data_ptr(),
+                     o_b.data_ptr() if o_b is not None else None, o_g.data_ptr(), o_bt.data_ptr(), acc, _stream())
+            dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf)
+            _dgrad(X(dv12), w_v, s1, 0, None, dx12, B2, bpg=n, accumulate=True)                          # dx12 += value convs
+        else:
+            dx12 = new(B2)
+            _dgrad(X(dv12), w_v, s1, 0, None, dx12, B2, bpg=n)                                           # dx12  =
+            # ---- clustering, LayerNorm, convf
+            dwc, dbc = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev, p_wc, p_bc)
+            dy12 = new(B2)
+            _dgrad(X(dc12), w_c, s1, 0, o_wc, dy12, B2)
+            dz12 = new(B2)
+            ws = torch.empty(2 * 1024 * Cn, device=dev, dtype=torch.float32)
+            sg = ops.sink_group([p_gamma, p_beta])
+            if sg is not None:
+                (o_g, o_bt), ln_acc = sg
+                dgamma = dbeta = None
+            else:
+                o_g = dgamma = torch.empty(Cn, device=dev, dtype=torch.float32)
+                o_bt = dbeta = torch.empty(Cn, device=dev, dtype=torch.float32)
+                ln_acc = 0
+            lib.call(lib._ln_bwd, "bmc_layernorm_bwd", dy12.data_ptr(), z12.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
+                     B2 * H * W, Cn, dz12.data_ptr(), ws.data_ptr(), o_g.data_ptr(), o_bt.data_ptr(), ln_acc, _stream())
+            dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf)
+            dxs = new(n)
+            _dgrad(X(dz12, b0=0, B=n), w_f, s2, 0, o_wf, dxs, n, residual=X(g_x))                        # dxs  = skip + half 0
+            _dgrad(X(dz12, b0=n, B=n), w_f, s2, 0, o_wf, dxs, n, accumulate=True)                        # dxs += half 1
+            _dgrad(X(dz12, shift=n, mod=B2), w_f, s2, 1, o_wf, dx12, B2, accumulate=True)                # dx12 += (rotated)
         # ---- residual block, upstream gradient = batch-rotated g_o
         g_r = X(g_o, shift=n, mod=B2)
-        dw2, db2 = _wgrad(g_r, [X(t12)], s1, B2, H, W, 9, Cn, dev)
+        dw2, db2 = _wgrad(g_r, [X(t12)], s1, B2, H, W, 9, Cn, dev, p_rw2, p_rb2)
         dt = new(B2)
         _dgrad(g_r, w_r2, s1, 0, o_rw2, dt, B2, mask=X(t12))
-        dw1, db1 = _wgrad(X(dt), [X(x12)], s1, B2, H, W, 9, Cn, dev)
+        dw1, db1 = _wgrad(X(dt), [X(x12)], s1, B2, H, W, 9, Cn, dev, p_rw1, p_rb1)
         _dgrad(X(dt), w_r1, s1, 0, o_rw1, dx12, B2, residual=g_r, accumulate=True)                       # dx12 += conv1^T + skip
-        return (dx12, dxs, dw1.view(rw1.shape), db1[0], dw2.view(rw2.shape), db2[0], dwf.view(wf.shape), dbf[0], dgamma, dbeta,
-                dwc.view(wc.shape), dbc[0], dwu.view(wu.shape), dbu[0], dwv[0].reshape(wv1.shape), dbv[0],
-                dwv[1].reshape(wv2.shape), dbv[1], None, None)
+        v = lambda t, ref: None if t is None else t.view(ref.shape)
+        return (dx12, dxs, dw1, db1, dw2, db2, dwf, dbf, dgamma, dbeta, v(dwc, wc), dbc, dwu, dbu,
+                dwv[0].reshape(wv1.shape), dbv[0], dwv[1].reshape(wv2.shape), dbv[1], None, None)
 
 
 def bie_twin(m, x12, xs):

@@ -47,6 +47,18 @@ class PgemmArgs(C.Structure):
                 ("zeros", C.c_void_p), ("bias_slabs", C.c_void_p), ("math", C.c_int)]
 
 
+class ChainFwdArgs(C.Structure):
+    _fields_ = [("s0", Src), ("s1", Src), ("wstream", C.c_void_p), ("bias_f", C.c_void_p), ("bias_c", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("yhat", C.c_void_p), ("rstd", C.c_void_p),
+                ("centre", C.c_void_p), ("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+
+
+class ChainBwdArgs(C.Structure):
+    _fields_ = [("dcentre", Src), ("wstream", C.c_void_p), ("gamma", C.c_void_p), ("yhat", C.c_void_p), ("rstd", C.c_void_p),
+                ("dz", C.c_void_p), ("ds1", C.c_void_p), ("ds0", C.c_void_p), ("ds0_add", Src), ("n", C.c_int), ("C", C.c_int),
+                ("H", C.c_int), ("W", C.c_int)]
+
+
 def _sig(name, argtypes, restype=C.c_int):
     fn = getattr(_lib, name)
     fn.argtypes = argtypes
@@ -80,11 +92,15 @@ _unshuffle = _sig("bmc_unshuffle_to_nhwc", [_p, _i, _i, _i, _i, _i, _p, _p])
 _shuffle = _sig("bmc_shuffle_to_hr", [_p, _i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _ll, _p, _p])
 _bicubic_fwd = _sig("bmc_bicubic_resize_fwd", [_p, _ll, _i, _i, _i, _i, _p, _p])
 _bicubic_bwd = _sig("bmc_bicubic_resize_bwd", [_p, _ll, _i, _i, _i, _i, _p, _p])
+_chain_fwd = _sig("bmc_chain_fwd", [C.POINTER(ChainFwdArgs), _p])
+_chain_bwd = _sig("bmc_chain_bwd", [C.POINTER(ChainBwdArgs), _p])
+_chain_affine = _sig("bmc_chain_affine_grads", [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p])
 
 EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_events_to_voxel", "bmc_events_to_stack", "bmc_encode_raw_events", "bmc_pack_weight", "bmc_pack_weight_t", "bmc_split_weight", "bmc_conv",
            "bmc_pgemm", "bmc_pgemm_reduce_weight", "bmc_pgemm_reduce_plain", "bmc_colsum", "bmc_relu_bwd",
            "bmc_layernorm_fwd", "bmc_layernorm_bwd", "bmc_softmax_fwd", "bmc_softmax_bwd", "bmc_pack_inputs",
-           "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr", "bmc_bicubic_resize_fwd", "bmc_bicubic_resize_bwd"]
+           "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr", "bmc_bicubic_resize_fwd", "bmc_bicubic_resize_bwd",
+           "bmc_chain_fwd", "bmc_chain_bwd", "bmc_chain_affine_grads"]
 
 
 def check(rc, what):

@@ -23,16 +23,19 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_cur_dev = torch._C._cuda_getDevice      # torch.cuda.current_device() without its Python-level lazy-init wrapper
+
+
 def _need_gpu(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError("bmc_hip: tensor is on %s -- the BMCNet MI355X path has no CPU fallback" % t.device)
     if t.dtype != torch.float32:
         raise RuntimeError("bmc_hip: fp32 tensors only (got %s)" % t.dtype)
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != _cur_dev():
         # launches go to the CURRENT device's current stream (_stream()): a tensor of another device would be
         # touched from the wrong device / stream
         raise RuntimeError("bmc_hip: tensor lives on %s but the current device is cuda:%d -- call torch.cuda.set_device "
-                           "(one process per GPU)" % (t.device, torch.cuda.current_device()))
+                           "(one process per GPU)" % (t.device, _cur_dev()))
 
 
 def round_up(v, m):
@@ -315,6 +318,64 @@ def colsum(x2d_ptr, npix, pix_stride, Cn, device):
 
 
 # --------------------------------------------------------------------------
+# parameter gradients: accumulate in the slab reduction, not in autograd
+# --------------------------------------------------------------------------
+# Every parameter of the network is used 10-40 times per recurrent window (5 weight-shared blocks, twin branches) and in
+# 8 windows per step: routed through autograd, each use costs one slab reduction into a fresh tensor plus one ATen add
+# into the running sum (~1 800 add launches per C2 step).  When the weight of a launch IS a leaf parameter, its reduction
+# adds straight into param.grad instead (bmc_pgemm_reduce_weight(accumulate=1), fixed order = backward's execution order,
+# deterministic) and autograd gets None for it.  Derived weights (slices / stacks of parameters) keep the autograd route.
+# Side effect to know about: post-accumulate-grad hooks do not fire for such parameters (parallel.GradAllReducer stages
+# the finished gradients in its optimizer pre-step hook instead).  BMC_ACCUM_GRADS=0 switches this off.
+ACCUM_PARAM_GRADS = os.environ.get("BMC_ACCUM_GRADS", "1") != "0"
+
+
+def is_sink(p):
+    return ACCUM_PARAM_GRADS and p is not None and p.is_leaf and p.requires_grad and p.is_contiguous()
+
+
+def sink_group(params):
+    """params: the parameters ONE launch writes gradients for (it has one accumulate flag for all of them).
+    -> ([their .grad tensors], accumulate) if every one is a leaf parameter, else None.  First use in a step allocates
+    the accumulators (accumulate = 0: the launch overwrites them); mixed states are aligned by zero-filling."""
+    if not all(is_sink(p) for p in params):
+        return None
+    missing = [p.grad is None for p in params]
+    if all(missing):
+        for p in params:
+            p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
+        acc = 0
+    else:
+        for p, m in zip(params, missing):
+            if m:
+                p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            elif not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
+        acc = 1
+    return [p.grad for p in params], acc
+
+
+def reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bias_slabs, w_param, b_param, w_shape):
+    """Sum the pixel-reduction GEMM's slabs into the weight (+ bias) gradient.  -> (dw, db) for autograd; entries are
+    None where the gradient went straight into a leaf parameter's .grad (see above)."""
+    want_b = bias_slabs is not None
+    sg = sink_group([w_param, b_param] if want_b else [w_param]) if G == 1 and w_param is not None else None
+    if sg is not None:
+        (gw, *rest), acc = sg
+        gb = rest[0] if want_b else None
+        lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, 1, taps, Cout, spec.kpad,
+                 spec.kmap(dev).data_ptr(), spec.cin, gw.data_ptr(), acc, bias_slabs.data_ptr() if want_b else None,
+                 gb.data_ptr() if want_b else None, _stream())
+        return None, None
+    dw = torch.empty(G * Cout * spec.cin * taps, device=dev, dtype=torch.float32)
+    db = torch.empty((G, Cout), device=dev, dtype=torch.float32) if want_b else None
+    lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, G, taps, Cout, spec.kpad,
+             spec.kmap(dev).data_ptr(), spec.cin, dw.data_ptr(), 0, bias_slabs.data_ptr() if want_b else None,
+             db.data_ptr() if want_b else None, _stream())
+    return dw.view(w_shape), ((db[0] if G == 1 else db) if want_b else None)
+
+
+# --------------------------------------------------------------------------
 # convolution (3x3 / 1x1, multi-source, grouped weights)
 # --------------------------------------------------------------------------
 class ConvMeta:
@@ -351,6 +412,7 @@ class ConvFn(torch.autograd.Function):
                  out.data_ptr(), H * W * Cout, Cout, B, H, W, Cout, taps, relu=meta.relu, residual=res,
                  bpg=B // G, flops=2.0 * B * H * W * Cout * taps * meta.spec.cin)
         ctx.meta = meta
+        ctx.params = (weight, bias)  # the objects the caller passed (leaf parameters take their gradients directly)
         ctx.w_owner = ck            # identity of the parameter object (saved_tensors may hand back a new wrapper)
         ctx.has_bias = bias is not None
         ctx.has_res = res_t is not None
@@ -370,6 +432,7 @@ class ConvFn(torch.autograd.Function):
         ck = ctx.w_owner
         need = ctx.needs_input_grad
         dw = db = dres = None
+        bias_done = False
         # ---- weight gradient: pixel-reduction GEMM  dW[co][k][tap] = sum_px g[px][co] * x[px+tap][k]
         if need[1]:
             srcs = [_src(t, *v, B) for t, v in zip(src_ts, meta.views)]
@@ -378,15 +441,11 @@ class ConvFn(torch.autograd.Function):
             r_pg = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
                              flops=2.0 * B * H * W * Cout * taps * spec.cin, want_bias=wb)
             slabs, nsplit = r_pg[0], r_pg[1]
-            dwf = torch.empty(G * Cout * spec.cin * taps, device=dev, dtype=torch.float32)   # every (co, ci, tap) is written
-            dbf = torch.empty((G, Cout), device=dev, dtype=torch.float32) if wb else None
-            lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, G, taps, Cout, spec.kpad,
-                     spec.kmap(dev).data_ptr(), spec.cin, dwf.data_ptr(), 0, r_pg[3].data_ptr() if wb else None,
-                     dbf.data_ptr() if wb else None, _stream())
-            if wb:
-                db = dbf[0] if G == 1 else dbf
-            dw = dwf.view(weight.shape)
-        if ctx.has_bias and need[2] and db is None:
+            wp_, bp_ = ctx.params
+            dw, db = reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, r_pg[3] if wb else None, wp_, bp_ if wb else None,
+                                  weight.shape)
+            bias_done = wb
+        if ctx.has_bias and need[2] and not bias_done:
             bpg = B // G
             parts = [colsum(g.data_ptr() + 4 * gi * bpg * H * W * Cout, bpg * H * W, Cout, Cout, dev) for gi in range(G)]
             db = parts[0] if G == 1 else torch.stack(parts)
@@ -463,17 +522,14 @@ def conv(views: Sequence[View], weight, bias, spec: ConvSpec, *, B=None, relu=Fa
 # fused residual block (models/submodules.py:17-35): both ReLU-backward and the skip-path gradient add live in
 # convolution epilogues, so the backward is exactly 2 data-gradient + 2 weight-gradient launches (+ bias sums)
 # --------------------------------------------------------------------------
-def _wgrad_plain(g, x, spec, weight_shape, taps):
-    """-> (dW, db): weight gradient and bias gradient (column sums of g) from one pgemm launch."""
+def _wgrad_plain(g, x, spec, w_param, b_param, taps):
+    """-> (dW, db) for autograd (None where accumulated into the leaf parameter's .grad): weight gradient and bias
+    gradient (column sums of g) from one pgemm launch."""
     B, H, W, Cout = g.shape
     dev = g.device
     slabs, nsplit, _, bsl = pgemm_raw(_src(g, 0, Cout, 0, None, 0, B), [_src(x, 0, x.shape[3], 0, None, 0, B)], B, H, W, taps,
                                       B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.cin, want_bias=True)
-    db = torch.empty((1, Cout), device=dev, dtype=torch.float32)
-    dw = torch.empty(Cout * spec.cin * taps, device=dev, dtype=torch.float32)
-    lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, 1, taps, Cout, spec.kpad,
-             spec.kmap(dev).data_ptr(), spec.cin, dw.data_ptr(), 0, bsl.data_ptr(), db.data_ptr(), _stream())
-    return dw.view(weight_shape), db[0]
+    return reduce_wgrad(slabs, nsplit, 1, taps, Cout, spec, dev, bsl, w_param, b_param, w_param.shape)
 
 
 class OutSlot:
@@ -505,6 +561,7 @@ class ResBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x, t, w1, w2)
         ctx.spec, ctx.taps = spec, taps
         ctx.owners = (w1, w2)
+        ctx.params = (w1, b1, w2, b2)
         return y
 
     @staticmethod
@@ -518,13 +575,14 @@ class ResBlockFn(torch.autograd.Function):
         fl = 2.0 * B * H * W * Cn * taps * Cn
         gs = _src(g, 0, Cn, 0, None, 0, B)
         nkpad, c16 = coutpad(Cn), round_up(Cn, CK)
-        dw2, db2 = _wgrad_plain(g, t, spec, w2.shape, taps) if (need[3] or need[4]) else (None, None)
+        p_w1, p_b1, p_w2, p_b2 = ctx.params
+        dw2, db2 = _wgrad_plain(g, t, spec, p_w2, p_b2, taps) if (need[3] or need[4]) else (None, None)
         # d(pre-activation of conv1) = ReLU'(t) * conv2^T(g): mask epilogue
         w2t = _packed_weight_t(w2.detach().reshape(1, Cn, Cn, taps), spec, 0, ctx.owners[1])
         dt = torch.empty_like(g)
         conv_raw([gs], w2t, c16 * taps * nkpad, None, 0, dt.data_ptr(), H * W * Cn, Cn, B, H, W, Cn, taps,
                  mask=_src(t, 0, Cn, 0, None, 0, B), flops=fl)
-        dw1, db1 = _wgrad_plain(dt, x, spec, w1.shape, taps) if (need[1] or need[2]) else (None, None)
+        dw1, db1 = _wgrad_plain(dt, x, spec, p_w1, p_b1, taps) if (need[1] or need[2]) else (None, None)
         dx = None
         if need[0]:   # dx = conv1^T(dt) + g (skip path): residual epilogue
             w1t = _packed_weight_t(w1.detach().reshape(1, Cn, Cn, taps), spec, 0, ctx.owners[0])
@@ -553,6 +611,7 @@ class LayerNormFn(torch.autograd.Function):
         lib.call(lib._ln_fwd, "bmc_layernorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), npix, Cn, eps,
                  y.data_ptr(), stats.data_ptr(), _stream())
         ctx.save_for_backward(x, stats, gamma)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -563,6 +622,12 @@ class LayerNormFn(torch.autograd.Function):
         npix = x.numel() // Cn
         dx = torch.empty_like(x)
         ws = torch.empty(2 * 1024 * Cn, device=x.device, dtype=torch.float32)
+        sg = sink_group(list(ctx.params))
+        if sg is not None:
+            (dg, db), acc = sg
+            lib.call(lib._ln_bwd, "bmc_layernorm_bwd", dy.data_ptr(), x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), npix,
+                     Cn, dx.data_ptr(), ws.data_ptr(), dg.data_ptr(), db.data_ptr(), acc, _stream())
+            return dx, None, None, None
         dg = torch.empty(Cn, device=x.device, dtype=torch.float32)
         db = torch.empty(Cn, device=x.device, dtype=torch.float32)
         lib.call(lib._ln_bwd, "bmc_layernorm_bwd", dy.data_ptr(), x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), npix,

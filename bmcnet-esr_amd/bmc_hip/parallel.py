@@ -88,26 +88,26 @@ class GradAllReducer:
 
     def finish(self):
         """Join outstanding all-reduces, average, and expose the result as .grad (views of the flat buckets).
-        Every rank runs the same graph, so which parameters received a gradient is the same on every rank."""
+        Every rank runs the same graph, so which parameters received a gradient is the same on every rank.
+        Buckets whose parameters did not all come through the hooks -- gradient accumulation over several backward()
+        calls, or gradients that the kernels accumulated straight into .grad (bmc_hip.ops.ACCUM_PARAM_GRADS: no autograd
+        accumulation, hence no hook) -- are staged and reduced here."""
         nb = len(self.buckets)
-        active = [any(p in self.seen for p in self.buckets[bi]) for bi in range(nb)]
+        active = [any(p.grad is not None for p in self.buckets[bi]) for bi in range(nb)]
         for bi in range(nb):
-            if not active[bi]:
-                continue
-            if self.deferred:                              # gradient accumulation: stage the accumulated gradients now
-                for p in self.buckets[bi]:
-                    o = self.slot[p][1]
-                    if p.grad is None:
-                        self.flat[bi][o:o + p.numel()].zero_()
-                    elif p.grad.data_ptr() != self.flat[bi][o:].data_ptr():
-                        self.flat[bi][o:o + p.numel()].copy_(p.grad.reshape(-1))
-                self._launch(bi)
-            elif self.pending[bi] != 0:                    # bucket holds parameters the loss did not reach
-                for p in self.buckets[bi]:
-                    if p.grad is None:
-                        o = self.slot[p][1]
-                        self.flat[bi][o:o + p.numel()].zero_()
-                self._launch(bi)
+            if not active[bi] or (not self.deferred and self.pending[bi] == 0):
+                continue                                   # nothing to do / complete and already in flight
+            w = self.works[bi]
+            if w is not None:                              # (cannot happen today: a launched bucket has pending == 0)
+                w.wait(); self.works[bi] = None
+            for p in self.buckets[bi]:
+                o = self.slot[p][1]
+                dst = self.flat[bi][o:o + p.numel()]
+                if p.grad is None:                         # parameter the loss did not reach
+                    dst.zero_()
+                elif p.grad.data_ptr() != dst.data_ptr():
+                    dst.copy_(p.grad.reshape(-1))
+            self._launch(bi)
         self._join()
         for bi in range(nb):
             if not active[bi]:

@@ -200,6 +200,56 @@ int bmc_unshuffle_to_nhwc(const float* hr, int B, int C, int H, int W, int r, fl
 int bmc_shuffle_to_hr(const float* lr, int B, int C, int H, int W, int r, const float* base,
                       long long sb, long long sc, long long sy, long long sx, float* hr, bmc_stream_t s);
 
+/* ---- fused "centre" chain of the BIE block ----------------------------------
+ * forward: centre = clustering(LayerNorm2d(convf(cat[s0, s1])))  -- models/submodules.py:63-64 with LayerNormFunction
+ * (:127-140) between the two 1x1 convolutions -- in ONE launch: z and y = LN(z) never reach HBM (the second GEMM takes
+ * its pixel operand from the first one's accumulator registers).  Saved for backward: yhat = (z - mean)/sqrt(var + eps)
+ * (before the affine) and rstd.  C = channels of s0, s1, yhat, centre: 32, 64 or 128.  All outputs are contiguous
+ * [B][H][W][C] (rstd [B][H][W]).
+ * wstream: 3C/16 slices of [C][16] floats = bmc_pack_weight(W_f, Kpad = 2C, Coutpad = C) followed by
+ * bmc_pack_weight(W_c, Kpad = C, Coutpad = C). */
+typedef struct bmc_chain_fwd_args {
+    bmc_src_t s0, s1;           /* nch = C each; launch batch b reads them through their batch maps */
+    const float* wstream;
+    const float* bias_f;        /* [C] convf bias */
+    const float* bias_c;        /* [C] clustering bias */
+    const float* gamma;         /* [C] LayerNorm2d weight */
+    const float* beta;          /* [C] LayerNorm2d bias */
+    float eps;
+    float* yhat;
+    float* rstd;
+    float* centre;
+    int B, C, H, W;
+} bmc_chain_fwd_args_t;
+int bmc_chain_fwd(const bmc_chain_fwd_args_t* host_args, bmc_stream_t s);
+
+/* backward of the same chain for the twin layout (2n launch batches; batch bb read s0 at bb % n and s1 at (bb + n) % 2n):
+ *   dy = W_c^T dcentre;  dz = rstd * (g - yhat*mean_c(g*yhat) - mean_c(g)), g = dy*gamma  (LayerNormFunction.backward, :141-154);
+ *   dz  [2n][H][W][C]  is written for the weight-gradient GEMM of convf;
+ *   ds1 [(bb + n) % 2n] = W_f[:, C:]^T dz[bb];
+ *   ds0 [b] = ds0_add[b] + W_f[:, :C]^T (dz[b] + dz[b + n])   (both halves summed in registers, ds0 written once).
+ * Weight / bias / affine gradients: bmc_pgemm on (dcentre, yhat) and (dz, s0, s1) + bmc_chain_affine_grads.
+ * wstream: 6C/16 slices of [C][16]: T(W_c), T1(W_f), T0(W_f), T(W_c), T0(W_f), T1(W_f) with
+ * T(.) = bmc_pack_weight_t(., nkpad = C) and T0 / T1 the operators of W_f's first / second C input channels. */
+typedef struct bmc_chain_bwd_args {
+    bmc_src_t dcentre;          /* nch = C, 2n launch batches */
+    const float* wstream;
+    const float* gamma;
+    const float* yhat;          /* [2n][H][W][C] from bmc_chain_fwd */
+    const float* rstd;          /* [2n][H][W] */
+    float* dz;
+    float* ds1;
+    float* ds0;
+    bmc_src_t ds0_add;          /* ptr NULL -> none */
+    int n, C, H, W;
+} bmc_chain_bwd_args_t;
+int bmc_chain_bwd(const bmc_chain_bwd_args_t* host_args, bmc_stream_t s);
+/* G[C][C] = bmc_pgemm(dcentre, yhat) reduced with bmc_pgemm_reduce_weight, dbc[C] its bias column sums ->
+ * dwc (=|+=) gamma[ci] G[co][ci] + dbc[co] beta[ci];  dgamma[ci] (=|+=) sum_co W_c[co][ci] G[co][ci];  dbeta (=|+=) W_c^T dbc
+ * (accumulate 0 | 1; dwc may alias G); dbc_out, if not NULL, (=|+=) dbc. */
+int bmc_chain_affine_grads(const float* G, const float* dbc, const float* Wc, const float* gamma, const float* beta, int C,
+                           float* dwc, float* dbc_out, float* dgamma, float* dbeta, int accumulate, bmc_stream_t s);
+
 /* ---- loss-side resize ------------------------------------------------------
  * F.interpolate(prediction, size=gt.size()[-2:], mode='bicubic', align_corners=False): train.py:227-231,
  * infer_BMCNet.py:77-78 (taken when scale * round(sensor / scale) != sensor, dataloader/h5dataset.py:88-100; EventZoom:

@@ -26,12 +26,13 @@ def test_struct_layout_matches_header():
     import subprocess
     import tempfile
     from bmc_hip import lib
-    src = '#include <stdio.h>\n#include "bmc_hip.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(bmc_src_t), sizeof(bmc_conv_args_t), sizeof(bmc_pgemm_args_t));return 0;}'
+    src = '#include <stdio.h>\n#include "bmc_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(bmc_src_t), sizeof(bmc_conv_args_t), sizeof(bmc_pgemm_args_t), sizeof(bmc_chain_fwd_args_t), sizeof(bmc_chain_bwd_args_t));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
         out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, text=True).stdout.split()
-    assert [int(v) for v in out] == [C.sizeof(lib.Src), C.sizeof(lib.ConvArgs), C.sizeof(lib.PgemmArgs)]
+    assert [int(v) for v in out] == [C.sizeof(lib.Src), C.sizeof(lib.ConvArgs), C.sizeof(lib.PgemmArgs),
+                                      C.sizeof(lib.ChainFwdArgs), C.sizeof(lib.ChainBwdArgs)]
 
 
 def test_state_dict_surface_matches_reference_counts():
