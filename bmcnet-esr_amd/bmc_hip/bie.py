@@ -331,5 +331,12 @@ class Unstack2Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g1, g2):
+        if g1 is not None and g2 is not None and g1.is_contiguous() and g2.is_contiguous() \
+                and g1.untyped_storage().data_ptr() == g2.untyped_storage().data_ptr() \
+                and g2.storage_offset() == g1.storage_offset() + g1.numel():
+            # the two gradients already lie back to back in one buffer (ops.StackViewsFn.backward hands out such views)
+            out = torch.empty(0, device=g1.device, dtype=g1.dtype)
+            out.set_(g1.untyped_storage(), g1.storage_offset(), tuple(ctx.shape), torch.empty(ctx.shape, device="meta").stride())
+            return out
         z = lambda: torch.zeros((ctx.n,) + tuple(ctx.shape[1:]), device=(g1 if g1 is not None else g2).device)
         return torch.cat([g1 if g1 is not None else z(), g2 if g2 is not None else z()], 0)

@@ -88,8 +88,11 @@ _ln_bwd = _sig("bmc_layernorm_bwd", [_p, _p, _p, _p, _ll, _i, _p, _p, _p, _p, _i
 _sm_fwd = _sig("bmc_softmax_fwd", [_p, _ll, _i, _p, _p])
 _sm_bwd = _sig("bmc_softmax_bwd", [_p, _p, _ll, _i, _f, _p, _p])
 _pack_in = _sig("bmc_pack_inputs", [_p, _ll, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _p, _p, _p])
-_unshuffle = _sig("bmc_unshuffle_to_nhwc", [_p, _i, _i, _i, _i, _i, _p, _p])
-_shuffle = _sig("bmc_shuffle_to_hr", [_p, _i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _ll, _p, _p])
+_unshuffle = _sig("bmc_unshuffle_to_nhwc", [_p, _i, _i, _i, _i, _i, _p, _i, _p])
+_shuffle = _sig("bmc_shuffle_to_hr", [_p, _i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _ll, _p, _i, _p])
+_head_mse_fwd = _sig("bmc_head_mse_fwd", [_p, _i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _ll, _p, _ll, _p, _p, _p, _p])
+_head_mse_bwd = _sig("bmc_head_mse_bwd", [_p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _p, _p])
+_group_sum = _sig("bmc_group_sum", [_p, _i, _ll, _p, _p])
 _bicubic_fwd = _sig("bmc_bicubic_resize_fwd", [_p, _ll, _i, _i, _i, _i, _p, _p])
 _bicubic_bwd = _sig("bmc_bicubic_resize_bwd", [_p, _ll, _i, _i, _i, _i, _p, _p])
 _chain_fwd = _sig("bmc_chain_fwd", [C.POINTER(ChainFwdArgs), _p])
@@ -100,7 +103,8 @@ EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_event
            "bmc_pgemm", "bmc_pgemm_reduce_weight", "bmc_pgemm_reduce_plain", "bmc_colsum", "bmc_relu_bwd",
            "bmc_layernorm_fwd", "bmc_layernorm_bwd", "bmc_softmax_fwd", "bmc_softmax_bwd", "bmc_pack_inputs",
            "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr", "bmc_bicubic_resize_fwd", "bmc_bicubic_resize_bwd",
-           "bmc_chain_fwd", "bmc_chain_bwd", "bmc_chain_affine_grads"]
+           "bmc_chain_fwd", "bmc_chain_bwd", "bmc_chain_affine_grads", "bmc_group_sum",
+           "bmc_head_mse_fwd", "bmc_head_mse_bwd"]
 
 
 def check(rc, what):

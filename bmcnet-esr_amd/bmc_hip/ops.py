@@ -310,6 +310,14 @@ def relu_bwd(dy, y):
     return g
 
 
+def group_sum(g, groups):
+    """[groups*n, ...] -> [n, ...]: sum over the batch groups, fixed order (bmc_group_sum)."""
+    n = g.shape[0] // groups
+    out = torch.empty((n,) + tuple(g.shape[1:]), device=g.device, dtype=torch.float32)
+    lib.call(lib._group_sum, "bmc_group_sum", g.data_ptr(), groups, out.numel(), out.data_ptr(), _stream())
+    return out
+
+
 def colsum(x2d_ptr, npix, pix_stride, Cn, device):
     ws = torch.empty(2048 * Cn, device=device, dtype=torch.float32)
     out = torch.empty(Cn, device=device, dtype=torch.float32)
@@ -379,11 +387,11 @@ def reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bias_slabs, w_param, b
 # convolution (3x3 / 1x1, multi-source, grouped weights)
 # --------------------------------------------------------------------------
 class ConvMeta:
-    __slots__ = ("spec", "views", "B", "relu", "G", "res", "cache", "taps")
+    __slots__ = ("spec", "views", "B", "relu", "G", "res", "cache", "taps", "out")
 
-    def __init__(self, spec, views, B, relu, G, res, cache, taps):
-        self.spec, self.views, self.B, self.relu, self.G, self.res, self.cache, self.taps = \
-            spec, views, B, relu, G, res, cache, taps
+    def __init__(self, spec, views, B, relu, G, res, cache, taps, out=None):
+        self.spec, self.views, self.B, self.relu, self.G, self.res, self.cache, self.taps, self.out = \
+            spec, views, B, relu, G, res, cache, taps, out
 
 
 class ConvFn(torch.autograd.Function):
@@ -402,7 +410,11 @@ class ConvFn(torch.autograd.Function):
         Cout = w4.shape[1]
         ck = weight if meta.cache else None
         wp = _packed_weight(w4.contiguous(), meta.spec, ck)
-        out = torch.empty((B, H, W, Cout), device=t0.device, dtype=torch.float32)
+        if meta.out is not None:       # write into a batch range of a preallocated buffer (see OutSlot)
+            out = meta.out.t[meta.out.b0:meta.out.b0 + B]
+            assert out.shape == (B, H, W, Cout) and out.is_contiguous()
+        else:
+            out = torch.empty((B, H, W, Cout), device=t0.device, dtype=torch.float32)
         srcs = [_src(t.detach(), *v, B) for t, v in zip(src_ts, meta.views)]
         res = None
         if res_t is not None:
@@ -453,14 +465,43 @@ class ConvFn(torch.autograd.Function):
             shift, mod = meta.res
             dres = g
             if mod is not None and mod < B:
-                dres = g.view(B // mod, mod, H, W, Cout).sum(0)
+                dres = group_sum(g, B // mod)
             elif shift:
                 dres = torch.roll(g, shifts=shift, dims=0)
-        # ---- data gradients: same conv kernel, transposed + mirrored weights, one launch per source
+        # ---- data gradients: same conv kernel, transposed + mirrored weights, one launch per source.
+        # Sources that are disjoint windows of ONE tensor (the batch halves of a twin tensor) share one gradient tensor:
+        # each launch writes its window, the tensor is handed to autograd once -- no zero fill, no add.
+        shared_dx = {}
+        simple = lambda v: v[2] == 0 and v[3] is None
+        for i, (t, v) in enumerate(zip(src_ts, meta.views)):
+            if need[4 + i] and simple(v):
+                shared_dx.setdefault(id(t), []).append(i)
+        for key, idxs in list(shared_dx.items()):
+            t = src_ts[idxs[0]]
+            Bt, _, _, Ct = t.shape
+            wins = [(meta.views[i][4], meta.views[i][0], meta.views[i][1]) for i in idxs]            # (b0, c0, nch)
+            apart = lambda p, q: p[0] + B <= q[0] or q[0] + B <= p[0] or p[1] + p[2] <= q[1] or q[1] + q[2] <= p[1]
+            disjoint = all(apart(wins[j], wins[k]) for j in range(len(wins)) for k in range(j + 1, len(wins)))
+            inside = all(w[0] + B <= Bt and w[1] + w[2] <= Ct for w in wins)
+            if len(idxs) >= 2 and G == 1 and disjoint and inside and sum(B * w[2] for w in wins) == Bt * Ct:
+                shared_dx[key] = (idxs, torch.empty_like(t))
+            else:
+                del shared_dx[key]
         dsrcs = []
         for i, (t, v) in enumerate(zip(src_ts, meta.views)):
             if not need[4 + i]:
                 dsrcs.append(None)
+                continue
+            grp = shared_dx.get(id(t)) if simple(v) else None
+            if grp is not None:
+                c0, nch, shift, mod, b0 = v
+                Bt, _, _, Ct = t.shape
+                dxs_ = grp[1]
+                wt = _packed_weight_t(w4, spec, i, ck)
+                conv_raw([_src(g, 0, Cout, 0, None, 0, B)], wt, round_up(Cout, CK) * taps * coutpad(nch), None, 0,
+                         dxs_.data_ptr() + 4 * (b0 * H * W * Ct + c0), H * W * Ct, Ct, B, H, W, nch, taps, bpg=B,
+                         flops=2.0 * B * H * W * spec.real_nch[i] * taps * Cout)
+                dsrcs.append(dxs_ if i == grp[0][0] else None)
                 continue
             c0, nch, shift, mod, b0 = v
             Bt, _, _, Ct = t.shape
@@ -490,7 +531,7 @@ class ConvFn(torch.autograd.Function):
                 continue
             if mod is not None and mod < B:          # operand shared by several launch batches: sum first (linearity)
                 assert shift == 0
-                gs, nb = g.view(B // mod, mod, H, W, Cout).sum(0), mod
+                gs, nb = group_sum(g, B // mod), mod
             elif shift:                               # operand read with a batch rotation: rotate back
                 assert mod == B
                 gshift, gmod = (mod - shift) % mod, mod
@@ -506,15 +547,16 @@ class ConvFn(torch.autograd.Function):
 
 
 def conv(views: Sequence[View], weight, bias, spec: ConvSpec, *, B=None, relu=False, residual=None, G=1,
-         cache=True, taps=None):
-    """views: operands (in packed-K order of `spec`); weight [Cout,Cin,kh,kw] (G == 1) or [G,Cout,Cin(,1,1)]."""
+         cache=True, taps=None, out=None):
+    """views: operands (in packed-K order of `spec`); weight [Cout,Cin,kh,kw] (G == 1) or [G,Cout,Cin(,1,1)];
+    out: optional OutSlot -- the result is written into (and returned as a view of) a batch range of its buffer."""
     B = views[0].t.shape[0] if B is None else B
     if taps is None:
         taps = weight.shape[-1] * weight.shape[-2] if weight.dim() >= 4 else 1
     res_t, res_meta = None, None
     if residual is not None:
         res_t, res_meta = residual.t, (residual.shift, residual.mod)
-    meta = ConvMeta(spec, [v.meta() for v in views], B, relu, G, res_meta, cache, taps)
+    meta = ConvMeta(spec, [v.meta() for v in views], B, relu, G, res_meta, cache, taps, out)
     return ConvFn.apply(meta, weight, bias, res_t, *[v.t for v in views])
 
 
@@ -743,39 +785,42 @@ def pack_inputs(x, repeat=3):
     return xin
 
 
-def _unshuffle(hr, r):
+def _unshuffle(hr, r, split=1):
     B, Cc, HH, WW = hr.shape
     H, W = HH // r, WW // r
-    lr = torch.empty((B, H, W, Cc * r * r), device=hr.device, dtype=torch.float32)
-    lib.call(lib._unshuffle, "bmc_unshuffle_to_nhwc", hr.data_ptr(), B, Cc, H, W, r, lr.data_ptr(), _stream())
+    lr = torch.empty((split * B, H, W, Cc * r * r // split), device=hr.device, dtype=torch.float32)
+    lib.call(lib._unshuffle, "bmc_unshuffle_to_nhwc", hr.data_ptr(), B, Cc, H, W, r, lr.data_ptr(), split, _stream())
     return lr
 
 
-def _shuffle(lr, r, base=None):
-    B, H, W, CC = lr.shape
+def _shuffle(lr, r, base=None, split=1):
+    Bs, H, W, cg = lr.shape
+    B, CC = Bs // split, cg * split
     Cc = CC // (r * r)
     hr = torch.empty((B, Cc, H * r, W * r), device=lr.device, dtype=torch.float32)
     if base is None:
-        lib.call(lib._shuffle, "bmc_shuffle_to_hr", lr.data_ptr(), B, Cc, H, W, r, None, 0, 0, 0, 0, hr.data_ptr(), _stream())
+        lib.call(lib._shuffle, "bmc_shuffle_to_hr", lr.data_ptr(), B, Cc, H, W, r, None, 0, 0, 0, 0, hr.data_ptr(), split,
+                 _stream())
     else:
         sb, sc, sy, sx = base.stride()
         lib.call(lib._shuffle, "bmc_shuffle_to_hr", lr.data_ptr(), B, Cc, H, W, r, base.data_ptr(), sb, sc, sy, sx,
-                 hr.data_ptr(), _stream())
+                 hr.data_ptr(), split, _stream())
     return hr
 
 
 class UnshuffleFn(torch.autograd.Function):
-    """HR NCHW [B,C,rH,rW] -> LR NHWC [B,H,W,C r r] (PixelUnShuffle, models/submodules.py:80-92)."""
+    """HR NCHW [B,C,rH,rW] -> LR NHWC [B,H,W,C r r] (PixelUnShuffle, models/submodules.py:80-92); split = S stores it as S
+    batch-stacked channel groups [S B,H,W,C r r / S] (what the input-fusion convolutions read: no cat in between)."""
 
     @staticmethod
-    def forward(ctx, hr, r):
+    def forward(ctx, hr, r, split):
         _need_gpu(hr)
-        ctx.r = r
-        return _unshuffle(hr.contiguous(), r)
+        ctx.r, ctx.split = r, split
+        return _unshuffle(hr.contiguous(), r, split)
 
     @staticmethod
     def backward(ctx, dlr):
-        return _shuffle(dlr.contiguous(), ctx.r), None
+        return _shuffle(dlr.contiguous(), ctx.r, None, ctx.split), None, None
 
 
 class HeadFn(torch.autograd.Function):
@@ -792,8 +837,95 @@ class HeadFn(torch.autograd.Function):
         return _unshuffle(dpred.contiguous(), ctx.r), None, None
 
 
-def pixel_unshuffle_nhwc(hr, r):
-    return UnshuffleFn.apply(hr, r)
+class HeadMseFn(torch.autograd.Function):
+    """(pred, mse) = head + nn.MSELoss in one pass (bmc_head_mse_fwd); the backward folds the loss gradient
+    2 (pred - gt) / numel into the pixel-unshuffle of the gradient arriving from the next window (bmc_head_mse_bwd)."""
+
+    @staticmethod
+    def forward(ctx, xo, base, gt, r):
+        _need_gpu(xo)
+        xo = xo.contiguous()
+        B, H, W, CC = xo.shape
+        Cc = CC // (r * r)
+        if tuple(gt.shape) != (B, Cc, H * r, W * r) or not gt.is_cuda or gt.dtype != torch.float32:
+            raise RuntimeError("head_mse: ground truth must be a float32 GPU tensor of the prediction's shape")
+        if gt.stride()[1:] != (H * r * W * r, W * r, 1):
+            gt = gt.contiguous()
+        pred = torch.empty((B, Cc, H * r, W * r), device=xo.device, dtype=torch.float32)
+        ws = torch.empty(2048, device=xo.device, dtype=torch.float32)
+        loss = torch.empty((), device=xo.device, dtype=torch.float32)
+        sb, sc, sy, sx = base.stride()
+        lib.call(lib._head_mse_fwd, "bmc_head_mse_fwd", xo.data_ptr(), B, Cc, H, W, r, base.data_ptr(), sb, sc, sy, sx,
+                 gt.data_ptr(), gt.stride(0), pred.data_ptr(), ws.data_ptr(), loss.data_ptr(), _stream())
+        ctx.r = r
+        ctx.dims = (B, Cc, H, W)
+        ctx.save_for_backward(pred, gt)
+        return pred, loss
+
+    @staticmethod
+    def backward(ctx, dpred, dloss):
+        pred, gt = ctx.saved_tensors
+        B, Cc, H, W = ctx.dims
+        r = ctx.r
+        if dpred is not None:
+            dpred = dpred.contiguous()
+        if dloss is not None:
+            dloss = dloss.contiguous()
+        dlr = torch.empty((B, H, W, Cc * r * r), device=pred.device, dtype=torch.float32)
+        lib.call(lib._head_mse_bwd, "bmc_head_mse_bwd", dpred.data_ptr() if dpred is not None else None, pred.data_ptr(),
+                 gt.data_ptr(), gt.stride(0), dloss.data_ptr() if dloss is not None else None, B, Cc, H, W, r,
+                 dlr.data_ptr(), _stream())
+        return dlr, None, None, None
+
+
+def head_mse(xo, base, gt, r):
+    return HeadMseFn.apply(xo, base, gt, r)
+
+
+def pixel_unshuffle_nhwc(hr, r, split=1):
+    return UnshuffleFn.apply(hr, r, split)
+
+
+class StackViewsFn(torch.autograd.Function):
+    """NCHW-shaped, channels-last-strided tensors that already lie back to back in one allocation (the recurrent states
+    the previous window's convolutions wrote into one buffer) -> the NHWC tensor [sum B,H,W,C] over the same memory: no
+    copy.  Backward hands every part its slice of the gradient as a view."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        p0 = parts[0]
+        B, Cc, H, W = p0.shape
+        ctx.nb = [p.shape[0] for p in parts]
+        out = torch.empty(0, device=p0.device, dtype=p0.dtype)
+        out.set_(p0.untyped_storage(), p0.storage_offset(), (sum(ctx.nb), H, W, Cc), (H * W * Cc, W * Cc, Cc, 1))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, b = [], 0
+        for n in ctx.nb:
+            outs.append(g[b:b + n].permute(0, 3, 1, 2))
+            b += n
+        return tuple(outs)
+
+
+def stack_states(parts):
+    """[B,C,H,W] tensors -> NHWC [sum B,H,W,C]; free when they are adjacent channels-last views of one buffer (see
+    StackViewsFn), one copy (torch.cat) otherwise (first window: the caller's separate zero tensors)."""
+    p0 = parts[0]
+    B, Cc, H, W = p0.shape
+    want = (H * W * Cc, 1, W * Cc, Cc)
+    ok = all(p.is_cuda and p.dtype == torch.float32 and tuple(p.shape[1:]) == (Cc, H, W) and p.stride() == want for p in parts)
+    if ok:
+        off = p0.storage_offset()
+        for p in parts:
+            if p.untyped_storage().data_ptr() != p0.untyped_storage().data_ptr() or p.storage_offset() != off:
+                ok = False
+                break
+            off += p.shape[0] * H * W * Cc
+    if ok:
+        return StackViewsFn.apply(*parts)
+    return torch.cat([p.permute(0, 2, 3, 1).contiguous() for p in parts], 0)
 
 
 def head(xo, base, r):

@@ -31,7 +31,6 @@
 namespace {
 
 constexpr int CK = BMC_CK;
-constexpr int RS = 20;            // LDS row stride in floats (16 + 4 pad)
 constexpr int TW = 16, TH = 8, NPX = TW * TH;
 __device__ __attribute__((aligned(16))) const float g_zero4c[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -51,22 +50,53 @@ struct ChainK {
     int H, W, tiles_x, tiles_y, nunits;
 };
 
+// 16 bytes per lane from global memory straight into LDS (lane-linear image at the wave-uniform LDS byte address):
+// address = uniform base (SGPR pair) + this lane's 32-bit byte offset.  Inline asm on purpose -- the compiler must not
+// track these as LDS stores (it would drain vmcnt(0) before every later ds_read and the rings could never run ahead);
+// completion is waited for with counted vmcnt (dma_wait) before the barrier that publishes a stage.
+// (readfirstlane: the base pointer and the LDS address are wave-uniform, but must BE in SGPRs; s_nop 4: wait states between
+// the VALU-written SGPRs / m0 and the VMEM instruction -- inline asm is opaque to the hazard recognizer.  m0 is reserved and
+// cannot be named as a clobber; nothing else in this kernel uses it.)
+__device__ __forceinline__ void dma16(const void* gbase, unsigned voff, unsigned lds_addr) {
+    const unsigned long long pv = reinterpret_cast<unsigned long long>(gbase);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pv), hi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
+    const void* const sb = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+    const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(la) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void dma_wait() {   // all but the newest N vector-memory operations of this wave are done
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+// One workgroup per CU (the two 64-register result tiles + operands of a wave need more than the 256 registers that two
+// waves per SIMD would leave), so nothing but this workgroup's own prefetch hides HBM latency: both operand streams
+// run through LDS rings filled by LDS-DMA several steps ahead -- X chunks (128 px x 16 ch = 8 KB, from HBM) DX = 6
+// chunks ahead in an 8-slot ring, weight slices (C x 16, from L2) DW = 3 steps ahead in a 5-slot ring.  Roles by wave
+// (a wave's vmcnt completes in order: a wave waiting for a weight slice would wait for its younger X chunks too):
+// waves 0-1 fill the X ring, waves 2-3 the W ring; all four compute.  Rows are 64 B without padding; the 16-byte quads
+// of a row are XOR-swizzled with (row >> 2) & 3 on the DMA's SOURCE address and on the fragment reads (conflict-free
+// ds_read_b128), the LDS destination of a DMA stays lane-linear.
 template <int NU, bool BWD>
-__global__ __launch_bounds__(256, NU == 4 ? 1 : 2) void chain_kernel(const ChainK a) {
+__global__ __launch_bounds__(256, 1) void chain_kernel(const ChainK a) {
     constexpr int C = 32 * NU;
     constexpr int NR = C / CK;                    // steps of one register-operand GEMM (K = C)
     constexpr int NS = BWD ? 6 * NR : 3 * NR;     // steps per unit
     constexpr int NXC = 2 * NR;                   // X chunks per unit (two segments of C channels)
-    constexpr int NXLD = 2;                       // 128 px x 4 float4 / 256 threads
-    constexpr int NWLD = (C * 4 + 255) / 256;
-    constexpr int XBUF = NPX * RS, WBUF = C * RS;
-    __shared__ __attribute__((aligned(16))) float lds[2 * XBUF + 2 * WBUF + 2 * 8 + 5 * C];
+    constexpr int DX = 6, NXR = 8, DW = 3, NWR = 5;
+    constexpr int XSLOT = NPX * CK, WSLOT = C * CK;          // floats per ring slot
+    constexpr int NDX = 4;                        // DMA instructions (1 KB each) per X wave and chunk
+    constexpr int NDW = (C + 31) / 32;            // ... per W wave and slice (C = 32: one, issued by wave 2 only)
+    __shared__ __attribute__((aligned(16))) float lds[NXR * XSLOT + NWR * WSLOT + 2 * 8 + 5 * C];
     float* const Xb = lds;
-    float* const Wb = lds + 2 * XBUF;
-    SrcDev* const tab = reinterpret_cast<SrcDev*>(lds + 2 * XBUF + 2 * WBUF);
-    float* const img = lds + 2 * XBUF + 2 * WBUF + 2 * 8;     // [0] b_f | 0   [1] b_c | 0   [2] gamma   [3] beta   [4] zeros
+    float* const Wb = lds + NXR * XSLOT;
+    SrcDev* const tab = reinterpret_cast<SrcDev*>(lds + NXR * XSLOT + NWR * WSLOT);
+    float* const img = lds + NXR * XSLOT + NWR * WSLOT + 2 * 8;     // [0] b_f | 0   [1] b_c | 0   [2] gamma   [3] beta   [4] zeros
+    const unsigned xb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Xb;
+    const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Wb;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     if (tid < 2) tab[tid] = a.src[tid];
     for (int i = tid; i < 5 * C; i += 256) {
@@ -96,41 +126,43 @@ __global__ __launch_bounds__(256, NU == 4 ? 1 : 2) void chain_kernel(const Chain
         it.b = t / a.tiles_y;
         return it;
     };
-    const int q4 = (tid & 3) * 4;
 
-    // ---- X loader: chunks of 16 channels in consumption order; a unit has two segments of C channels
-    //      (fwd: s0 then s1 at batch b; bwd: dcentre at batch b then at batch b + n)
+    // ---- X ring loader (waves 0-1): chunks of 16 channels in consumption order; a unit has two segments of C channels
+    //      (fwd: s0 then s1 at batch b; bwd: dcentre at batch b then at batch b + n).  Instruction i of wave w covers the
+    //      16 pixels [(4w + i) * 16, +16) of the tile, 4 lanes per pixel row; lane (pixel p, position q') fetches quad
+    //      q' ^ ((p >> 2) & 3).  Pixels outside the image re-read the clamped edge pixel: their columns of the result are
+    //      never stored, and a pixel's column never mixes with another's.
+    const bool xrole = wave < 2;
     int xl_unit = t_first, xl_seg = 0, c_in = 0, xl_cnt = 0;
     UnitIt xl_it = decode(t_first);
     const float* sbase = nullptr;
-    int spix = 0;
-    int xpix[NXLD];
-    bool xok[NXLD];
+    int xpixq[NDX];               // pixel index of this lane's row per instruction (tile-dependent)
+    unsigned xvoff[NDX];          // byte offset from the segment's batch pointer (segment-dependent: pixel stride)
+    const int xq = ((lane & 3) ^ ((lane >> 4) & 3)) * 4;      // (p >> 2) & 3 with p = 16*(4w + i) + lane/4: bits 4-5 of lane
     auto seg_select = [&]() {
         const SrcDev S = tab[BWD ? 0 : xl_seg];
         sbase = src_batch_ptr(S, BWD ? xl_it.b + xl_seg * a.n : xl_it.b);
-        spix = S.pix_stride;
+#pragma unroll
+        for (int i = 0; i < NDX; ++i) xvoff[i] = (unsigned)(xpixq[i] * S.pix_stride + xq) * 4u;
     };
     auto xl_setup = [&]() {
         const int y0 = xl_it.ty * TH, x0 = xl_it.tx * TW;
 #pragma unroll
-        for (int n = 0; n < NXLD; ++n) {
-            const int hp = (tid + 256 * n) >> 2;
-            const int y = y0 + hp / TW, x = x0 + hp % TW;
-            xok[n] = y < a.H && x < a.W;
-            xpix[n] = y * a.W + x;
+        for (int i = 0; i < NDX; ++i) {
+            const int p = ((wave & 1) * NDX + i) * 16 + (lane >> 2);
+            int y = y0 + p / TW, x = x0 + p % TW;
+            y = y < a.H ? y : a.H - 1;
+            x = x < a.W ? x : a.W - 1;
+            xpixq[i] = y * a.W + x;
         }
         xl_seg = 0; c_in = 0;
         seg_select();
     };
-    f32x4 xr[NXLD], wr[NWLD];
-    auto load_x = [&]() {
-        const float* base = sbase + c_in + q4;
+    auto issue_x = [&]() {       // the next chunk of the stream -> ring slot xl_cnt % NXR
+        const float* base = sbase + c_in;
+        const unsigned dst = xb_lds + (unsigned)(((xl_cnt % NXR) * XSLOT + (wave & 1) * NDX * 256) * 4);
 #pragma unroll
-        for (int n = 0; n < NXLD; ++n) {
-            const float* src = xok[n] ? base + (long long)xpix[n] * spix : g_zero4c;
-            xr[n] = *reinterpret_cast<const f32x4*>(src);
-        }
+        for (int i = 0; i < NDX; ++i) dma16(base, xvoff[i], dst + i * 1024);
         ++xl_cnt;
         c_in += CK;
         if (c_in >= C) {
@@ -143,43 +175,38 @@ __global__ __launch_bounds__(256, NU == 4 ? 1 : 2) void chain_kernel(const Chain
             }
         }
     };
-    auto store_x = [&](int buf) {
+    // ---- W ring loader (waves 2-3): NS slices per unit, the same for every unit
+    const bool wrole_active = !xrole && (NDW * (wave & 1) * 16 < C);       // C = 32: wave 3 has nothing to load
+    int wl_step = 0, wl_cnt = 0;
+    unsigned wvoff[NDW];
 #pragma unroll
-        for (int n = 0; n < NXLD; ++n) {
-            const int hp = (tid + 256 * n) >> 2;
-            *reinterpret_cast<f32x4*>(Xb + buf * XBUF + hp * RS + q4) = xr[n];
-        }
-    };
-    // ---- W loader: NS slices per unit, the same for every unit
-    int wl_step = 0;
-    auto load_w = [&]() {
-        const float* p = a.w + (long long)wl_step * (C * CK);
+    for (int i = 0; i < NDW; ++i) {
+        const int row = ((wave & 1) * NDW + i) * 16 + (lane >> 2);
+        wvoff[i] = (unsigned)(row * 64 + (((lane & 3) ^ ((row >> 2) & 3)) * 16));
+    }
+    auto issue_w = [&]() {
+        const float* p = a.w + (long long)wl_step * WSLOT;
+        const unsigned dst = wb_lds + (unsigned)(((wl_cnt % NWR) * WSLOT + (wave & 1) * NDW * 256) * 4);
+        if (wrole_active) {
 #pragma unroll
-        for (int n = 0; n < NWLD; ++n) {
-            const int e = tid + 256 * n;
-            const int ec = (n + 1) * 256 <= C * 4 ? e : (e < C * 4 ? e : C * 4 - 1);
-            wr[n] = *reinterpret_cast<const f32x4*>(p + ec * 4);
+            for (int i = 0; i < NDW; ++i) dma16(p, wvoff[i], dst + i * 1024);
         }
+        ++wl_cnt;
         if (++wl_step == NS) wl_step = 0;
     };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int n = 0; n < NWLD; ++n) {
-            const int e = tid + 256 * n;
-            if ((n + 1) * 256 <= C * 4 || e < C * 4) *reinterpret_cast<f32x4*>(Wb + buf * WBUF + (e >> 2) * RS + q4) = wr[n];
-        }
-    };
 
-    // ---- fragments
-    const int aoff = ((2 * wave + (li >> 4)) * TW + (li & 15)) * RS + 4 * lh;
-    int boff[NU];
+    // ---- fragments: row p = 32*wave + li (pixels) / 32*u + li (weights); quad (2 kg + lh) ^ ((row >> 2) & 3)
+    const int sw = (li >> 2) & 3;
+    const int qoff0 = ((0 + lh) ^ sw) * 4, qoff1 = ((2 + lh) ^ sw) * 4;
+    const int arow = (32 * wave + li) * CK;
+    int brow[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) boff[u] = (32 * u + li) * RS + 4 * lh;
+    for (int u = 0; u < NU; ++u) brow[u] = (32 * u + li) * CK;
     f32x4 af0, af1, bf0[NU], bf1[NU];
-    auto read_a = [&](const float* xb, int kg, f32x4& af) { af = *reinterpret_cast<const f32x4*>(xb + aoff + 8 * kg); };
+    auto read_a = [&](const float* xb, int kg, f32x4& af) { af = *reinterpret_cast<const f32x4*>(xb + arow + (kg ? qoff1 : qoff0)); };
     auto read_b = [&](const float* wb, int kg, f32x4 (&bf)[NU]) {
 #pragma unroll
-        for (int u = 0; u < NU; ++u) bf[u] = *reinterpret_cast<const f32x4*>(wb + boff[u] + 8 * kg);
+        for (int u = 0; u < NU; ++u) bf[u] = *reinterpret_cast<const f32x4*>(wb + brow[u] + (kg ? qoff1 : qoff0));
     };
 
     f32x16 Ra[NU], Rt[NU], Rx[BWD ? NU : 1];
@@ -201,26 +228,38 @@ __global__ __launch_bounds__(256, NU == 4 ? 1 : 2) void chain_kernel(const Chain
     };
 
     // ---- pipeline state
-    int gs = 0;        // global step of this workgroup (W buffer parity)
-    int xc = 0;        // next X chunk to be consumed (its LDS buffer is xc & 1)
-    bool x_full;       // the X register slot holds a loaded, not yet stored chunk
+    int gs = 0;        // global step of this workgroup: its weight slice sits in ring slot gs % NWR
+    int xc = 0;        // next X chunk to be consumed: ring slot xc % NXR
+    // Loader half of a step (between the two MFMA halves, before the barrier that publishes the next stage): issue what
+    // lies D stages ahead, then wait until the NEXT stage's data has landed (everything but the D - 1 younger stages).
+    // x_step: this step consumed an X chunk (the X ring advances only then).
+    auto loader = [&](bool x_step) {
+        if (xrole) {
+            if (x_step && xl_cnt < total_xchunks) issue_x();
+            if (xl_cnt - (xc + (x_step ? 1 : 0)) >= DX) dma_wait<NDX * (DX - 1)>(); else dma_wait<0>();
+        } else {
+            if (wl_cnt < total_steps) issue_w();
+            if (wl_cnt - (gs + 1) >= DW) dma_wait<NDW * (DW - 1)>(); else dma_wait<0>();
+        }
+    };
+    auto publish = [&]() {      // raw barrier: no vmcnt(0) drain of the rings' prefetch (a __syncthreads() would)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
 
     // One step whose pixel operand comes from LDS (chunk xc).  next_lds: the following step also reads an X chunk.
     auto lds_step = [&](f32x16 (&acc)[NU], bool next_lds) {
         const bool has_next = gs + 1 < total_steps;
-        bool stored = false;
-        read_a(Xb + (xc & 1) * XBUF, 1, af1);
-        read_b(Wb + (gs & 1) * WBUF, 1, bf1);
-        if (has_next) store_w((gs + 1) & 1);
-        if (has_next && next_lds && x_full) { store_x((xc + 1) & 1); stored = true; }
+        read_a(Xb + (xc % NXR) * XSLOT, 1, af1);
+        read_b(Wb + (gs % NWR) * WSLOT, 1, bf1);
         mfma_lds(af0, bf0, acc);
-        __syncthreads();
+        loader(true);
+        publish();
         if (has_next) {
-            read_b(Wb + ((gs + 1) & 1) * WBUF, 0, bf0);
-            if (next_lds) read_a(Xb + ((xc + 1) & 1) * XBUF, 0, af0);
+            read_b(Wb + ((gs + 1) % NWR) * WSLOT, 0, bf0);
+            if (next_lds) read_a(Xb + ((xc + 1) % NXR) * XSLOT, 0, af0);
         }
-        if (gs + 2 < total_steps) load_w();
-        if (stored) { x_full = xl_cnt < total_xchunks; if (x_full) load_x(); }
         mfma_lds(af1, bf1, acc);
         ++gs; ++xc;
     };
@@ -231,22 +270,18 @@ __global__ __launch_bounds__(256, NU == 4 ? 1 : 2) void chain_kernel(const Chain
         for (int c = 0; c < NR; ++c) {
             const bool has_next = gs + 1 < total_steps;
             const bool nl = (c == NR - 1) && next_lds;
-            bool stored = false;
-            read_b(Wb + (gs & 1) * WBUF, 1, bf1);
-            if (has_next) store_w((gs + 1) & 1);
-            if (has_next && nl && x_full) { store_x(xc & 1); stored = true; }
+            read_b(Wb + (gs % NWR) * WSLOT, 1, bf1);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int u = 0; u < NU; ++u)
                     acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf0[u][j], op[c >> 1][4 * (2 * (c & 1) + 0) + j], acc[u], 0, 0, 0);
-            __syncthreads();
+            loader(false);
+            publish();
             if (has_next) {
-                read_b(Wb + ((gs + 1) & 1) * WBUF, 0, bf0);
-                if (nl) read_a(Xb + (xc & 1) * XBUF, 0, af0);
+                read_b(Wb + ((gs + 1) % NWR) * WSLOT, 0, bf0);
+                if (nl) read_a(Xb + (xc % NXR) * XSLOT, 0, af0);
             }
-            if (gs + 2 < total_steps) load_w();
-            if (stored) { x_full = xl_cnt < total_xchunks; if (x_full) load_x(); }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -281,16 +316,15 @@ __global__ __launch_bounds__(256, NU == 4 ? 1 : 2) void chain_kernel(const Chain
             }
     };
 
-    // ---- prologue
-    xl_setup();
-    load_x();
-    load_w();
-    store_x(0);
-    store_w(0);
-    if (total_steps > 1) load_w();
-    x_full = xl_cnt < total_xchunks;
-    if (x_full) load_x();
-    __syncthreads();
+    // ---- prologue: fill the rings DX / DW stages deep, publish stage 0
+    if (xrole) {
+        xl_setup();
+        for (int k = 0; k < DX && xl_cnt < total_xchunks; ++k) issue_x();
+    } else {
+        for (int k = 0; k < DW && wl_cnt < total_steps; ++k) issue_w();
+    }
+    dma_wait<0>();
+    publish();
     read_a(Xb, 0, af0);
     read_b(Wb, 0, bf0);
     init_acc(Ra, BWD ? 4 : 0);

@@ -25,6 +25,17 @@ __global__ void relu_bwd_kernel(const f32x4* __restrict__ dy, const f32x4* __res
     }
 }
 
+// ------------------------------------------------------------------ sum over batch groups
+// out[i] = sum_k in[k*n + i], fixed order: the gradient of an operand that several batch groups of a launch read
+// (batch_mod < B), e.g. the shared part of conv_fs (models/BMCNet.py:70-73).
+__global__ void group_sum_kernel(const f32x4* __restrict__ in, int groups, long long n4, f32x4* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 s = in[i];
+        for (int k = 1; k < groups; ++k) s += in[(long long)k * n4 + i];
+        out[i] = s;
+    }
+}
+
 // ------------------------------------------------------------------ column sums
 // stage 1: each block sums a contiguous pixel range per channel into ws[block][C];
 // stage 2: one block sums the partials (fixed order -> deterministic).
@@ -230,7 +241,14 @@ __global__ void pack_inputs_kernel(const float* __restrict__ x, long long sb, lo
 
 // ------------------------------------------------------------------ pixel (un)shuffle, NCHW HR <-> NHWC LR
 // LR channel index = c*r*r + i*r + j  <->  HR (c, y*r+i, x*r+j)
-__global__ void unshuffle_kernel(const float* __restrict__ hr, int B, int C, int H, int W, int r, float* __restrict__ lr) {
+// split = S > 1: the LR tensor is stored as S batch-stacked channel groups, [S*B][H][W][C*r*r/S] (group s of sample b at
+// batch s*B + b) -- the layout the multi-source convolutions read o[:, :s^2] / o[:, s^2:] in (models/BMCNet.py:63).
+__device__ __forceinline__ long long lr_index(int b, int y, int x, int ch, int B, int H, int W, int CC, int split) {
+    const int cg = CC / split, s = ch / cg, cw = ch - s * cg;
+    return ((((long long)s * B + b) * H + y) * W + x) * cg + cw;
+}
+__global__ void unshuffle_kernel(const float* __restrict__ hr, int B, int C, int H, int W, int r, float* __restrict__ lr,
+                                 int split) {
     const int CC = C * r * r;
     const long long total = (long long)B * H * W * CC;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -241,11 +259,11 @@ __global__ void unshuffle_kernel(const float* __restrict__ hr, int B, int C, int
         const int c = t % C;
         const int b = (int)(t / C);
         const int y = Y / r, i = Y - y * r, x = X / r, j = X - x * r;
-        lr[(((long long)b * H + y) * W + x) * CC + (c * r + i) * r + j] = hr[idx];
+        lr[lr_index(b, y, x, (c * r + i) * r + j, B, H, W, CC, split)] = hr[idx];
     }
 }
 __global__ void shuffle_kernel(const float* __restrict__ lr, int B, int C, int H, int W, int r, const float* __restrict__ base,
-                               long long sb, long long sc, long long sy, long long sx, float* __restrict__ hr) {
+                               long long sb, long long sc, long long sy, long long sx, float* __restrict__ hr, int split) {
     const int CC = C * r * r;
     const long long total = (long long)B * H * W * CC;
     const float inv = 1.f / r;
@@ -256,7 +274,7 @@ __global__ void shuffle_kernel(const float* __restrict__ lr, int B, int C, int H
         const int c = t % C;
         const int b = (int)(t / C);
         const int y = Y / r, i = Y - y * r, x = X / r, j = X - x * r;
-        float v = lr[(((long long)b * H + y) * W + x) * CC + (c * r + i) * r + j];
+        float v = lr[lr_index(b, y, x, (c * r + i) * r + j, B, H, W, CC, split)];
         if (base) {
             // F.interpolate(bilinear, align_corners=False): src = (dst+0.5)/r - 0.5 clamped at 0
             float fy = fmaxf((Y + 0.5f) * inv - 0.5f, 0.f), fx = fmaxf((X + 0.5f) * inv - 0.5f, 0.f);
@@ -270,6 +288,79 @@ __global__ void shuffle_kernel(const float* __restrict__ lr, int B, int C, int H
             v += top * (1.f - ly) + bot * ly;
         }
         hr[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------ head + MSE (models/BMCNet.py:119 + train.py:233)
+// forward: pred = pixel_shuffle(x_o) + bilinear(base) as shuffle_kernel, plus per-block partial sums of (pred - gt)^2
+// (fixed-order tree in LDS; mse_finish sums the partials in index order -> deterministic loss);
+// backward: d x_o = pixel_unshuffle(dpred + (2 dloss / numel) (pred - gt)) in one pass: the MSE gradient is never
+// materialised and never added by a separate kernel.
+__global__ void head_mse_fwd_kernel(const float* __restrict__ lr, int B, int C, int H, int W, int r, const float* __restrict__ base,
+                                    long long sb, long long sc, long long sy, long long sx, const float* __restrict__ gt,
+                                    long long gsb, float* __restrict__ hr, float* __restrict__ partials) {
+    const int CC = C * r * r;
+    const long long per_b = (long long)C * H * W * r * r, total = per_b * B;
+    const float inv = 1.f / r;
+    float acc = 0.f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int X = idx % (W * r);
+        long long t = idx / (W * r);
+        const int Y = t % (H * r); t /= (H * r);
+        const int c = t % C;
+        const int b = (int)(t / C);
+        const int y = Y / r, i = Y - y * r, x = X / r, j = X - x * r;
+        float v = lr[(((long long)b * H + y) * W + x) * CC + (c * r + i) * r + j];
+        float fy = fmaxf((Y + 0.5f) * inv - 0.5f, 0.f), fx = fmaxf((X + 0.5f) * inv - 0.5f, 0.f);
+        const int yy0 = (int)fy, xx0 = (int)fx;
+        const int yy1 = yy0 + 1 < H ? yy0 + 1 : H - 1, xx1 = xx0 + 1 < W ? xx0 + 1 : W - 1;
+        const float ly = fy - yy0, lx = fx - xx0;
+        const float* bp = base + b * sb + c * sc;
+        const float v00 = bp[yy0 * sy + xx0 * sx], v01 = bp[yy0 * sy + xx1 * sx];
+        const float v10 = bp[yy1 * sy + xx0 * sx], v11 = bp[yy1 * sy + xx1 * sx];
+        const float top = v00 * (1.f - lx) + v01 * lx, bot = v10 * (1.f - lx) + v11 * lx;
+        v += top * (1.f - ly) + bot * ly;
+        hr[idx] = v;
+        const float d = v - gt[(long long)b * gsb + (idx - (long long)b * per_b)];
+        acc += d * d;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+__global__ void mse_finish_kernel(const float* __restrict__ partials, int n, float scale, float* __restrict__ loss) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0] * scale;
+}
+__global__ void head_mse_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ gt,
+                                    long long gsb, const float* __restrict__ gloss, int B, int C, int H, int W, int r,
+                                    float* __restrict__ dlr) {
+    const int CC = C * r * r;
+    const long long per_b = (long long)C * H * W * r * r, total = per_b * B;
+    const float coef = gloss ? 2.f * gloss[0] / (float)total : 0.f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int X = idx % (W * r);
+        long long t = idx / (W * r);
+        const int Y = t % (H * r); t /= (H * r);
+        const int c = t % C;
+        const int b = (int)(t / C);
+        const int y = Y / r, i = Y - y * r, x = X / r, j = X - x * r;
+        float g = dpred ? dpred[idx] : 0.f;
+        if (gloss) g += coef * (pred[idx] - gt[(long long)b * gsb + (idx - (long long)b * per_b)]);
+        dlr[(((long long)b * H + y) * W + x) * CC + (c * r + i) * r + j] = g;
     }
 }
 
@@ -323,6 +414,14 @@ extern "C" int bmc_relu_bwd(const float* dy, const float* y, float* g, long long
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblocks(n / 4, 256 * 4)), dim3(256), 0, (hipStream_t)s,
                        (const f32x4*)dy, (const f32x4*)y, (f32x4*)g, n / 4);
     BMC_CHECK_LAUNCH("bmc_relu_bwd");
+    return 0;
+}
+
+extern "C" int bmc_group_sum(const float* in, int groups, long long n, float* out, bmc_stream_t s) {
+    BMC_CHECK_ARG(in && out && groups >= 1 && n % 4 == 0, "bmc_group_sum: n must be a multiple of 4");
+    hipLaunchKernelGGL(group_sum_kernel, dim3(nblocks(n / 4, 256 * 4)), dim3(256), 0, (hipStream_t)s, (const f32x4*)in, groups,
+                       n / 4, (f32x4*)out);
+    BMC_CHECK_LAUNCH("bmc_group_sum");
     return 0;
 }
 
@@ -391,18 +490,42 @@ extern "C" int bmc_pack_inputs(const float* x, long long sb, long long sc, long 
     return 0;
 }
 
-extern "C" int bmc_unshuffle_to_nhwc(const float* hr, int B, int C, int H, int W, int r, float* lr, bmc_stream_t s) {
+extern "C" int bmc_unshuffle_to_nhwc(const float* hr, int B, int C, int H, int W, int r, float* lr, int split, bmc_stream_t s) {
+    BMC_CHECK_ARG(split >= 1 && (C * r * r) % split == 0, "bmc_unshuffle_to_nhwc: split=%d must divide C*r*r", split);
     const long long n = (long long)B * C * H * W * r * r;
-    hipLaunchKernelGGL(unshuffle_kernel, dim3(nblocks(n, 256 * 4)), dim3(256), 0, (hipStream_t)s, hr, B, C, H, W, r, lr);
+    hipLaunchKernelGGL(unshuffle_kernel, dim3(nblocks(n, 256 * 4)), dim3(256), 0, (hipStream_t)s, hr, B, C, H, W, r, lr, split);
     BMC_CHECK_LAUNCH("bmc_unshuffle_to_nhwc");
     return 0;
 }
 extern "C" int bmc_shuffle_to_hr(const float* lr, int B, int C, int H, int W, int r, const float* base, long long sb,
-                                 long long sc, long long sy, long long sx, float* hr, bmc_stream_t s) {
+                                 long long sc, long long sy, long long sx, float* hr, int split, bmc_stream_t s) {
+    BMC_CHECK_ARG(split >= 1 && (C * r * r) % split == 0, "bmc_shuffle_to_hr: split=%d must divide C*r*r", split);
     const long long n = (long long)B * C * H * W * r * r;
     hipLaunchKernelGGL(shuffle_kernel, dim3(nblocks(n, 256 * 4)), dim3(256), 0, (hipStream_t)s, lr, B, C, H, W, r, base, sb,
-                       sc, sy, sx, hr);
+                       sc, sy, sx, hr, split);
     BMC_CHECK_LAUNCH("bmc_shuffle_to_hr");
+    return 0;
+}
+
+extern "C" int bmc_head_mse_fwd(const float* lr, int B, int C, int H, int W, int r, const float* base, long long sb,
+                                long long sc, long long sy, long long sx, const float* gt, long long gt_batch_stride, float* hr,
+                                float* partials, float* loss, bmc_stream_t s) {
+    BMC_CHECK_ARG(lr && base && gt && hr && partials && loss, "bmc_head_mse_fwd: null pointer");
+    const long long n = (long long)B * C * H * W * r * r;
+    const int nb = nblocks(n, 256 * 4);      // <= 2048 partials
+    hipLaunchKernelGGL(head_mse_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, lr, B, C, H, W, r, base, sb, sc, sy, sx, gt,
+                       gt_batch_stride, hr, partials);
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, partials, nb, 1.f / (float)n, loss);
+    BMC_CHECK_LAUNCH("bmc_head_mse_fwd");
+    return 0;
+}
+extern "C" int bmc_head_mse_bwd(const float* dpred, const float* pred, const float* gt, long long gt_batch_stride,
+                                const float* gloss, int B, int C, int H, int W, int r, float* dlr, bmc_stream_t s) {
+    BMC_CHECK_ARG(dlr && (dpred || gloss) && (!gloss || (pred && gt)), "bmc_head_mse_bwd: bad arguments");
+    const long long n = (long long)B * C * H * W * r * r;
+    hipLaunchKernelGGL(head_mse_bwd_kernel, dim3(nblocks(n, 256 * 4)), dim3(256), 0, (hipStream_t)s, dpred, pred, gt,
+                       gt_batch_stride, gloss, B, C, H, W, r, dlr);
+    BMC_CHECK_LAUNCH("bmc_head_mse_bwd");
     return 0;
 }
 

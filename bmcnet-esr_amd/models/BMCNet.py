@@ -116,12 +116,16 @@ class Backbone(nn.Module):
         n_layers = len(self.para_reschunk)
         for i, layer in enumerate(self.para_reschunk):      # x*_st of the last block is never read: skip what only feeds it
             s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12, need_st=i + 1 < n_layers)
-        x_h = ops.conv([View(xs)], self.conv_hs.weight, self.conv_hs.bias, self._sp_h, relu=True)
+        # the three new states go into ONE buffer [x_h; x_h_p; x_h_n]: the next window reads them as h3 without a copy
+        # (ops.stack_states recognises the adjacent views)
+        hbuf = torch.empty((3 * B,) + tuple(xs.shape[1:]), device=xs.device, dtype=xs.dtype)
+        x_h = ops.conv([View(xs)], self.conv_hs.weight, self.conv_hs.bias, self._sp_h, relu=True, out=ops.OutSlot(hbuf, 0))
         hw = torch.stack([self.conv_hp.weight, self.conv_hn.weight])
         hb = torch.stack([self.conv_hp.bias, self.conv_hn.bias])
-        x_hpn = ops.conv([View(sst12)], hw, hb, self._sp_h, relu=True, G=2, cache=False)
+        x_hpn = ops.conv([View(sst12)], hw, hb, self._sp_h, relu=True, G=2, cache=False, out=ops.OutSlot(hbuf, B))
+        x_hp, x_hn = bie.Unstack2Fn.apply(x_hpn)
         x_o = ops.conv([View(s12, b0=0), View(s12, b0=B)], self.conv_o.weight, self.conv_o.bias, self._sp_o, B=B)
-        return x_h, x_hpn[:B], x_hpn[B:], x_o
+        return x_h, x_hp, x_hn, x_o
 
     def forward(self, xs, hp, hn, hs, o):
         """NCHW interface of the reference (xs = [x1p, x1n, x2p, x2n], 3 repeated channels each)."""
@@ -146,17 +150,29 @@ class BMCNet(nn.Module):
         self.down = PixelUnShuffle(scale)
         self.repeat = repeat
 
-    def forward(self, x, x_h, x_h_p, x_h_n, x_o, init):
+    def forward_loss(self, x, x_h, x_h_p, x_h_n, x_o, init, gt):
+        """forward() + nn.MSELoss()(prediction, gt) with the loss computed by the head kernel (one pass over the HR
+        tensor forward, the loss gradient folded into the head's backward): -> (x_h, x_h_p, x_h_n, prediction, mse).
+        gt must have the prediction's size (otherwise use forward() + bicubic resize, train.py:227-231)."""
+        return self.forward(x, x_h, x_h_p, x_h_n, x_o, init, _gt=gt)
+
+    def forward(self, x, x_h, x_h_p, x_h_n, x_o, init, _gt=None):
         """x [B,2,T>=2,H,W]; x_h/x_h_p/x_h_n [B,n_c,H,W]; x_o [B,2*s*s,H,W] if init else the previous HR
         prediction [B,2,sH,sW]; returns (x_h, x_h_p, x_h_n, prediction [B,2,sH,sW])."""
         B = x.shape[0]
         s2 = self.scale ** 2
         xin12 = ops.pack_inputs(x, self.repeat)
-        on = to_nhwc(x_o) if init else ops.pixel_unshuffle_nhwc(x_o, self.scale)
-        o12 = torch.cat([on[..., :s2], on[..., s2:]], 0)
+        if init:
+            on = to_nhwc(x_o)
+            o12 = torch.cat([on[..., :s2], on[..., s2:]], 0)
+        else:       # the previous HR prediction, unshuffled straight into the batch-stacked channel halves
+            o12 = ops.pixel_unshuffle_nhwc(x_o, self.scale, split=2)
         # the reference passes (x_h, x_h_p, x_h_n) positionally into Backbone.forward(xs, hp, hn, hs, o)
         # (models/BMCNet.py:115,118 vs :57): x_h acts as hp, x_h_p as hn, x_h_n as hs.
-        h3 = torch.cat([to_nhwc(x_h), to_nhwc(x_h_p), to_nhwc(x_h_n)], 0)
+        h3 = ops.stack_states([x_h, x_h_p, x_h_n])
         n_h, n_hp, n_hn, o = self.neuro.forward_nhwc(xin12, h3, o12)
+        if _gt is not None:
+            pred, mse = ops.head_mse(o, x[:, :, 1], _gt, self.scale)
+            return to_nchw(n_h), to_nchw(n_hp), to_nchw(n_hn), pred, mse
         pred = ops.head(o, x[:, :, 1], self.scale)
         return to_nchw(n_h), to_nchw(n_hp), to_nchw(n_hn), pred

@@ -65,10 +65,20 @@ class BMCNet_plain(nn.Module):
         self.down = PixelUnShuffle(scale)
         self.repeat = repeat
 
-    def forward(self, x, x_h, x_o, init):
+    def forward_loss(self, x, x_h, x_o, init, gt):
+        """forward() + nn.MSELoss()(prediction, gt) computed by the head kernel -> (x_h, prediction, mse)."""
+        return self.forward(x, x_h, x_o, init, _gt=gt)
+
+    def forward(self, x, x_h, x_o, init, _gt=None):
         s2 = self.scale ** 2
         xin12 = ops.pack_inputs(x, self.repeat)
-        on = to_nhwc(x_o) if init else ops.pixel_unshuffle_nhwc(x_o, self.scale)
-        o12 = torch.cat([on[..., :s2], on[..., s2:]], 0)
+        if init:
+            on = to_nhwc(x_o)
+            o12 = torch.cat([on[..., :s2], on[..., s2:]], 0)
+        else:
+            o12 = ops.pixel_unshuffle_nhwc(x_o, self.scale, split=2)
         n_h, o = self.neuro.forward_nhwc(xin12, to_nhwc(x_h), o12)
+        if _gt is not None:
+            pred, mse = ops.head_mse(o, x[:, :, 1], _gt, self.scale)
+            return to_nchw(n_h), pred, mse
         return to_nchw(n_h), ops.head(o, x[:, :, 1], self.scale)

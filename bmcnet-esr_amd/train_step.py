@@ -64,21 +64,25 @@ def bptt_step(model, optimizer, inp_cnt, gt_cnt, n_c, scale, seqn=2, plain=False
     for i in range(L - seqn + 1):
         x = inp_cnt[:, i:i + seqn].transpose(1, 2)          # [B,2(pol),seqn,H,W]   (train.py:211)
         gt = gt_cnt[:, i + 1]                                # (train.py:213)
+        # nn.MSELoss on a prediction of the ground truth's size: head + loss in one kernel pass (models.*.forward_loss)
+        fused = loss_fn is F.mse_loss and hasattr(model, "forward_loss") and tuple(gt.shape[-2:]) == (scale * H, scale * W)
+        fn = model.forward_loss if fused else model
+        extra = (gt,) if fused else ()
         if init:
-            if plain:
-                h, pred = model(x, z(n_c), z(2 * scale * scale), True)
-            else:
-                h, hp, hn, pred = model(x, z(n_c), z(n_c), z(n_c), z(2 * scale * scale), True)
+            state = (z(n_c), z(2 * scale * scale)) if plain else (z(n_c), z(n_c), z(n_c), z(2 * scale * scale))
+            out = fn(x, *state, True, *extra)
             init = False
-        elif plain:
-            h, pred = checkpoint(model, x, h, pred, False, use_reentrant=False) if recompute else model(x, h, pred, False)
         elif recompute:
-            h, hp, hn, pred = checkpoint(model, x, h, hp, hn, pred, False, use_reentrant=False)
+            out = checkpoint(fn, x, *state, False, *extra, use_reentrant=False)
         else:
-            h, hp, hn, pred = model(x, h, hp, hn, pred, False)
-        # size-mismatch branch of train.py:227-231 (EventZoom: 124x224 prediction vs 124x222 ground truth); the
-        # UNRESIZED prediction is what recurs into the next window (train.py:224)
-        mse = loss_fn(ops.bicubic_resize(pred, gt.shape[-2:]), gt)
+            out = fn(x, *state, False, *extra)
+        if fused:
+            state, mse = tuple(out[:-1]), out[-1]
+        else:
+            state = tuple(out)
+            # size-mismatch branch of train.py:227-231 (EventZoom: 124x224 prediction vs 124x222 ground truth); the
+            # UNRESIZED prediction is what recurs into the next window (train.py:224)
+            mse = loss_fn(ops.bicubic_resize(state[-1], gt.shape[-2:]), gt)
         loss = loss + mse
     loss.backward()
     optimizer.step()

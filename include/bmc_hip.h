@@ -166,6 +166,8 @@ int bmc_pgemm_reduce_plain(const float* slabs, int nsplit, int G, int M, int N, 
                            float* out, bmc_stream_t s);
 
 /* ---- streaming kernels ---------------------------------------------------*/
+/* out[i] = sum_{k < groups} in[k*n + i] (fixed order): gradient of an operand shared by several batch groups of a launch */
+int bmc_group_sum(const float* in, int groups, long long n, float* out, bmc_stream_t s);
 /* column sums over pixels (bias gradients): out[c] (+)= sum_p x[p*pix_stride + c]; ws >= 2048*C floats */
 int bmc_colsum(const float* x, long long npix, int pix_stride, int C, float* ws, float* out,
                int accumulate, bmc_stream_t s);
@@ -192,13 +194,27 @@ int bmc_softmax_bwd(const float* p, const float* dp, long long rows, int C, floa
 int bmc_pack_inputs(const float* x, long long sb, long long sc, long long st, long long sy, long long sx,
                     int B, int H, int W, int repeat, float* xin_p, float* xin_n, bmc_stream_t s);
 /* HR NCHW [B,C,rH,rW] -> LR NHWC [B,H,W,C*r*r] (pixel_unshuffle, models/submodules.py:80-92;
- * also the backward of the head).  */
-int bmc_unshuffle_to_nhwc(const float* hr, int B, int C, int H, int W, int r, float* lr, bmc_stream_t s);
+ * also the backward of the head).  split = S > 1 stores the LR tensor as S batch-stacked channel groups
+ * [S*B][H][W][C*r*r/S] (group s of sample b at batch s*B + b): with S = 2 that is [o[:, :s^2]; o[:, s^2:]], the operand
+ * layout of the input-fusion convolutions (models/BMCNet.py:63) -- no torch.cat between the two.  */
+int bmc_unshuffle_to_nhwc(const float* hr, int B, int C, int H, int W, int r, float* lr, int split, bmc_stream_t s);
 /* LR NHWC [B,H,W,C*r*r] -> HR NCHW [B,C,rH,rW] (+ bilinear x r of base[B,C,H,W] given with strides
  * (sb,sc,sy,sx), align_corners=False) -- F.pixel_shuffle + F.interpolate + add, models/BMCNet.py:119;
  * base NULL -> pure shuffle (backward of pixel_unshuffle). */
 int bmc_shuffle_to_hr(const float* lr, int B, int C, int H, int W, int r, const float* base,
-                      long long sb, long long sc, long long sy, long long sx, float* hr, bmc_stream_t s);
+                      long long sb, long long sc, long long sy, long long sx, float* hr, int split /* as above */,
+                      bmc_stream_t s);
+
+/* Head + loss of one window in one pass: pred = pixel_shuffle(x_o, r) + bilinear(base) (models/BMCNet.py:119) written to hr
+ * [B,C,rH,rW], and loss[0] = mean((pred - gt)^2) (nn.MSELoss, train.py:233,647) from per-block partial sums
+ * (partials: >= 2048 floats of workspace; fixed-order reduction).  gt: [B][C][rH][rW] with batch stride gt_batch_stride. */
+int bmc_head_mse_fwd(const float* lr, int B, int C, int H, int W, int r, const float* base, long long sb, long long sc,
+                     long long sy, long long sx, const float* gt, long long gt_batch_stride, float* hr, float* partials,
+                     float* loss, bmc_stream_t s);
+/* Its backward: dlr [B,H,W,C*r*r] = pixel_unshuffle(dpred + (2 gloss[0] / numel) (pred - gt)); dpred NULL = no gradient
+ * from the next window, gloss (DEVICE scalar) NULL = no gradient from the loss. */
+int bmc_head_mse_bwd(const float* dpred, const float* pred, const float* gt, long long gt_batch_stride, const float* gloss,
+                     int B, int C, int H, int W, int r, float* dlr, bmc_stream_t s);
 
 /* ---- fused "centre" chain of the BIE block ----------------------------------
  * forward: centre = clustering(LayerNorm2d(convf(cat[s0, s1])))  -- models/submodules.py:63-64 with LayerNormFunction

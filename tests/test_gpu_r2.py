@@ -203,8 +203,11 @@ def test_config3_eventzoom_shape_fp32_and_bf16():
                 errs.append(max(rel_l2(a, b) for a, b in zip(st[:3], states_ref)))       # final hidden states (no bilinear base in them)
             loss = loss + F.mse_loss(ops.bicubic_resize(st[-1], (gh, gw)), gts[i].to(dev))
         loss.backward()
-        gerr = max(rel_l2(p.grad, params[n].grad) for n, p in m.named_parameters() if params[n].grad is not None)
-        return loss.item(), errs, gerr
+        named = [(n, p) for n, p in m.named_parameters() if params[n].grad is not None]
+        gerr = max(rel_l2(p.grad, params[n].grad) for n, p in named)
+        flat = lambda ts: torch.cat([t.detach().double().cpu().reshape(-1) for t in ts])
+        ga, gb = flat([p.grad for _, p in named]), flat([params[n].grad for n, _ in named])
+        return loss.item(), errs, (gerr, ((ga - gb).norm() / gb.norm()).item())
 
     l32, e32, g32 = run("fp32")
     print("config3 fp32: SR rel-L2 per window (+ final states)", ["%.1e" % e for e in e32], "grad (worst tensor, whole vector)", g32)
