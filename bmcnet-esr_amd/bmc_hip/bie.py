@@ -34,8 +34,8 @@ def chain_supported(Cn):
 
 def _chain_streams(wf, wc, Cn):
     """Weight streams of bmc_chain_fwd / bmc_chain_bwd for (convf.weight, clustering.weight), cached per parameter
-    version: the forward stream is pack(W_f) | pack(W_c); the backward stream is T(W_c) T1(W_f) T0(W_f) T(W_c) T0(W_f)
-    T1(W_f) (include/bmc_hip.h)."""
+    version: the forward stream is pack(W_f) | pack(W_c); the backward stream is T(W_c) T(W_c) T1(W_f) T1(W_f) T0(W_f)
+    (include/bmc_hip.h)."""
     key = (id(wf), id(wc))
     hit = _CHAIN_CACHE.get(key)
     if hit is not None and hit[0]() is wf and hit[1]() is wc and hit[2] == (wf._version, wc._version):
@@ -59,7 +59,7 @@ def _chain_streams(wf, wc, Cn):
     wfd, wcd = wf.detach().contiguous(), wc.detach().contiguous()
     fwd = torch.cat([pack(wfd, s2, 2 * Cn), pack(wcd, s1, Cn)])
     tc, t0, t1 = pack_t(wcd, s1, Cn, 0), pack_t(wfd, s2, 2 * Cn, 0), pack_t(wfd, s2, 2 * Cn, 1)
-    bwd = torch.cat([tc, t1, t0, tc, t0, t1])
+    bwd = torch.cat([tc, tc, t1, t1, t0])
     if len(_CHAIN_CACHE) > 64:
         for k in [k for k, v in _CHAIN_CACHE.items() if v[0]() is None or v[1]() is None]:
             del _CHAIN_CACHE[k]

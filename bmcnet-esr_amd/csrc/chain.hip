@@ -28,10 +28,15 @@
 // LayerNorm affine gradients follow algebraically from its results (bmc_chain_affine_grads below).
 #include "bmc_common.h"
 
+#ifndef BMC_CHAIN_ABL
+#define BMC_CHAIN_ABL 0     // ablation bits for tools/ builds only: 1 no MFMAs, 2 no DMA issue, 4 no global stores,
+                            // 8 no LayerNorm math, 16 no barriers, 32 no fragment reads, 64 no DMA waits
+#endif
+
 namespace {
 
 constexpr int CK = BMC_CK;
-constexpr int TW = 16, TH = 8, NPX = TW * TH;
+constexpr int TW = 16, TH = 4, NPX = TW * TH;      // workgroup tile: 4 rows x 16 pixels, one row per wave
 __device__ __attribute__((aligned(16))) const float g_zero4c[4] = {0.f, 0.f, 0.f, 0.f};
 
 struct ChainK {
@@ -70,24 +75,32 @@ __device__ __forceinline__ void dma_wait() {   // all but the newest N vector-me
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
 
-// One workgroup per CU (the two 64-register result tiles + operands of a wave need more than the 256 registers that two
-// waves per SIMD would leave), so nothing but this workgroup's own prefetch hides HBM latency: both operand streams
-// run through LDS rings filled by LDS-DMA several steps ahead -- X chunks (128 px x 16 ch = 8 KB, from HBM) DX = 6
-// chunks ahead in an 8-slot ring, weight slices (C x 16, from L2) DW = 3 steps ahead in a 5-slot ring.  Roles by wave
-// (a wave's vmcnt completes in order: a wave waiting for a weight slice would wait for its younger X chunks too):
-// waves 0-1 fill the X ring, waves 2-3 the W ring; all four compute.  Rows are 64 B without padding; the 16-byte quads
-// of a row are XOR-swizzled with (row >> 2) & 3 on the DMA's SOURCE address and on the fragment reads (conflict-free
-// ds_read_b128), the LDS destination of a DMA stays lane-linear.
-template <int NU, bool BWD>
-__global__ __launch_bounds__(256, 1) void chain_kernel(const ChainK a) {
-    constexpr int C = 32 * NU;
-    constexpr int NR = C / CK;                    // steps of one register-operand GEMM (K = C)
-    constexpr int NS = BWD ? 6 * NR : 3 * NR;     // steps per unit
+// Two (or more) independent workgroups per CU hide each other's LayerNorm / epilogue / barrier phases (a first version
+// with 32x32x2 MFMAs needed 128 accumulator registers per lane for its two result tiles = one workgroup per CU, and ran
+// its matrix pipes only 60 % busy: every non-MFMA instruction of the single wave per SIMD was exposed).  Both operand
+// streams run through LDS rings filled by LDS-DMA several steps ahead -- X chunks (64 px x 16 ch = 4 KB, from HBM) DX
+// chunks ahead, weight slices (C x 16, from L2) DW steps ahead.  Roles by wave (a wave's vmcnt completes in order: a
+// wave waiting for a weight slice would wait for its younger X chunks too): waves 0-1 fill the X ring, waves 2-3 the W
+// ring; all four compute.  Rows are 64 B without padding; the 16-byte quads of a row are XOR-swizzled with
+// SWZ[(row >> 2) & 3] on the DMA's SOURCE address and on the fragment reads (conflict-free ds_read_b128 for the
+// 16-row x 4-quad fragment shape), the LDS destination of a DMA stays lane-linear.
+__device__ __forceinline__ int swz(int row) { return (0x1320 >> (4 * ((row >> 2) & 3))) & 3; }      // {0, 2, 3, 1}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    if (BMC_CHAIN_ABL & 1) { c[0] += a * b; return c; }      // ablation: one VALU fma instead, operands stay live
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int NT, bool BWD>
+__global__ __launch_bounds__(256, 2) void chain_kernel(const ChainK a) {
+    constexpr int C = 16 * NT;
+    constexpr int NR = NT;                        // steps of one register-operand GEMM (K = C, 16 per step)
+    constexpr int NS = BWD ? 5 * NR : 3 * NR;     // steps per unit
     constexpr int NXC = 2 * NR;                   // X chunks per unit (two segments of C channels)
     constexpr int DX = 6, NXR = 8, DW = 3, NWR = 5;
     constexpr int XSLOT = NPX * CK, WSLOT = C * CK;          // floats per ring slot
-    constexpr int NDX = 4;                        // DMA instructions (1 KB each) per X wave and chunk
-    constexpr int NDW = (C + 31) / 32;            // ... per W wave and slice (C = 32: one, issued by wave 2 only)
+    constexpr int NDX = NPX / 32;                 // DMA instructions (16 rows = 1 KB each) per X wave and chunk
+    constexpr int NDW = (C + 31) / 32;            // ... per W wave and slice
     __shared__ __attribute__((aligned(16))) float lds[NXR * XSLOT + NWR * WSLOT + 2 * 8 + 5 * C];
     float* const Xb = lds;
     float* const Wb = lds + NXR * XSLOT;
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainK a) {
     const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Wb;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
+    const int lp = lane & 15, lg = lane >> 4;     // pixel of the wave's row / channel quad: D rows 4*lg .. 4*lg+3
     if (tid < 2) tab[tid] = a.src[tid];
     for (int i = tid; i < 5 * C; i += 256) {
         const int k = i / C, c = i - k * C;
@@ -128,17 +141,17 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainK a) {
     };
 
     // ---- X ring loader (waves 0-1): chunks of 16 channels in consumption order; a unit has two segments of C channels
-    //      (fwd: s0 then s1 at batch b; bwd: dcentre at batch b then at batch b + n).  Instruction i of wave w covers the
-    //      16 pixels [(4w + i) * 16, +16) of the tile, 4 lanes per pixel row; lane (pixel p, position q') fetches quad
-    //      q' ^ ((p >> 2) & 3).  Pixels outside the image re-read the clamped edge pixel: their columns of the result are
-    //      never stored, and a pixel's column never mixes with another's.
+    //      (fwd: s0 then s1 at batch b; bwd: dcentre at batch b then at batch b + n).  Instruction i of X wave w covers the
+    //      16 tile pixels [(NDX w + i) * 16, +16) = tile row NDX w + i, 4 lanes per pixel row; lane (pixel p, position q')
+    //      fetches quad q' ^ swz(p).  Pixels outside the image re-read the clamped edge pixel: their columns of the result
+    //      are never stored, and a pixel's column never mixes with another's.
     const bool xrole = wave < 2;
     int xl_unit = t_first, xl_seg = 0, c_in = 0, xl_cnt = 0;
     UnitIt xl_it = decode(t_first);
     const float* sbase = nullptr;
     int xpixq[NDX];               // pixel index of this lane's row per instruction (tile-dependent)
     unsigned xvoff[NDX];          // byte offset from the segment's batch pointer (segment-dependent: pixel stride)
-    const int xq = ((lane & 3) ^ ((lane >> 4) & 3)) * 4;      // (p >> 2) & 3 with p = 16*(4w + i) + lane/4: bits 4-5 of lane
+    const int xq = ((lane & 3) ^ swz(lane >> 2)) * 4;         // row index within the instruction = lane / 4
     auto seg_select = [&]() {
         const SrcDev S = tab[BWD ? 0 : xl_seg];
         sbase = src_batch_ptr(S, BWD ? xl_it.b + xl_seg * a.n : xl_it.b);
@@ -149,8 +162,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainK a) {
         const int y0 = xl_it.ty * TH, x0 = xl_it.tx * TW;
 #pragma unroll
         for (int i = 0; i < NDX; ++i) {
-            const int p = ((wave & 1) * NDX + i) * 16 + (lane >> 2);
-            int y = y0 + p / TW, x = x0 + p % TW;
+            int y = y0 + (wave & 1) * NDX + i, x = x0 + (lane >> 2);
             y = y < a.H ? y : a.H - 1;
             x = x < a.W ? x : a.W - 1;
             xpixq[i] = y * a.W + x;
@@ -162,7 +174,8 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainK a) {
         const float* base = sbase + c_in;
         const unsigned dst = xb_lds + (unsigned)(((xl_cnt % NXR) * XSLOT + (wave & 1) * NDX * 256) * 4);
 #pragma unroll
-        for (int i = 0; i < NDX; ++i) dma16(base, xvoff[i], dst + i * 1024);
+        for (int i = 0; i < NDX; ++i)
+            if (!(BMC_CHAIN_ABL & 2)) dma16(base, xvoff[i], dst + i * 1024);
         ++xl_cnt;
         c_in += CK;
         if (c_in >= C) {
@@ -176,144 +189,148 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainK a) {
         }
     };
     // ---- W ring loader (waves 2-3): NS slices per unit, the same for every unit
-    const bool wrole_active = !xrole && (NDW * (wave & 1) * 16 < C);       // C = 32: wave 3 has nothing to load
     int wl_step = 0, wl_cnt = 0;
     unsigned wvoff[NDW];
+    bool wact[NDW];
 #pragma unroll
     for (int i = 0; i < NDW; ++i) {
         const int row = ((wave & 1) * NDW + i) * 16 + (lane >> 2);
-        wvoff[i] = (unsigned)(row * 64 + (((lane & 3) ^ ((row >> 2) & 3)) * 16));
+        wact[i] = ((wave & 1) * NDW + i) * 16 < C;
+        wvoff[i] = (unsigned)(row * 64 + (((lane & 3) ^ swz(row)) * 16));
     }
     auto issue_w = [&]() {
         const float* p = a.w + (long long)wl_step * WSLOT;
         const unsigned dst = wb_lds + (unsigned)(((wl_cnt % NWR) * WSLOT + (wave & 1) * NDW * 256) * 4);
-        if (wrole_active) {
 #pragma unroll
-            for (int i = 0; i < NDW; ++i) dma16(p, wvoff[i], dst + i * 1024);
-        }
+        for (int i = 0; i < NDW; ++i)
+            if (wact[i] && !(BMC_CHAIN_ABL & 2)) dma16(p, wvoff[i], dst + i * 1024);
         ++wl_cnt;
         if (++wl_step == NS) wl_step = 0;
     };
 
-    // ---- fragments: row p = 32*wave + li (pixels) / 32*u + li (weights); quad (2 kg + lh) ^ ((row >> 2) & 3)
-    const int sw = (li >> 2) & 3;
-    const int qoff0 = ((0 + lh) ^ sw) * 4, qoff1 = ((2 + lh) ^ sw) * 4;
-    const int arow = (32 * wave + li) * CK;
-    int brow[NU];
+    // ---- fragments: pixel row 16*wave + lp / weight row 16*t + lp; this lane's quad lg, swizzled by the row
+    const int qoff = (lg ^ swz(lp)) * 4;          // (16*wave + lp) and (16*t + lp) have the same (row >> 2) & 3
+    const int arow = (16 * wave + lp) * CK + qoff;
+    const int brow = lp * CK + qoff;              // + 16*t rows
+    f32x4 afA, afB, bfA[NT], bfB[NT];             // two fragment sets: the next step's reads fly under this step's MFMAs
+    auto read_a = [&](const float* xb, f32x4& af) {
+        if (BMC_CHAIN_ABL & 32) { af = f32x4{1.f, 2.f, 3.f, 4.f}; asm volatile("" : "+v"(af)); return; }
+        af = *reinterpret_cast<const f32x4*>(xb + arow);
+    };
+    auto read_b = [&](const float* wb, f32x4 (&bf)[NT]) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) brow[u] = (32 * u + li) * CK;
-    f32x4 af0, af1, bf0[NU], bf1[NU];
-    auto read_a = [&](const float* xb, int kg, f32x4& af) { af = *reinterpret_cast<const f32x4*>(xb + arow + (kg ? qoff1 : qoff0)); };
-    auto read_b = [&](const float* wb, int kg, f32x4 (&bf)[NU]) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u) bf[u] = *reinterpret_cast<const f32x4*>(wb + brow[u] + (kg ? qoff1 : qoff0));
+        for (int t = 0; t < NT; ++t) {
+            if (BMC_CHAIN_ABL & 32) { bf[t] = f32x4{1.f, 2.f, 3.f, 4.f}; asm volatile("" : "+v"(bf[t])); continue; }
+            bf[t] = *reinterpret_cast<const f32x4*>(wb + brow + 16 * t * CK);
+        }
     };
 
-    f32x16 Ra[NU], Rt[NU], Rx[BWD ? NU : 1];
-    auto init_acc = [&](f32x16 (&R)[NU], int which) {
+    f32x4 Ra[NT], Rt[NT], Rz[BWD ? NT : 1];
+    auto init_acc = [&](f32x4 (&R)[NT], int which) {
 #pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(img + which * C + 32 * u + 8 * rq + 4 * lh);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) R[u][4 * rq + k] = v[k];
-            }
-    };
-    auto mfma_lds = [&](const f32x4& af, const f32x4 (&bf)[NU], f32x16 (&acc)[NU]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int u = 0; u < NU; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[u][j], af[j], acc[u], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) R[t] = *reinterpret_cast<const f32x4*>(img + which * C + 16 * t + 4 * lg);
     };
 
     // ---- pipeline state
     int gs = 0;        // global step of this workgroup: its weight slice sits in ring slot gs % NWR
     int xc = 0;        // next X chunk to be consumed: ring slot xc % NXR
-    // Loader half of a step (between the two MFMA halves, before the barrier that publishes the next stage): issue what
-    // lies D stages ahead, then wait until the NEXT stage's data has landed (everything but the D - 1 younger stages).
-    // x_step: this step consumed an X chunk (the X ring advances only then).
+    // Loader part of a step (before the barrier that publishes the next stage): issue what lies D stages ahead, then
+    // wait until the NEXT stage's data has landed (everything but the D - 1 younger stages).  x_step: this step consumed
+    // an X chunk (the X ring advances only then).
     auto loader = [&](bool x_step) {
         if (xrole) {
             if (x_step && xl_cnt < total_xchunks) issue_x();
-            if (xl_cnt - (xc + (x_step ? 1 : 0)) >= DX) dma_wait<NDX * (DX - 1)>(); else dma_wait<0>();
+            if (BMC_CHAIN_ABL & 64) {}
+            else if (xl_cnt - (xc + (x_step ? 1 : 0)) >= DX) dma_wait<NDX * (DX - 1)>(); else dma_wait<0>();
         } else {
             if (wl_cnt < total_steps) issue_w();
-            if (wl_cnt - (gs + 1) >= DW) dma_wait<NDW * (DW - 1)>(); else dma_wait<0>();
+            if (BMC_CHAIN_ABL & 64) {}
+            else if (wl_cnt - (gs + 1) >= DW) dma_wait<NDW * (DW - 1)>(); else dma_wait<0>();
         }
     };
     auto publish = [&]() {      // raw barrier: no vmcnt(0) drain of the rings' prefetch (a __syncthreads() would)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(BMC_CHAIN_ABL & 16)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
 
-    // One step whose pixel operand comes from LDS (chunk xc).  next_lds: the following step also reads an X chunk.
-    auto lds_step = [&](f32x16 (&acc)[NU], bool next_lds) {
-        const bool has_next = gs + 1 < total_steps;
-        read_a(Xb + (xc % NXR) * XSLOT, 1, af1);
-        read_b(Wb + (gs % NWR) * WSLOT, 1, bf1);
-        mfma_lds(af0, bf0, acc);
-        loader(true);
-        publish();
-        if (has_next) {
-            read_b(Wb + ((gs + 1) % NWR) * WSLOT, 0, bf0);
-            if (next_lds) read_a(Xb + ((xc + 1) % NXR) * XSLOT, 0, af0);
+    // Two steps whose pixel operand comes from LDS (chunks xc, xc + 1), fragment sets A then B.  next_lds: the step after
+    // the pair also reads an X chunk.  (LDS phases always have an even number of steps: NR is even for C >= 32.)
+    auto lds_pair = [&](f32x4 (&acc)[NT], bool next_lds) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4& af = h ? afB : afA;
+            f32x4(&bf)[NT] = h ? bfB : bfA;
+            f32x4& afn = h ? afA : afB;
+            f32x4(&bfn)[NT] = h ? bfA : bfB;
+            const bool has_next = gs + 1 < total_steps;
+            const bool nl = h == 0 || next_lds;
+            loader(true);
+            publish();                      // stage gs + 1 (and chunk xc + 1) is in LDS for everybody
+            if (has_next) {
+                read_b(Wb + ((gs + 1) % NWR) * WSLOT, bfn);
+                if (nl) read_a(Xb + ((xc + 1) % NXR) * XSLOT, afn);
+            }
+            // tile pairs outermost: a pair's two chains alternate (dependent MFMAs 64 cycles apart, latency 40) and its
+            // weight fragments die after 8 MFMAs, so the registers of set A and of the incoming set B overlap
+#pragma unroll
+            for (int t = 0; t < NT; t += 2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[t] = mfma16(bf[t][j], af[j], acc[t]);
+                    acc[t + 1] = mfma16(bf[t + 1][j], af[j], acc[t + 1]);
+                }
+            ++gs; ++xc;
         }
-        mfma_lds(af1, bf1, acc);
-        ++gs; ++xc;
     };
     // NR steps whose pixel operand is the register tile `op` (a previous result); next_lds refers to the step after the
     // last one (the first step of the next LDS phase consumes chunk xc).
-    auto reg_steps = [&](const f32x16 (&op)[NU], f32x16 (&acc)[NU], bool next_lds) {
+    auto reg_steps = [&](const f32x4 (&op)[NT], f32x4 (&acc)[NT], bool next_lds) {
 #pragma unroll
         for (int c = 0; c < NR; ++c) {
+            f32x4(&bf)[NT] = (c & 1) ? bfB : bfA;
+            f32x4(&bfn)[NT] = (c & 1) ? bfA : bfB;
+            f32x4& afn = (c & 1) ? afA : afB;
             const bool has_next = gs + 1 < total_steps;
             const bool nl = (c == NR - 1) && next_lds;
-            read_b(Wb + (gs % NWR) * WSLOT, 1, bf1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int u = 0; u < NU; ++u)
-                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf0[u][j], op[c >> 1][4 * (2 * (c & 1) + 0) + j], acc[u], 0, 0, 0);
             loader(false);
             publish();
             if (has_next) {
-                read_b(Wb + ((gs + 1) % NWR) * WSLOT, 0, bf0);
-                if (nl) read_a(Xb + (xc % NXR) * XSLOT, 0, af0);
+                read_b(Wb + ((gs + 1) % NWR) * WSLOT, bfn);
+                if (nl) read_a(Xb + (xc % NXR) * XSLOT, afn);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int t = 0; t < NT; t += 2)
 #pragma unroll
-                for (int u = 0; u < NU; ++u)
-                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf1[u][j], op[c >> 1][4 * (2 * (c & 1) + 1) + j], acc[u], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    acc[t] = mfma16(bf[t][j], op[c][j], acc[t]);
+                    acc[t + 1] = mfma16(bf[t + 1][j], op[c][j], acc[t + 1]);
+                }
             ++gs;
         }
     };
 
-    // ---- per-lane output geometry of the current unit
+    // ---- per-lane output geometry of the current unit: pixel (row wave, column lp) of the tile, channels 16 t + 4 lg ..
     UnitIt ep_it = decode(t_first);
     int ep_unit = t_first;
     bool pok = false;
     int pix = 0;
     auto ep_setup = [&]() {
-        const int y = ep_it.ty * TH + 2 * wave + (li >> 4), x = ep_it.tx * TW + (li & 15);
+        const int y = ep_it.ty * TH + wave, x = ep_it.tx * TW + lp;
         pok = y < a.H && x < a.W;
         pix = y * a.W + x;
     };
     const long long img_elems = (long long)a.H * a.W;
-    auto store_tile = [&](const f32x16 (&R)[NU], float* base) {     // base: batch plane [H][W][C]
-        if (!pok) return;
-        float* p = base + (long long)pix * C + 4 * lh;
+    auto store_tile = [&](const f32x4 (&R)[NT], float* base) {     // base: batch plane [H][W][C]
+        if (!pok || ((BMC_CHAIN_ABL & 4) && R[0][0] != 12345.678f)) return;
+        float* p = base + (long long)pix * C + 4 * lg;
 #pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                f32x4 v;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = R[u][4 * rq + k];
-                *reinterpret_cast<f32x4*>(p + 32 * u + 8 * rq) = v;
-            }
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(p + 16 * t) = R[t];
+    };
+    auto wsum = [&](float v) {      // over the four lanes (channel quads) that share a pixel
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        return v;
     };
 
     // ---- prologue: fill the rings DX / DW stages deep, publish stage 0
@@ -325,9 +342,11 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainK a) {
     }
     dma_wait<0>();
     publish();
-    read_a(Xb, 0, af0);
-    read_b(Wb, 0, bf0);
+    read_a(Xb, afA);
+    read_b(Wb, bfA);
     init_acc(Ra, BWD ? 4 : 0);
+    // Steps alternate between the fragment sets A and B; every phase has an even number of steps, so each phase starts on A.
+    static_assert(NR % 2 == 0, "C must be a multiple of 32");
 
     for (; ep_unit < t_hi; ep_unit += t_stride) {
         ep_it = decode(ep_unit);
@@ -335,112 +354,97 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainK a) {
         const bool more_units = ep_unit + t_stride < t_hi;
         if constexpr (!BWD) {
             // ---- z = convf(cat[s0, s1]) + b_f
-            for (int i = 0; i < NXC; ++i) lds_step(Ra, i + 1 < NXC);
-            // ---- LayerNorm over the C channels of each pixel: registers of lanes l and l ^ 32
-            float s = 0.f;
+            for (int i = 0; i < NXC; i += 2) lds_pair(Ra, i + 2 < NXC);
+            // ---- LayerNorm over the C channels of each pixel: 4 NT registers in each of the pixel's four lanes
+            float rstd = 1.f;
+            if (!(BMC_CHAIN_ABL & 8)) {
+                float s = 0.f;
 #pragma unroll
-            for (int u = 0; u < NU; ++u)
+                for (int t = 0; t < NT; ++t) s += (Ra[t][0] + Ra[t][1]) + (Ra[t][2] + Ra[t][3]);
+                const float mu = wsum(s) * (1.f / C);
+                float q = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += Ra[u][r];
-            s += __shfl_xor(s, 32);
-            const float mu = s * (1.f / C);
-            float q = 0.f;
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int u = 0; u < NU; ++u)
+                    for (int k = 0; k < 4; ++k) {
+                        const float d = Ra[t][k] - mu;
+                        Ra[t][k] = d;
+                        q += d * d;
+                    }
+                rstd = 1.f / sqrtf(wsum(q) * (1.f / C) + a.eps);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float d = Ra[u][r] - mu;
-                    Ra[u][r] = d;
-                    q += d * d;
-                }
-            q += __shfl_xor(q, 32);
-            const float rstd = 1.f / sqrtf(q * (1.f / C) + a.eps);
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Ra[u][r] *= rstd;
+                for (int t = 0; t < NT; ++t) Ra[t] *= rstd;
+            }
             store_tile(Ra, a.out0 + (long long)ep_it.b * img_elems * C);
-            if (pok && lh == 0) a.out2[(long long)ep_it.b * img_elems + pix] = rstd;
+            if (pok && lg == 0) a.out2[(long long)ep_it.b * img_elems + pix] = rstd;
 #pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const f32x4 gq = *reinterpret_cast<const f32x4*>(img + 2 * C + 32 * u + 8 * rq + 4 * lh);
-                    const f32x4 bq = *reinterpret_cast<const f32x4*>(img + 3 * C + 32 * u + 8 * rq + 4 * lh);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) Ra[u][4 * rq + k] = Ra[u][4 * rq + k] * gq[k] + bq[k];
-                }
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 gq = *reinterpret_cast<const f32x4*>(img + 2 * C + 16 * t + 4 * lg);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(img + 3 * C + 16 * t + 4 * lg);
+                Ra[t] = Ra[t] * gq + bq;
+            }
             // ---- centre = clustering(y) + b_c, pixel operand = the registers of y
             init_acc(Rt, 1);
             reg_steps(Ra, Rt, more_units);
             store_tile(Rt, a.out1 + (long long)ep_it.b * img_elems * C);
             init_acc(Ra, 0);
         } else {
+            // dz of BOTH halves stays in registers (Rz: batch b, Ra: batch b + n): the shared stream's gradient needs
+            // W_f[:, :C]^T (dz[b] + dz[b + n]) -- ONE register-operand GEMM on the sum instead of two (5 C^2 instead of
+            // 6 C^2 multiply-adds per pixel pair half), and d s0 is written once.
             for (int half = 0; half < 2; ++half) {
                 const int bb = ep_it.b + half * a.n;
                 // ---- dy = W_c^T dcentre
-                for (int i = 0; i < NR; ++i) lds_step(Ra, i + 1 < NR);
+                for (int i = 0; i < NR; i += 2) lds_pair(Ra, half == 0 || i + 2 < NR);
                 // ---- LayerNorm backward: g = dy*gamma, dz = rstd * (g - yhat*mean(g*yhat) - mean(g))
-                const float* const yh = a.in0 + (long long)bb * img_elems * C + (long long)pix * C + 4 * lh;
+                const float* const yh = a.in0 + (long long)bb * img_elems * C + (long long)pix * C + 4 * lg;
                 const float rstd = pok ? a.in1[(long long)bb * img_elems + pix] : 0.f;
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int u = 0; u < NU; ++u)
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 gq = *reinterpret_cast<const f32x4*>(img + 2 * C + 16 * t + 4 * lg);
+                    const f32x4 yq = *reinterpret_cast<const f32x4*>(pok ? yh + 16 * t : g_zero4c);
 #pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const f32x4 gq = *reinterpret_cast<const f32x4*>(img + 2 * C + 32 * u + 8 * rq + 4 * lh);
-                        const f32x4 yq = *reinterpret_cast<const f32x4*>(pok ? yh + 32 * u + 8 * rq : g_zero4c);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float g = Ra[u][4 * rq + k] * gq[k];
-                            Ra[u][4 * rq + k] = g;
-                            s1 += g;
-                            s2 += g * yq[k];
-                        }
+                    for (int k = 0; k < 4; ++k) {
+                        const float g = Ra[t][k] * gq[k];
+                        Ra[t][k] = g;
+                        s1 += g;
+                        s2 += g * yq[k];
                     }
-                s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 32);
-                const float m1 = s1 * (1.f / C), m2 = s2 * (1.f / C);
-#pragma unroll
-                for (int u = 0; u < NU; ++u)
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const f32x4 yq = *reinterpret_cast<const f32x4*>(pok ? yh + 32 * u + 8 * rq : g_zero4c);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) Ra[u][4 * rq + k] = rstd * (Ra[u][4 * rq + k] - yq[k] * m2 - m1);
-                    }
-                store_tile(Ra, a.out0 + (long long)bb * img_elems * C);
-                // ---- d s1 (written for the batch the forward READ s1 from) and d s0 (both halves summed in Rx)
-                if (half == 0) {
-                    init_acc(Rt, 4);
-                    reg_steps(Ra, Rt, false);                                  // W_f[:, C:]^T dz
-                    store_tile(Rt, a.out1 + (long long)((bb + a.n) % (2 * a.n)) * img_elems * C);
-                    init_acc(Rt, 4);
-                    reg_steps(Ra, Rt, true);                                   // W_f[:, :C]^T dz (first half)
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) Rx[u] = Rt[u];
-                } else {
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) Rt[u] = Rx[u];
-                    reg_steps(Ra, Rt, false);                                  // + W_f[:, :C]^T dz (second half)
-                    if (a.res.ptr && pok) {
-                        const float* rp = src_batch_ptr(a.res, ep_it.b) + (long long)pix * a.res.pix_stride + 4 * lh;
-#pragma unroll
-                        for (int u = 0; u < NU; ++u)
-#pragma unroll
-                            for (int rq = 0; rq < 4; ++rq) {
-                                const f32x4 v = *reinterpret_cast<const f32x4*>(rp + 32 * u + 8 * rq);
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) Rt[u][4 * rq + k] += v[k];
-                            }
-                    }
-                    store_tile(Rt, a.out2 + (long long)ep_it.b * img_elems * C);
-                    init_acc(Rt, 4);
-                    reg_steps(Ra, Rt, more_units);                             // W_f[:, C:]^T dz
-                    store_tile(Rt, a.out1 + (long long)((bb + a.n) % (2 * a.n)) * img_elems * C);
                 }
-                init_acc(Ra, 4);
+                const float m1 = wsum(s1) * (1.f / C), m2 = wsum(s2) * (1.f / C);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 yq = *reinterpret_cast<const f32x4*>(pok ? yh + 16 * t : g_zero4c);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) Ra[t][k] = rstd * (Ra[t][k] - yq[k] * m2 - m1);
+                }
+                store_tile(Ra, a.out0 + (long long)bb * img_elems * C);
+                if (half == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) Rz[t] = Ra[t];
+                    init_acc(Ra, 4);
+                }
             }
+            // ---- d s1, written for the batch the forward READ s1 from: batch b's dz goes to b + n and vice versa
+            init_acc(Rt, 4);
+            reg_steps(Rz, Rt, false);                                          // W_f[:, C:]^T dz[b]
+            store_tile(Rt, a.out1 + (long long)(ep_it.b + a.n) * img_elems * C);
+            init_acc(Rt, 4);
+            reg_steps(Ra, Rt, false);                                          // W_f[:, C:]^T dz[b + n]
+            store_tile(Rt, a.out1 + (long long)ep_it.b * img_elems * C);
+            // ---- d s0 = add + W_f[:, :C]^T (dz[b] + dz[b + n])
+#pragma unroll
+            for (int t = 0; t < NT; ++t) Rz[t] += Ra[t];
+            init_acc(Rt, 4);
+            if (a.res.ptr && pok) {
+                const float* rp = src_batch_ptr(a.res, ep_it.b) + (long long)pix * a.res.pix_stride + 4 * lg;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) Rt[t] = *reinterpret_cast<const f32x4*>(rp + 16 * t);
+            }
+            reg_steps(Rz, Rt, more_units);
+            store_tile(Rt, a.out2 + (long long)ep_it.b * img_elems * C);
+            init_acc(Ra, 4);
         }
     }
 }
@@ -474,16 +478,16 @@ __global__ void affine_grads_kernel(const float* G, const float* __restrict__ db
 
 int launch(const ChainK& k, int C, bool bwd, hipStream_t st) {
     const int cus = bmc_num_cus();
-    const int max_blocks = (C == 128 ? 1 : 2) * cus;      // resident workgroups per CU (registers: 128 accumulators per lane at C = 128)
+    const int max_blocks = 2 * cus;      // resident workgroups per CU (LDS rings: ~75 KB per workgroup at C = 128)
     dim3 grid((unsigned)(k.nunits < max_blocks ? k.nunits : max_blocks)), block(256);
 #define BMC_LAUNCH_CHAIN(NU_)                                                                    \
     do {                                                                                          \
         if (bwd) hipLaunchKernelGGL((chain_kernel<NU_, true>), grid, block, 0, st, k);            \
         else hipLaunchKernelGGL((chain_kernel<NU_, false>), grid, block, 0, st, k);               \
     } while (0)
-    if (C == 128) BMC_LAUNCH_CHAIN(4);
-    else if (C == 64) BMC_LAUNCH_CHAIN(2);
-    else BMC_LAUNCH_CHAIN(1);
+    if (C == 128) BMC_LAUNCH_CHAIN(8);
+    else if (C == 64) BMC_LAUNCH_CHAIN(4);
+    else BMC_LAUNCH_CHAIN(2);
 #undef BMC_LAUNCH_CHAIN
     return 0;
 }

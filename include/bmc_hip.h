@@ -243,9 +243,9 @@ int bmc_chain_fwd(const bmc_chain_fwd_args_t* host_args, bmc_stream_t s);
  *   dy = W_c^T dcentre;  dz = rstd * (g - yhat*mean_c(g*yhat) - mean_c(g)), g = dy*gamma  (LayerNormFunction.backward, :141-154);
  *   dz  [2n][H][W][C]  is written for the weight-gradient GEMM of convf;
  *   ds1 [(bb + n) % 2n] = W_f[:, C:]^T dz[bb];
- *   ds0 [b] = ds0_add[b] + W_f[:, :C]^T (dz[b] + dz[b + n])   (both halves summed in registers, ds0 written once).
+ *   ds0 [b] = ds0_add[b] + W_f[:, :C]^T (dz[b] + dz[b + n])   (dz of both halves summed in registers: one GEMM, ds0 written once).
  * Weight / bias / affine gradients: bmc_pgemm on (dcentre, yhat) and (dz, s0, s1) + bmc_chain_affine_grads.
- * wstream: 6C/16 slices of [C][16]: T(W_c), T1(W_f), T0(W_f), T(W_c), T0(W_f), T1(W_f) with
+ * wstream: 5C/16 slices of [C][16]: T(W_c), T(W_c), T1(W_f), T1(W_f), T0(W_f) with
  * T(.) = bmc_pack_weight_t(., nkpad = C) and T0 / T1 the operators of W_f's first / second C input channels. */
 typedef struct bmc_chain_bwd_args {
     bmc_src_t dcentre;          /* nch = C, 2n launch batches */
