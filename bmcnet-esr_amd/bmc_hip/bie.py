@@ -222,19 +222,21 @@ class BIETwinFn(torch.autograd.Function):
         slabs, nsplit, G = pgemm_raw(X(g_o), [X(v12)], B2, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * B2 * H * W * Cn * Cn)
         dp = torch.empty_like(p)
         lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, 1.0, dp.data_ptr(), _stream())
-        dv12 = new(B2)
-        _conv([X(g_o)], p.transpose(1, 2).contiguous().view(B2, Cn, Cn, 1), s1, None, None, dv12, B2, bpg=1)
         # ---- softmax, Gram (att = scale * center v^T)
         da = torch.empty_like(p)
         lib.call(lib._sm_bwd, "bmc_softmax_bwd", p.data_ptr(), dp.data_ptr(), B2 * Cn, Cn, ctx.scale, da.data_ptr(), _stream())
-        dc12 = new(B2)
-        _conv([X(v12)], da.view(B2, Cn, Cn, 1), s1, None, None, dc12, B2, bpg=1)                         # d center
-        _conv([X(c12)], da.transpose(1, 2).contiguous().view(B2, Cn, Cn, 1), s1, None, None, dv12, B2, bpg=1,
-              accumulate=True)                                                                           # dv +=
-        # ---- unclustering(cat[c1, c2]) + xs
+        # Each of dv and d center has two contributions that are 1x1 products with per-sample / per-half matrices: ONE
+        # two-source launch each (K = 2C, the matrices side by side) instead of a launch + accumulating launches --
+        #   dv[b]      = P_b^T g_o[b] + da_b^T center[b]
+        #   dcenter[b] = da_b  v[b]   + W_u[:, half(b)]^T g_x[b mod n]            (unclustering reads cat[c1, c2])
+        dv12, dc12 = new(B2), new(B2)
+        w_dv = torch.cat([p.transpose(1, 2), da.transpose(1, 2)], 2).view(B2, Cn, 2 * Cn, 1)
+        _conv([X(g_o), X(c12)], w_dv, s2, None, None, dv12, B2, bpg=1)
+        w_ut = wu.detach().view(Cn, 2, Cn).permute(1, 2, 0).repeat_interleave(n, 0)           # [B2, C (c_i), C (co)]
+        w_dc = torch.cat([da, w_ut], 2).view(B2, Cn, 2 * Cn, 1)
+        _conv([X(v12), X(g_x, mod=n, B=B2)], w_dc, s2, None, None, dc12, B2, bpg=1)
+        # ---- unclustering(cat[c1, c2]) + xs: weight gradient
         dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu)
-        _dgrad(X(g_x), w_u, s2, 0, o_wu, dc12, n, accumulate=True, out_b0=0)
-        _dgrad(X(g_x), w_u, s2, 1, o_wu, dc12, n, accumulate=True, out_b0=n)
         # ---- value convs (two weight groups)
         dwv, dbv = _wgrad(X(dv12), [X(x12)], s1, B2, H, W, 1, Cn, dev, None, None, G=2, w_shape=(2, Cn, Cn, 1, 1))
         if ctx.fused:

@@ -44,6 +44,29 @@ def events_to_stack_no_polarity(xs, ys, ts, ps, B, device=None, sensor_size=(180
     return ops.events_to_stack(xs, ys, ts, ps, int(B), H, W)
 
 
+def events_to_stack_polarity(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240)):
+    """Polarity-split event stack [2,B,H,W] (reference: dataloader/encodings.py:151-199, same signature) on GPU tensors;
+    like the reference: [B,H,W] zeros for windows of <= 3 events or all-zero timestamps, and the caller's xs / ys lose their
+    out-of-range entries (ps is left alone)."""
+    assert len(xs) == len(ys) and len(ys) == len(ts) and len(ts) == len(ps)
+    if not (xs.is_cuda and ys.is_cuda and ts.is_cuda and ps.is_cuda):
+        raise RuntimeError("events_to_stack_polarity: tensors must live on the MI355X (no CPU fallback in this build)")
+    H, W = int(sensor_size[0]), int(sensor_size[1])
+    if ts.sum() == 0 or len(ts) <= 3:
+        return torch.zeros([B, H, W], device=xs.device)
+    return ops.events_to_stack_polarity(xs, ys, ts, ps, int(B), H, W)
+
+
+def events_to_mask(xs, ys, ps, sensor_size=(180, 240)):
+    """Binary event mask [H,W] (reference: dataloader/encodings.py:308-332, same signature) on GPU tensors; as in the
+    reference the caller's xs / ys / ps lose their out-of-range entries in place."""
+    if not (xs.is_cuda and ys.is_cuda and ps.is_cuda):
+        raise RuntimeError("events_to_mask: tensors must live on the MI355X (no CPU fallback in this build)")
+    if not (xs.is_contiguous() and ys.is_contiguous() and ps.is_contiguous()):
+        raise RuntimeError("events_to_mask: xs/ys/ps must be contiguous (they are updated in place)")
+    return ops.events_to_mask(xs, ys, ps, int(sensor_size[0]), int(sensor_size[1]))
+
+
 def events_to_channels_batch(xs, ys, ps, offsets, sensor_size=(180, 240), mutate=True):
     """Many frames in one launch: frame f owns events [offsets[f], offsets[f+1]) -> [nframes,2,H,W]."""
     return ops.events_to_channels_batched(xs, ys, ps, offsets, int(sensor_size[0]), int(sensor_size[1]), mutate=mutate)

@@ -71,7 +71,9 @@ _ll, _i, _f, _p = C.c_longlong, C.c_int, C.c_float, C.c_void_p
 bmc_version = _sig("bmc_version", [])
 bmc_last_error = _sig("bmc_last_error", [], C.c_char_p)
 _events = _sig("bmc_events_to_channels", [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p])
-_voxel = _sig("bmc_events_to_voxel", [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p])
+_voxel = _sig("bmc_events_to_voxel", [_p, _p, _p, _p, _p, _ll, _i, _i, _i, _i, _p, _i, _p, _p])
+_stack_pol = _sig("bmc_events_to_stack_polarity", [_p, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p, _p, _i, _p])
+_mask = _sig("bmc_events_to_mask", [_p, _p, _p, _ll, _i, _i, _p, _p, _i, _p])
 _stack = _sig("bmc_events_to_stack", [_p, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p, _p, _i, _p])
 _enc_raw = _sig("bmc_encode_raw_events", [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p])
 _pack_w = _sig("bmc_pack_weight", [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p])
@@ -104,7 +106,7 @@ EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_event
            "bmc_layernorm_fwd", "bmc_layernorm_bwd", "bmc_softmax_fwd", "bmc_softmax_bwd", "bmc_pack_inputs",
            "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr", "bmc_bicubic_resize_fwd", "bmc_bicubic_resize_bwd",
            "bmc_chain_fwd", "bmc_chain_bwd", "bmc_chain_affine_grads", "bmc_group_sum",
-           "bmc_head_mse_fwd", "bmc_head_mse_bwd"]
+           "bmc_head_mse_fwd", "bmc_head_mse_bwd", "bmc_events_to_stack_polarity", "bmc_events_to_mask"]
 
 
 def check(rc, what):

@@ -997,9 +997,42 @@ def events_to_voxel_batched(xs, ys, ts, ps, offsets, bins, H, W, mutate=True):
     """fp32 device vectors + int64 frame offsets -> [nframes, bins, H, W] temporal-bilinear voxel grids."""
     _need_gpu(xs)
     nframes = offsets.numel() - 1
+    n = xs.numel()
     out = torch.empty((nframes, bins, H, W), device=xs.device, dtype=torch.float32)
+    ws = torch.empty(2 * nframes * (H * W + 1) + n, device=xs.device, dtype=torch.int32)
     lib.call(lib._voxel, "bmc_events_to_voxel", xs.data_ptr(), ys.data_ptr(), ts.data_ptr(), ps.data_ptr(),
-             offsets.data_ptr(), nframes, bins, H, W, out.data_ptr(), int(mutate), _stream())
+             offsets.data_ptr(), n, nframes, bins, H, W, out.data_ptr(), int(mutate), ws.data_ptr(), _stream())
+    return out
+
+
+def _bin_bounds(ts, bins):
+    """float32 bin bounds with the reference's own expressions (dataloader/encodings.py:171-176,224-229), on the device."""
+    dt = ts[-1] - ts[0] + 1e-6
+    delta_t = dt / bins
+    bi = torch.arange(bins, device=ts.device, dtype=torch.float32)
+    tstart = ts[0] + delta_t * bi
+    return tstart, tstart + delta_t
+
+
+def events_to_stack_polarity(xs, ys, ts, ps, bins, H, W, mutate=True):
+    """fp32 device vectors of ONE event window -> [2, bins, H, W] polarity-split event stack (events_to_stack_polarity)."""
+    _need_gpu(xs)
+    tstart, tend = _bin_bounds(ts, bins)
+    out = torch.empty((2, bins, H, W), device=xs.device, dtype=torch.float32)
+    ranges = torch.empty(2 * bins, device=xs.device, dtype=torch.int32)
+    lib.call(lib._stack_pol, "bmc_events_to_stack_polarity", xs.data_ptr(), ys.data_ptr(), ts.data_ptr(), ps.data_ptr(),
+             ts.numel(), tstart.data_ptr(), tend.data_ptr(), bins, H, W, out.data_ptr(), ranges.data_ptr(), int(mutate),
+             _stream())
+    return out
+
+
+def events_to_mask(xs, ys, ps, H, W, mutate=True):
+    """fp32 device vectors -> [H, W] event mask (events_to_mask); xs / ys / ps lose their out-of-range entries in place."""
+    _need_gpu(xs)
+    out = torch.empty((H, W), device=xs.device, dtype=torch.float32)
+    ws = torch.empty(H * W, device=xs.device, dtype=torch.int32)
+    lib.call(lib._mask, "bmc_events_to_mask", xs.data_ptr(), ys.data_ptr(), ps.data_ptr(), xs.numel(), H, W, out.data_ptr(),
+             ws.data_ptr(), int(mutate), _stream())
     return out
 
 

@@ -62,27 +62,96 @@ __global__ void encode_raw_kernel(const short* __restrict__ xs, const short* __r
 // Temporal-bilinear voxel grid (dataloader/encodings.py:272-287): bin b receives p * max(0, 1 - |t*(bins-1) - b|)
 // through events_to_image(), i.e. with the vertical flip and with the same side effect as above: the FIRST bin's call
 // zeroes out-of-range events and resets their coordinates in place, so in every later bin they are no longer masked
-// and deposit their weight at [H-1, 0].  Weights are arbitrary floats: the sum is accumulated with float atomics, so
-// (like the reference's multi-threaded index_put_) it is defined up to summation order.
-__global__ void voxel_kernel(float* __restrict__ xs, float* __restrict__ ys, const float* __restrict__ ts,
-                             const float* __restrict__ ps, const long long* __restrict__ offsets, int bins, int H, int W,
-                             float* __restrict__ out, int mutate) {
+// and deposit their weight at [H-1, 0].  Weights are arbitrary floats, so the summation ORDER is part of the result:
+// the reference's index_put_(accumulate=True) adds a pixel's events in event order (sequential CPU kernel).  Same
+// order here, without float atomics (deterministic, bit-identical run to run and to the single-threaded reference):
+//   count   : events per pixel (integer atomics);
+//   scan    : exclusive prefix sum over the pixels of a frame (one workgroup per frame) -> segment offsets;
+//   fill    : every event drops its index into its pixel's segment (arrival order, arbitrary);
+//   reduce  : one thread per pixel sorts its segment by event index (segments are a handful of events) and sums the
+//             bins' weights in that order.
+__device__ __forceinline__ int voxel_pixel(float x, float y, int H, int W, bool& oob) {
+    oob = (x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f);
+    if (oob) { x = 0.f; y = 0.f; }
+    return (H - (int)y - 1) * W + (int)x;
+}
+__global__ void voxel_count_kernel(const float* __restrict__ xs, const float* __restrict__ ys,
+                                   const long long* __restrict__ offsets, int H, int W, int* __restrict__ cnt) {
     const int f = blockIdx.y;
     const long long e0 = offsets[f], e1 = offsets[f + 1];
-    float* const vox = out + (long long)f * bins * H * W;
+    int* const c = cnt + (long long)f * (H * W + 1);
     for (long long e = e0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += (long long)gridDim.x * blockDim.x) {
-        float x = xs[e], y = ys[e];
-        const float p = ps[e], t = ts[e] * (float)(bins - 1);
-        const bool oob = (x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f);
-        if (oob) {
-            x = 0.f; y = 0.f;
-            if (mutate) { xs[e] = 0.f; ys[e] = 0.f; }
+        bool oob;
+        atomicAdd(c + voxel_pixel(xs[e], ys[e], H, W, oob), 1);
+    }
+}
+// in-place exclusive scan of cnt[f][0 .. HW] (entry HW receives the total); cur[f][q] = start of segment q (fill cursor)
+__global__ void voxel_scan_kernel(int* __restrict__ cnt, int* __restrict__ cur, int HW) {
+    int* const c = cnt + (long long)blockIdx.x * (HW + 1);
+    int* const u = cur + (long long)blockIdx.x * (HW + 1);
+    const int per = (HW + blockDim.x - 1) / blockDim.x;
+    const int lo = threadIdx.x * per, hi = lo + per < HW ? lo + per : HW;
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += c[i];
+    __shared__ int part[1024];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < (int)blockDim.x; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        c[HW] = run;
+        u[HW] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { const int v = c[i]; c[i] = run; u[i] = run; run += v; }
+}
+__global__ void voxel_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys,
+                                  const long long* __restrict__ offsets, int H, int W, int* __restrict__ cur,
+                                  int* __restrict__ idx) {
+    const int f = blockIdx.y;
+    const long long e0 = offsets[f], e1 = offsets[f + 1];
+    int* const u = cur + (long long)f * (H * W + 1);
+    for (long long e = e0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += (long long)gridDim.x * blockDim.x) {
+        bool oob;
+        const int q = voxel_pixel(xs[e], ys[e], H, W, oob);
+        idx[e0 + atomicAdd(u + q, 1)] = (int)(e - e0);
+    }
+}
+__global__ void voxel_reduce_kernel(float* __restrict__ xs, float* __restrict__ ys, const float* __restrict__ ts,
+                                    const float* __restrict__ ps, const long long* __restrict__ offsets, int bins, int H, int W,
+                                    const int* __restrict__ seg, int* __restrict__ idx, float* __restrict__ out, int mutate) {
+    const int f = blockIdx.y, HW = H * W;
+    const long long e0 = offsets[f];
+    const int* const sg = seg + (long long)f * (HW + 1);
+    float* const vox = out + (long long)f * bins * HW;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < HW; q += gridDim.x * blockDim.x) {
+        const int a = sg[q], b = sg[q + 1];
+        int* const id = idx + e0;
+        for (int i = a + 1; i < b; ++i) {          // insertion sort by event index: restores event order
+            const int v = id[i];
+            int j = i - 1;
+            while (j >= a && id[j] > v) { id[j + 1] = id[j]; --j; }
+            id[j + 1] = v;
         }
-        const long long pix = (long long)(H - (int)y - 1) * W + (int)x;
-        for (int b = 0; b < bins; ++b) {
-            const float wgt = p * fmaxf(0.f, 1.0f - fabsf(t - (float)b));
-            if (wgt != 0.f && !(oob && b == 0)) atomicAdd(vox + (long long)b * H * W + pix, wgt);
+        for (int bi = 0; bi < bins; ++bi) {
+            float acc = 0.f;
+            for (int i = a; i < b; ++i) {
+                const long long e = e0 + id[i];
+                const float x = xs[e], y = ys[e];
+                const bool oob = (x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f);
+                const float t = ts[e] * (float)(bins - 1);
+                const float wgt = ps[e] * fmaxf(0.f, 1.0f - fabsf(t - (float)bi));
+                if (!(oob && bi == 0)) acc += wgt;
+            }
+            vox[(long long)bi * HW + q] = acc;
         }
+        if (mutate && q == (H - 1) * W)            // every out-of-range event sits in this pixel's segment: reset them
+            for (int i = a; i < b; ++i) {
+                const long long e = e0 + id[i];
+                const float x = xs[e], y = ys[e];
+                if ((x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f)) { xs[e] = 0.f; ys[e] = 0.f; }
+            }
     }
 }
 
@@ -135,16 +204,100 @@ __global__ void stack_mutate_kernel(float* __restrict__ xs, float* __restrict__ 
     }
 }
 
+
+// Event stack WITH polarity split (dataloader/encodings.py:151-199): per bin two count images [2][bins][H][W] =
+// (positives, negatives), no vertical flip, weights p*p.  Per bin the reference calls events_to_image_torch twice on
+// VIEWS of the caller's coordinates with a temporary weight vector: the first (positive) call of the FIRST bin that
+// covers an event resets its out-of-range coordinates to (0, 0) and masks only that call; in every later call
+// (the same bin's negative image, and both images of any later bin that covers the event again) it is in range at
+// [0, 0].  Counts are integers: float atomics are exact.
+__global__ void stack_pol_scatter_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ ps,
+                                         const int* __restrict__ ranges, int bins, int H, int W, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int beg = ranges[2 * b], end = ranges[2 * b + 1];
+    float* const pos = out + (long long)b * H * W;
+    float* const neg = out + ((long long)bins + b) * H * W;
+    for (int e = beg + blockIdx.x * blockDim.x + threadIdx.x; e < end; e += gridDim.x * blockDim.x) {
+        const float x = xs[e], y = ys[e], p = ps[e];
+        const bool oob = (x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f);
+        if (p == 0.f) continue;
+        if (!oob) {
+            atomicAdd((p > 0.f ? pos : neg) + (long long)(int)y * W + (int)x, p * p);
+        } else {
+            bool first = true;          // did an earlier bin already cover (and reset) this event?
+            for (int bb = 0; bb < b; ++bb) first = first && !(e >= ranges[2 * bb] && e < ranges[2 * bb + 1]);
+            if (p < 0.f) atomicAdd(neg, p * p);
+            else if (!first) atomicAdd(pos, p * p);
+        }
+    }
+}
+__global__ void stack_pol_mutate_kernel(float* __restrict__ xs, float* __restrict__ ys, const int* __restrict__ ranges, int H,
+                                        int W) {
+    const int b = blockIdx.y;
+    const int beg = ranges[2 * b], end = ranges[2 * b + 1];
+    for (int e = beg + blockIdx.x * blockDim.x + threadIdx.x; e < end; e += gridDim.x * blockDim.x) {
+        const float x = xs[e], y = ys[e];
+        if ((x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f)) { xs[e] = 0.f; ys[e] = 0.f; }
+    }
+}
+
+// Binary event mask (dataloader/encodings.py:308-332): out-of-range events get xs = ys = ps = 0 in place, then
+// mask[(long) y][(long) x] = |p| with index_put_(accumulate=False): for a pixel hit several times the LAST event in
+// order wins (sequential semantics; a zeroed out-of-range event can clear [0, 0]).  Deterministic here: atomicMax of the
+// event index per pixel, then the winner writes.
+__global__ void mask_owner_kernel(const float* __restrict__ xs, const float* __restrict__ ys, long long n, int H, int W,
+                                  int* __restrict__ owner) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        float x = xs[e], y = ys[e];
+        if ((x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f)) { x = 0.f; y = 0.f; }
+        atomicMax(owner + (long long)(int)y * W + (int)x, (int)e + 1);
+    }
+}
+__global__ void mask_write_kernel(float* __restrict__ xs, float* __restrict__ ys, float* __restrict__ ps, long long n, int H, int W,
+                                  const int* __restrict__ owner, float* __restrict__ out, int mutate) {
+    const long long hw = (long long)H * W;
+    const long long total = hw > n ? hw : n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        if (i < hw) {
+            const int o = owner[i];
+            float v = 0.f;
+            if (o > 0) {
+                const float x = xs[o - 1], y = ys[o - 1];
+                const bool oob = (x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f);
+                v = oob ? 0.f : fabsf(ps[o - 1]);
+            }
+            out[i] = v;
+        }
+    }
+}
+__global__ void mask_mutate_kernel(float* __restrict__ xs, float* __restrict__ ys, float* __restrict__ ps, long long n, int H,
+                                   int W) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const float x = xs[e], y = ys[e];
+        if ((x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f)) { xs[e] = 0.f; ys[e] = 0.f; ps[e] = 0.f; }
+    }
+}
+
 }  // namespace
 
 extern "C" int bmc_events_to_voxel(float* xs, float* ys, const float* ts, const float* ps, const long long* offsets,
-                                   int nframes, int bins, int H, int W, float* out, int mutate, bmc_stream_t s) {
-    BMC_CHECK_ARG(nframes >= 0 && bins >= 1 && H > 0 && W > 0 && out, "bmc_events_to_voxel: bad shape");
+                                   long long nevents, int nframes, int bins, int H, int W, float* out, int mutate, int* ws,
+                                   bmc_stream_t s) {
+    BMC_CHECK_ARG(nframes >= 0 && bins >= 1 && H > 0 && W > 0 && out && ws, "bmc_events_to_voxel: bad shape / null workspace");
+    BMC_CHECK_ARG(nevents >= 0 && nevents < (1ll << 31), "bmc_events_to_voxel: event count out of range");
     hipStream_t st = (hipStream_t)s;
     if (nframes == 0) return 0;
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)nframes * bins * H * W * sizeof(float), st);
+    const long long segn = (long long)nframes * (H * W + 1);
+    int* const seg = ws;                 // [nframes][HW + 1] segment offsets
+    int* const cur = ws + segn;          // [nframes][HW + 1] fill cursors
+    int* const idx = ws + 2 * segn;      // [nevents] event indices grouped by pixel
+    hipError_t e = hipMemsetAsync(seg, 0, (size_t)segn * sizeof(int), st);
     if (e != hipSuccess) { bmc_set_error("bmc_events_to_voxel: memset failed: %s", hipGetErrorString(e)); return -2; }
-    hipLaunchKernelGGL(voxel_kernel, dim3(64, nframes), dim3(256), 0, st, xs, ys, ts, ps, offsets, bins, H, W, out, mutate);
+    hipLaunchKernelGGL(voxel_count_kernel, dim3(64, nframes), dim3(256), 0, st, xs, ys, offsets, H, W, seg);
+    hipLaunchKernelGGL(voxel_scan_kernel, dim3(nframes), dim3(1024), 0, st, seg, cur, H * W);
+    hipLaunchKernelGGL(voxel_fill_kernel, dim3(64, nframes), dim3(256), 0, st, xs, ys, offsets, H, W, cur, idx);
+    hipLaunchKernelGGL(voxel_reduce_kernel, dim3((H * W + 255) / 256, nframes), dim3(256), 0, st, xs, ys, ts, ps, offsets, bins,
+                       H, W, seg, idx, out, mutate);
     BMC_CHECK_LAUNCH("bmc_events_to_voxel");
     return 0;
 }
@@ -186,5 +339,35 @@ extern "C" int bmc_events_to_stack(float* xs, float* ys, const float* ts, float*
     hipLaunchKernelGGL(stack_scatter_kernel, dim3(64, bins), dim3(256), 0, st, xs, ys, ps, ranges, H, W, out);
     if (mutate) hipLaunchKernelGGL(stack_mutate_kernel, dim3(64, bins), dim3(256), 0, st, xs, ys, ps, ranges, H, W);
     BMC_CHECK_LAUNCH("bmc_events_to_stack");
+    return 0;
+}
+
+extern "C" int bmc_events_to_stack_polarity(float* xs, float* ys, const float* ts, const float* ps, long long n,
+                                            const float* tstart, const float* tend, int bins, int H, int W, float* out,
+                                            int* ranges, int mutate, bmc_stream_t s) {
+    BMC_CHECK_ARG(bins >= 1 && H > 0 && W > 0 && out && ranges && tstart && tend, "bmc_events_to_stack_polarity: bad arguments");
+    BMC_CHECK_ARG(n >= 0 && n < (1ll << 31), "bmc_events_to_stack_polarity: event count out of range");
+    hipStream_t st = (hipStream_t)s;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)2 * bins * H * W * sizeof(float), st);
+    if (e != hipSuccess) { bmc_set_error("bmc_events_to_stack_polarity: memset failed: %s", hipGetErrorString(e)); return -2; }
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(stack_search_kernel, dim3((2 * bins + 63) / 64), dim3(64), 0, st, ts, n, tstart, tend, bins, ranges);
+    hipLaunchKernelGGL(stack_pol_scatter_kernel, dim3(64, bins), dim3(256), 0, st, xs, ys, ps, ranges, bins, H, W, out);
+    if (mutate) hipLaunchKernelGGL(stack_pol_mutate_kernel, dim3(64, bins), dim3(256), 0, st, xs, ys, ranges, H, W);
+    BMC_CHECK_LAUNCH("bmc_events_to_stack_polarity");
+    return 0;
+}
+
+extern "C" int bmc_events_to_mask(float* xs, float* ys, float* ps, long long n, int H, int W, float* out, int* ws, int mutate,
+                                  bmc_stream_t s) {
+    BMC_CHECK_ARG(H > 0 && W > 0 && out && ws, "bmc_events_to_mask: bad arguments");
+    BMC_CHECK_ARG(n >= 0 && n < (1ll << 31) - 1, "bmc_events_to_mask: event count out of range");
+    hipStream_t st = (hipStream_t)s;
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)H * W * sizeof(int), st);
+    if (e != hipSuccess) { bmc_set_error("bmc_events_to_mask: memset failed: %s", hipGetErrorString(e)); return -2; }
+    if (n > 0) hipLaunchKernelGGL(mask_owner_kernel, dim3(256), dim3(256), 0, st, xs, ys, n, H, W, ws);
+    hipLaunchKernelGGL(mask_write_kernel, dim3(256), dim3(256), 0, st, xs, ys, ps, n, H, W, ws, out, mutate);
+    if (mutate && n > 0) hipLaunchKernelGGL(mask_mutate_kernel, dim3(256), dim3(256), 0, st, xs, ys, ps, n, H, W);
+    BMC_CHECK_LAUNCH("bmc_events_to_mask");
     return 0;
 }

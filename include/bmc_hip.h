@@ -60,10 +60,13 @@ int bmc_events_to_channels(float* xs, float* ys, const float* ps, const long lon
                            int nframes, int H, int W, float* out, int mutate, bmc_stream_t s);
 
 /* events_to_voxel(): temporal-bilinear voxel grid [nframes][bins][H][W] (dataloader/encodings.py:272-287; ts already
- * normalised to [0,1] by event_formatting).  Same coordinate conventions and first-call side effect as above; float
- * weights are summed with float atomics (summation order undefined, as in the reference's threaded index_put_). */
+ * normalised to [0,1] by event_formatting).  Same coordinate conventions and first-call side effect as above.  The
+ * weights are arbitrary floats, so the order of summation is part of the result: a pixel's events are added in EVENT
+ * ORDER, as the reference's sequential index_put_ does -- deterministic (no float atomics) and bit-identical to the
+ * single-threaded reference.  nevents = offsets[nframes]; ws: workspace of 2*nframes*(H*W + 1) + nevents ints. */
 int bmc_events_to_voxel(float* xs, float* ys, const float* ts, const float* ps, const long long* offsets,
-                        int nframes, int bins, int H, int W, float* out, int mutate, bmc_stream_t s);
+                        long long nevents, int nframes, int bins, int H, int W, float* out, int mutate, int* ws,
+                        bmc_stream_t s);
 
 /* events_to_stack_no_polarity() (dataloader/encodings.py:202-238): `bins` temporal bins over one event window, each the
  * signed per-pixel sum of the polarities of its events at [(long) y, (long) x] (no vertical flip).  tstart / tend [bins]:
@@ -73,6 +76,22 @@ int bmc_events_to_voxel(float* xs, float* ys, const float* ts, const float* ps, 
  * place, as the reference does to its caller's tensors.  Exact for +-1 polarities (integer-valued sums). */
 int bmc_events_to_stack(float* xs, float* ys, const float* ts, float* ps, long long n, const float* tstart,
                         const float* tend, int bins, int H, int W, float* out, int* ranges, int mutate, bmc_stream_t s);
+
+/* events_to_stack_polarity() (dataloader/encodings.py:151-199): as bmc_events_to_stack but two COUNT images per bin,
+ * out [2][bins][H][W] = (positives, negatives), weights p*p.  The reference's first (positive) call of the first bin that
+ * covers an event resets its out-of-range coordinates (in place, if mutate) and masks only that call: an out-of-range
+ * negative event counts at [0,0] of the negative image, and an out-of-range event that a later, overlapping bin covers
+ * again counts at [0,0] whatever its sign.  ps is never modified. */
+int bmc_events_to_stack_polarity(float* xs, float* ys, const float* ts, const float* ps, long long n, const float* tstart,
+                                 const float* tend, int bins, int H, int W, float* out, int* ranges, int mutate,
+                                 bmc_stream_t s);
+
+/* events_to_mask() (dataloader/encodings.py:308-332; the hot-pixel filter's input, dataloader/h5dataset.py:528-546):
+ * out [H][W], out[(long) y][(long) x] = |p| of the LAST event (in order) that maps there -- index_put_(accumulate=False)
+ * semantics, made deterministic with an integer atomicMax over event indices (ws: H*W ints).  Out-of-range events
+ * count as (0, 0) with p = 0; if mutate != 0 their xs / ys / ps are zeroed in place as the reference does. */
+int bmc_events_to_mask(float* xs, float* ys, float* ps, long long n, int H, int W, float* out, int* ws, int mutate,
+                       bmc_stream_t s);
 
 /* Sequence encoder on raw dataset columns: what H5Dataset.__getitem__ does per frame on the CPU
  * (dataloader/h5dataset.py:261-316: get_events :407-414 -> augment_event :559-578 -> event_formatting

@@ -710,8 +710,9 @@ def test_conv_fuzz_random_shapes_vs_torch(math):
 
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
 def test_events_to_voxel_golden(tag):
-    """GPU voxel encoder vs the reference's output.  Float weights + atomics: equal up to summation order
-    (abs 1e-5 on values of O(1..10)); the in-place reset of out-of-range coordinates is exact."""
+    """GPU voxel encoder vs the reference's output: float weights summed per pixel in EVENT ORDER (segmented, no float
+    atomics), i.e. the order of the reference's sequential index_put_ -- bit-exact, and identical run to run; the
+    in-place reset of out-of-range coordinates is exact too."""
     dev = _gpu()
     from bmc_hip.encodings import events_to_voxel
     z = load("voxel.npz")
@@ -719,8 +720,10 @@ def test_events_to_voxel_golden(tag):
     xs, ys, ts, ps = (torch.tensor(z[f"{tag}/{k}"], device=dev) for k in ("xs", "ys", "ts", "ps"))
     vox = events_to_voxel(xs, ys, ts, ps, bins, (H, W))
     assert vox.shape == (bins, H, W)
-    assert np.abs(vox.cpu().numpy() - z[f"{tag}/vox"]).max() <= 1e-5
+    assert np.array_equal(vox.cpu().numpy(), z[f"{tag}/vox"])
     assert np.array_equal(xs.cpu().numpy(), z[f"{tag}/xs_after"]) and np.array_equal(ys.cpu().numpy(), z[f"{tag}/ys_after"])
+    xs2, ys2 = (torch.tensor(z[f"{tag}/{k}"], device=dev) for k in ("xs", "ys"))
+    assert torch.equal(events_to_voxel(xs2, ys2, ts, ps, bins, (H, W)), vox)          # deterministic
 
 
 # ------------------------------------------------------------------ arithmetic modes of the MFMA kernels

@@ -487,3 +487,56 @@ def test_bie_with_fused_chain_vs_float64_oracle(Cn, n, H, W):
     assert rel_l2(o12, o12u) < 5e-6 and rel_l2(xsn, xsnu) < 5e-6 and rel_l2(ga, gau) < 2e-5 and rel_l2(gb, gbu) < 2e-5
     for k in gp:
         assert rel_l2(gp[k], gpu_[k]) < 2e-5, k
+
+
+# ------------------------------------------------------------------ remaining encodings of dataloader/encodings.py
+@pytest.mark.parametrize("tag", list("abcdefg"))
+def test_events_to_stack_polarity_golden(tag):
+    dev = _gpu()
+    from bmc_hip.encodings import events_to_stack_polarity
+    z = load("stack_polarity.npz")
+    H, W, bins = (int(v) for v in z[tag + "/meta"])
+    xs, ys, ts, ps = (torch.tensor(z[tag + "/" + k], device=dev) for k in ("xs", "ys", "ts", "ps"))
+    st = events_to_stack_polarity(xs, ys, ts, ps, bins, sensor_size=(H, W))
+    assert tuple(st.shape) == z[tag + "/stack"].shape              # [B,H,W] zeros on the early return, else [2,B,H,W]
+    assert np.array_equal(st.cpu().numpy(), z[tag + "/stack"])
+    assert np.array_equal(xs.cpu().numpy(), z[tag + "/xs_after"]) and np.array_equal(ys.cpu().numpy(), z[tag + "/ys_after"])
+    assert np.array_equal(ps.cpu().numpy(), z[tag + "/ps_after"])
+
+
+@pytest.mark.parametrize("tag", list("abcd"))
+def test_events_to_mask_golden(tag):
+    dev = _gpu()
+    from bmc_hip.encodings import events_to_mask
+    z = load("mask.npz")
+    H, W = (int(v) for v in z[tag + "/meta"])
+    xs, ys, ps = (torch.tensor(z[tag + "/" + k], device=dev) for k in ("xs", "ys", "ps"))
+    mk = events_to_mask(xs, ys, ps, sensor_size=(H, W))
+    assert np.array_equal(mk.cpu().numpy(), z[tag + "/mask"])
+    for t, k in ((xs, "xs_after"), (ys, "ys_after"), (ps, "ps_after")):
+        assert np.array_equal(t.cpu().numpy(), z[tag + "/" + k])
+
+
+def test_voxel_full_size_is_deterministic_and_conserves_weight():
+    """180x240 frames, 24 576 events each, 5 bins, 4 frames in one launch: identical bits on every run, equal to the
+    event-order numpy oracle, and (size-independent property) every in-range event's weights over the bins sum to p."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from oracle import bmc_oracle as O
+    rng = np.random.default_rng(3)
+    H, W, bins, nf, n = 180, 240, 5, 4, 24576
+    xs = rng.uniform(-1.0, W + 1.0, nf * n).astype(np.float32)
+    ys = rng.uniform(-1.0, H + 1.0, nf * n).astype(np.float32)
+    ts = np.concatenate([np.sort(rng.uniform(0, 1, n)) for _ in range(nf)]).astype(np.float32)
+    ps = rng.choice([-1.0, 1.0], nf * n).astype(np.float32)
+    off = torch.arange(nf + 1, dtype=torch.int64, device=dev) * n
+    t = lambda a: torch.tensor(a, device=dev)
+    v1 = ops.events_to_voxel_batched(t(xs), t(ys), t(ts), t(ps), off, bins, H, W, mutate=False)
+    v2 = ops.events_to_voxel_batched(t(xs), t(ys), t(ts), t(ps), off, bins, H, W, mutate=False)
+    assert torch.equal(v1, v2)
+    for f in (0, nf - 1):
+        sl = slice(f * n, (f + 1) * n)
+        ref, _, _ = O.events_to_voxel_np(xs[sl], ys[sl], ts[sl], ps[sl], bins, (H, W))
+        assert np.array_equal(v1[f].cpu().numpy(), ref)
+    inr = (xs >= 0) & (xs < W) & (ys >= 0) & (ys < H)
+    assert abs(v1.double().sum().item() - float(ps[inr].astype(np.float64).sum())) < 20.0      # + the quirk's (H-1, 0) deposits
