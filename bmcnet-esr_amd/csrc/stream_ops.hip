@@ -71,19 +71,22 @@ __global__ void colsum_stage2(const float* __restrict__ ws, int nblk, int C, flo
 }
 
 // ------------------------------------------------------------------ LayerNorm2d
-// LPP = C/4 lanes per pixel (power of two <= 64), each lane owns one float4 of the channel row.
+// LPP lanes per pixel (power of two <= 64, LPP * 4 >= C), each lane owns one float4 of the channel row; C is any multiple
+// of 4 (lanes past the row are idle: C = 48 runs with LPP = 16, 12 of them active).
 template <int LPP>
 __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                              long long npix, float eps, float* __restrict__ y, float* __restrict__ stats) {
-    constexpr int C = LPP * 4, PPW = 64 / LPP;
+                              long long npix, int C, float eps, float* __restrict__ y, float* __restrict__ stats) {
+    constexpr int PPW = 64 / LPP;
     const int lane = threadIdx.x & 63, sub = lane % LPP, pw = lane / LPP;
+    const bool act = sub * 4 < C;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + sub * 4);
-    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + sub * 4);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 gm = act ? *reinterpret_cast<const f32x4*>(gamma + sub * 4) : zero4;
+    const f32x4 bt = act ? *reinterpret_cast<const f32x4*>(beta + sub * 4) : zero4;
     for (long long p0 = wave * PPW; p0 < npix; p0 += nwaves * PPW) {
         const long long p = p0 + pw;
-        const bool ok = p < npix;
+        const bool ok = p < npix && act;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (ok) v = *reinterpret_cast<const f32x4*>(x + p * C + sub * 4);
         float s = v[0] + v[1] + v[2] + v[3];
@@ -93,7 +96,7 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
         f32x4 d;
         float q = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { d[k] = v[k] - mu; q += d[k] * d[k]; }
+        for (int k = 0; k < 4; ++k) { d[k] = act ? v[k] - mu : 0.f; q += d[k] * d[k]; }
 #pragma unroll
         for (int m = 1; m < LPP; m <<= 1) q += __shfl_xor(q, m);
         const float rstd = 1.f / sqrtf(q * (1.f / C) + eps);
@@ -111,17 +114,19 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 // dgamma = sum dy*yhat, dbeta = sum dy go to ws[block][2][C].
 template <int LPP>
 __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
-                              const float* __restrict__ gamma, long long npix, float* __restrict__ dx,
+                              const float* __restrict__ gamma, long long npix, int C, float* __restrict__ dx,
                               float* __restrict__ ws) {
-    constexpr int C = LPP * 4, PPW = 64 / LPP;
+    constexpr int PPW = 64 / LPP;
     const int lane = threadIdx.x & 63, sub = lane % LPP, pw = lane / LPP;
+    const bool act = sub * 4 < C;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + sub * 4);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 gm = act ? *reinterpret_cast<const f32x4*>(gamma + sub * 4) : zero4;
     f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
     for (long long p0 = wave * PPW; p0 < npix; p0 += nwaves * PPW) {
         const long long p = p0 + pw;
-        const bool ok = p < npix;
+        const bool ok = p < npix && act;
         f32x4 v = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
         float mu = 0.f, rstd = 0.f;
         if (ok) {
@@ -133,7 +138,7 @@ __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restr
         float sg = 0.f, sgy = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            yh[k] = (v[k] - mu) * rstd;
+            yh[k] = ok ? (v[k] - mu) * rstd : 0.f;
             g[k] = d[k] * gm[k];
             sg += g[k];
             sgy += g[k] * yh[k];
@@ -437,21 +442,29 @@ extern "C" int bmc_colsum(const float* x, long long npix, int pix_stride, int C,
     return 0;
 }
 
+// lanes per pixel: the power of two >= C/4 (C = 16 -> 4, 48 -> 16, 128 -> 32, ...)
+static int ln_lpp(int C) {
+    int l = 1;
+    while (l * 4 < C) l <<= 1;
+    return l;
+}
 #define LN_DISPATCH(KERNEL, ...)                                                              \
-    switch (C) {                                                                              \
-        case 16: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
-        case 32: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
-        case 64: hipLaunchKernelGGL((KERNEL<16>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
-        case 128: hipLaunchKernelGGL((KERNEL<32>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
-        case 256: hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
-        default: bmc_set_error("layernorm: C=%d unsupported (16/32/64/128/256)", C); return -1; \
+    if (C < 4 || C > 256 || C % 4) { bmc_set_error("layernorm: C=%d unsupported (multiples of 4 up to 256)", C); return -1; } \
+    switch (ln_lpp(C)) {                                                                      \
+        case 1: hipLaunchKernelGGL((KERNEL<1>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 4: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 8: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 16: hipLaunchKernelGGL((KERNEL<16>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
+        case 32: hipLaunchKernelGGL((KERNEL<32>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
+        default: hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
     }
 
 extern "C" int bmc_layernorm_fwd(const float* x, const float* gamma, const float* beta, long long npix, int C, float eps,
                                  float* y, float* stats, bmc_stream_t s) {
     hipStream_t st = (hipStream_t)s;
-    dim3 grid(nblocks(npix * (C / 4), 256 * 4));
-    LN_DISPATCH(ln_fwd_kernel, x, gamma, beta, npix, eps, y, stats);
+    dim3 grid(nblocks(npix * ln_lpp(C), 256 * 4));
+    LN_DISPATCH(ln_fwd_kernel, x, gamma, beta, npix, C, eps, y, stats);
     BMC_CHECK_LAUNCH("bmc_layernorm_fwd");
     return 0;
 }
@@ -459,10 +472,10 @@ extern "C" int bmc_layernorm_fwd(const float* x, const float* gamma, const float
 extern "C" int bmc_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, long long npix,
                                  int C, float* dx, float* ws, float* dgamma, float* dbeta, int accumulate, bmc_stream_t s) {
     hipStream_t st = (hipStream_t)s;
-    int nb = nblocks(npix * (C / 4), 256 * 4);
+    int nb = nblocks(npix * ln_lpp(C), 256 * 4);
     if (nb > 1024) nb = 1024;
     dim3 grid(nb);
-    LN_DISPATCH(ln_bwd_kernel, dy, x, stats, gamma, npix, dx, ws);
+    LN_DISPATCH(ln_bwd_kernel, dy, x, stats, gamma, npix, C, dx, ws);
     hipLaunchKernelGGL(ln_bwd_finish, dim3(2 * C), dim3(256), 0, st, ws, nb, C, dgamma, dbeta, accumulate);
     BMC_CHECK_LAUNCH("bmc_layernorm_bwd");
     return 0;

@@ -10,6 +10,8 @@ Execution differs from the reference on purpose (results do not):
     batch; the three conv_fs calls run as one launch over a tripled batch;
   * ReLU, bias and residual adds live in convolution epilogues.
 """
+import torch.nn.functional as F
+
 from .submodules import *  # noqa: F401,F403  (same star-import surface as the reference)
 from .submodules import BIE, PixelUnShuffle, ResidualBlock_noBN, initialize_weights, to_nchw, to_nhwc
 from bmc_hip import bie, ops
@@ -64,9 +66,12 @@ class Backbone(nn.Module):
         super().__init__()
         pad = (1, 1)
         s2 = scale ** 2
-        if s2 % 16 or n_c % 16 or 2 * repeat > 16:
-            raise NotImplementedError("bmc_hip BMCNet needs scale^2 and n_c to be multiples of 16 and repeat <= 8 "
+        if s2 % 4 or n_c % 16 or 2 * repeat > 16:
+            raise NotImplementedError("bmc_hip BMCNet needs an even scale, n_c a multiple of 16 and repeat <= 8 "
                                       "(scale=%d, n_c=%d, repeat=%d)" % (scale, n_c, repeat))
+        # the kernels read operands in 16-channel granules: the s^2 sub-pixel channels of each polarity half of o (4 at
+        # x2 SR) are carried in tensors padded to s2p channels, and conv_o's 2 s^2 outputs in a tensor padded to cop
+        self.s2, self.s2p, self.cop = s2, ops.round_up(s2, 16), ops.round_up(2 * s2, 16)
         self.conv_fpst = nn.Conv2d(s2 + n_c + 2 * repeat, n_c, 3, 1, padding=pad)
         self.conv_fnst = self.conv_fpst
         self.conv_fps = nn.Conv2d(repeat + n_c, n_c, 3, 1, padding=pad)
@@ -84,12 +89,13 @@ class Backbone(nn.Module):
         pad16 = lambda used: list(used) + [-1] * (16 - len(used))
         rng = lambda a, n: list(range(a, a + n))
         # packed-K layouts (reference concat orders: models/BMCNet.py:60-73,78-82)
-        self._sp_fpst = ConvSpec([pad16(rng(0, 2 * r)), rng(2 * r, n_c), rng(2 * r + n_c, s2)])
+        padk = lambda a, n: rng(a, n) + [-1] * (self.s2p - n)
+        self._sp_fpst = ConvSpec([pad16(rng(0, 2 * r)), rng(2 * r, n_c), padk(2 * r + n_c, s2)])
         self._sp_fps = ConvSpec([pad16([-1] * r + rng(0, r)), rng(r, n_c)])
         # conv_fs is applied three times to cat[xp_st, xn_st, h*, o] with only h* changing (models/BMCNet.py:70-73):
         # the contribution of the shared 2*n_c + 2*s2 input channels is computed once (with the bias), the h* part per call
-        self._sp_fs_shared = ConvSpec([rng(0, n_c), rng(n_c, n_c), rng(2 * n_c, s2), rng(2 * n_c + s2, s2)])
-        self._sp_fs = ConvSpec([rng(0, n_c), rng(n_c, n_c), rng(2 * n_c, n_c), rng(3 * n_c, s2), rng(3 * n_c + s2, s2)])
+        self._sp_fs_shared = ConvSpec([rng(0, n_c), rng(n_c, n_c), padk(2 * n_c, s2), padk(2 * n_c + s2, s2)])
+        self._sp_fs = ConvSpec([rng(0, n_c), rng(n_c, n_c), rng(2 * n_c, n_c), padk(3 * n_c, s2), padk(3 * n_c + s2, s2)])
         self._sp_h = ConvSpec.dense(n_c)
         self._sp_o = ConvSpec.dense(n_c, n_c)
         self.n_c = n_c
@@ -124,7 +130,13 @@ class Backbone(nn.Module):
         hb = torch.stack([self.conv_hp.bias, self.conv_hn.bias])
         x_hpn = ops.conv([View(sst12)], hw, hb, self._sp_h, relu=True, G=2, cache=False, out=ops.OutSlot(hbuf, B))
         x_hp, x_hn = bie.Unstack2Fn.apply(x_hpn)
-        x_o = ops.conv([View(s12, b0=0), View(s12, b0=B)], self.conv_o.weight, self.conv_o.bias, self._sp_o, B=B)
+        w_o, b_o = self.conv_o.weight, self.conv_o.bias
+        if self.cop != 2 * self.s2:        # x2 SR: 8 output channels -> computed as 16 (zero rows), the head reads the first 8
+            w_o = F.pad(w_o, (0, 0, 0, 0, 0, 0, 0, self.cop - 2 * self.s2))
+            b_o = F.pad(b_o, (0, self.cop - 2 * self.s2))
+        x_o = ops.conv([View(s12, b0=0), View(s12, b0=B)], w_o, b_o, self._sp_o, B=B, cache=self.cop == 2 * self.s2)
+        if self.cop != 2 * self.s2:
+            x_o = x_o[..., :2 * self.s2].contiguous()
         return x_h, x_hp, x_hn, x_o
 
     def forward(self, xs, hp, hn, hs, o):
@@ -136,8 +148,12 @@ class Backbone(nn.Module):
         xin12 = torch.cat([z(x1p, x2p), z(x1n, x2n)], 0).contiguous()
         h3 = torch.cat([to_nhwc(hp), to_nhwc(hn), to_nhwc(hs)], 0)
         on = to_nhwc(o)
-        o12 = torch.cat([on[..., :s2], on[..., s2:]], 0).contiguous()
+        o12 = self.pad_o(torch.cat([on[..., :s2], on[..., s2:]], 0).contiguous())
         return tuple(to_nchw(t) for t in self.forward_nhwc(xin12, h3, o12))
+
+    def pad_o(self, o12):
+        """[2B,H,W,s^2] -> [2B,H,W,s2p] (zero channels up to the 16-channel granule; a no-op for x4 / x8 SR)."""
+        return o12 if self.s2p == self.s2 else F.pad(o12, (0, self.s2p - self.s2))
 
 
 class BMCNet(nn.Module):
@@ -167,6 +183,7 @@ class BMCNet(nn.Module):
             o12 = torch.cat([on[..., :s2], on[..., s2:]], 0)
         else:       # the previous HR prediction, unshuffled straight into the batch-stacked channel halves
             o12 = ops.pixel_unshuffle_nhwc(x_o, self.scale, split=2)
+        o12 = self.neuro.pad_o(o12)
         # the reference passes (x_h, x_h_p, x_h_n) positionally into Backbone.forward(xs, hp, hn, hs, o)
         # (models/BMCNet.py:115,118 vs :57): x_h acts as hp, x_h_p as hn, x_h_n as hs.
         h3 = ops.stack_states([x_h, x_h_p, x_h_n])

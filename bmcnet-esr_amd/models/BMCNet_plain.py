@@ -1,5 +1,7 @@
 """BMCNet_plain on MI355X: reference-compatible signatures and state_dict keys
 (reference: models/BMCNet_plain.py), gfx950 kernels underneath."""
+import torch.nn.functional as F
+
 from .submodules import *  # noqa: F401,F403
 from .submodules import BIE, PixelUnShuffle, initialize_weights, to_nchw, to_nhwc
 from bmc_hip import ops
@@ -13,8 +15,9 @@ class Backbone(nn.Module):
         super().__init__()
         pad = (1, 1)
         s2 = scale ** 2
-        if s2 % 16 or n_c % 16 or 2 * repeat > 16:
-            raise NotImplementedError("bmc_hip BMCNet_plain needs scale^2 and n_c to be multiples of 16, repeat <= 8")
+        if s2 % 4 or n_c % 16 or 2 * repeat > 16:
+            raise NotImplementedError("bmc_hip BMCNet_plain needs an even scale, n_c a multiple of 16 and repeat <= 8")
+        self.s2, self.s2p, self.cop = s2, ops.round_up(s2, 16), ops.round_up(2 * s2, 16)      # see models/BMCNet.py
         self.conv_f1 = nn.Conv2d(s2 + n_c + 2 * repeat, n_c, 3, 1, padding=pad)
         self.conv_f2 = self.conv_f1
         self.conv_fs = nn.Conv2d(s2 * 2 + n_c + 2 * 2 * repeat, n_c, 3, 1, padding=pad)
@@ -26,9 +29,10 @@ class Backbone(nn.Module):
         r = repeat
         pad16 = lambda used: list(used) + [-1] * (16 - len(used))
         rng = lambda a, n: list(range(a, a + n))
-        self._sp_f1 = ConvSpec([pad16(rng(0, 2 * r)), rng(2 * r, n_c), rng(2 * r + n_c, s2)])
-        self._sp_fs = ConvSpec([pad16(rng(0, 2 * r)), pad16(rng(2 * r, 2 * r)), rng(4 * r, n_c), rng(4 * r + n_c, s2),
-                                rng(4 * r + n_c + s2, s2)])
+        padk = lambda a, n: rng(a, n) + [-1] * (self.s2p - n)
+        self._sp_f1 = ConvSpec([pad16(rng(0, 2 * r)), rng(2 * r, n_c), padk(2 * r + n_c, s2)])
+        self._sp_fs = ConvSpec([pad16(rng(0, 2 * r)), pad16(rng(2 * r, 2 * r)), rng(4 * r, n_c), padk(4 * r + n_c, s2),
+                                padk(4 * r + n_c + s2, s2)])
         self._sp_h = ConvSpec.dense(n_c)
         self._sp_o = ConvSpec.dense(n_c, n_c)
 
@@ -41,8 +45,17 @@ class Backbone(nn.Module):
         for layer in self.para_reschunk:
             x12, xs = layer.forward_twin(x12, xs)
         x_h = ops.conv([View(xs)], self.conv_h.weight, self.conv_h.bias, self._sp_h, relu=True)
-        x_o = ops.conv([View(x12, b0=0), View(x12, b0=B)], self.conv_o.weight, self.conv_o.bias, self._sp_o, B=B)
+        w_o, b_o = self.conv_o.weight, self.conv_o.bias
+        if self.cop != 2 * self.s2:
+            w_o = F.pad(w_o, (0, 0, 0, 0, 0, 0, 0, self.cop - 2 * self.s2))
+            b_o = F.pad(b_o, (0, self.cop - 2 * self.s2))
+        x_o = ops.conv([View(x12, b0=0), View(x12, b0=B)], w_o, b_o, self._sp_o, B=B, cache=self.cop == 2 * self.s2)
+        if self.cop != 2 * self.s2:
+            x_o = x_o[..., :2 * self.s2].contiguous()
         return x_h, x_o
+
+    def pad_o(self, o12):
+        return o12 if self.s2p == self.s2 else F.pad(o12, (0, self.s2p - self.s2))
 
     def forward(self, xs, h, o):
         x1, x2 = xs
@@ -51,7 +64,7 @@ class Backbone(nn.Module):
         z = lambda a: torch.cat([to_nhwc(a), a.new_zeros(B, a.shape[2], a.shape[3], 16 - r2)], 3)
         xin12 = torch.cat([z(x1), z(x2)], 0).contiguous()
         on = to_nhwc(o)
-        o12 = torch.cat([on[..., :s2], on[..., s2:]], 0).contiguous()
+        o12 = self.pad_o(torch.cat([on[..., :s2], on[..., s2:]], 0).contiguous())
         return tuple(to_nchw(t) for t in self.forward_nhwc(xin12, to_nhwc(h), o12))
 
 
@@ -77,6 +90,7 @@ class BMCNet_plain(nn.Module):
             o12 = torch.cat([on[..., :s2], on[..., s2:]], 0)
         else:
             o12 = ops.pixel_unshuffle_nhwc(x_o, self.scale, split=2)
+        o12 = self.neuro.pad_o(o12)
         n_h, o = self.neuro.forward_nhwc(xin12, to_nhwc(x_h), o12)
         if _gt is not None:
             pred, mse = ops.head_mse(o, x[:, :, 1], _gt, self.scale)

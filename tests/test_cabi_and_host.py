@@ -100,7 +100,8 @@ def test_no_cpu_fallback():
 
 def test_unsupported_shapes_fail_loudly():
     from models.BMCNet import BMCNet
+    BMCNet(2, 16, 1)           # x2 SR (config/train_nfs.yml: SCALE 2/4/8): 4 sub-pixel channels, padded to the 16-channel granule
     with pytest.raises(NotImplementedError):
-        BMCNet(2, 16, 1)       # scale^2 = 4 is not a multiple of 16
+        BMCNet(3, 16, 1)       # odd scales: scale^2 is not a multiple of 4
     with pytest.raises(NotImplementedError):
         BMCNet(4, 8, 1)        # n_c = 8 is not a multiple of 16

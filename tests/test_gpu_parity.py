@@ -608,7 +608,9 @@ def test_training_reduces_loss_and_matches_oracle_trajectory(math):
 @pytest.mark.parametrize("cls_name,scale,n_c,n_b,H,W", [
     ("BMCNet", 8, 16, 1, 9, 11),          # x8 SR: 64-channel pixel-unshuffle halves, 128-channel conv_o
     ("BMCNet_plain", 4, 64, 1, 12, 20),   # n_c = 64: half-filled 128-channel tiles, LayerNorm over 64 channels
-    ("BMCNet", 4, 48, 2, 10, 17),         # n_c = 48 is not a power of two -> LayerNorm must refuse loudly
+    ("BMCNet", 4, 48, 2, 10, 17),         # n_c = 48 is not a power of two: LayerNorm with idle lanes, 3 chunks of 16
+    ("BMCNet", 2, 32, 1, 11, 13),         # x2 SR (config/train_nfs.yml SCALE 2): 4 sub-pixel channels per polarity, padded granules
+    ("BMCNet_plain", 2, 16, 2, 9, 14),    # x2 SR, plain model
 ])
 def test_other_model_shapes_vs_oracle(cls_name, scale, n_c, n_b, H, W):
     dev = _gpu()
@@ -631,10 +633,6 @@ def test_other_model_shapes_vs_oracle(cls_name, scale, n_c, n_b, H, W):
     gts = [gt[:, i + 1] for i in range(L - 1)]
     m.to(dev)
     z = lambda c: torch.zeros(B, c, H, W, device=dev)
-    if n_c == 48:
-        with pytest.raises(RuntimeError, match="unsupported"):
-            m(xs[0].to(dev), z(n_c), z(n_c), z(n_c), z(2 * scale * scale), True)
-        return
     loss_ref, preds_ref, _ = O.bptt_loss(params, xs, gts, n_c, scale, plain)
     loss_ref.backward()
     state = (z(n_c), z(2 * scale * scale)) if plain else (z(n_c), z(n_c), z(n_c), z(2 * scale * scale))
