@@ -88,17 +88,23 @@ def dominant_kernel_roofline(step_fn, iso, math="fp32"):
         a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1)
     n, fl, ms = agg["conv_kernel<9,128>"]
     ach = fl / (ms * 1e-3) / 1e12
-    traffic = None      # HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), never computed here
-    tj = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+    # HBM bytes per launch: from the committed rocprofv3 PMC passes over one bench step (profiles/r02_pmc_summary.json:
+    # the AVERAGE in-step launch of this kernel, FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes;
+    # tools/pmc_summary.py) -- never computed here
+    traffic, pmc = None, None
+    tj = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     if os.path.exists(tj):
-        entry = json.load(open(tj)).get({"fp32": "conv_kernel<9,128>", "bf16x6": "conv_bf_kernel<9,128,8,3>"}.get(math, ""))
-        traffic = entry["hbm_bytes_per_launch"] if entry else None
+        entry = json.load(open(tj)).get(math, {}).get({"fp32": "conv_kernel<9,128,8>", "bf16x6": "conv_bf_kernel<9,128,8,3>",
+                                                         "bf16": "conv_bf_kernel<9,128,8,1>"}[math])
+        if entry:
+            traffic = entry.get("hbm_bytes_per_launch")
+            pmc = {k: entry[k] for k in ("mfma_busy_frac", "in_kernel_clock_GHz", "hbm_GBps") if k in entry}
     peak = KERNEL_PEAK[math]
     out = {"bound": "mfma", "kernel": "%s (3x3 implicit GEMM fwd + dgrad, all %d launches of one step)" % (KERNEL_NAME[math], n),
            "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
            "frac": round(ach / peak, 4), "traffic": traffic,
            "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n, "launches_per_step": n,
-           "isolated_2B_128to128": iso,
+           "isolated_2B_128to128": iso, "pmc": pmc,
            "other_kernels": {k: {"launches": v[0], "achieved_tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2),
                                  "avg_launch_ms": round(v[2] / v[0], 4)} for k, v in agg.items() if k != "conv_kernel<9,128>"}}
     return out
@@ -254,8 +260,9 @@ def main():
     if args.math == "fp32" and not args.no_bf16x6 and not args.graph:
         ops.set_math("bf16x6")
         dt6, loss6 = timed(eager_step, 1, args.steps)
+        roof6 = dominant_kernel_roofline(eager_step, None, "bf16x6")
         ops.set_math("fp32")
-        split = (dt6, float(loss6))
+        split = (dt6, float(loss6), roof6)
     if rank == 0:
         windows = L - 1
         frames_per_step = world * B * windows
@@ -280,8 +287,10 @@ def main():
             "roofline": roof,
         }
         if split is not None:
-            dt6, loss6 = split
+            dt6, loss6, roof6 = split
+            roof6.pop("isolated_2B_128to128", None)
             out["bf16x6_mode"] = {
+                "roofline": roof6,
                 "value": round(frames_per_step * args.steps / dt6, 3), "unit": "LR-voxel-frames/s",
                 "ms_per_step": round(dt6 / args.steps * 1e3, 2), "steps": args.steps, "warmup": 1,
                 "final_loss": round(loss6, 6),

@@ -540,3 +540,88 @@ def test_voxel_full_size_is_deterministic_and_conserves_weight():
         assert np.array_equal(v1[f].cpu().numpy(), ref)
     inr = (xs >= 0) & (xs < W) & (ys >= 0) & (ys < H)
     assert abs(v1.double().sum().item() - float(ps[inr].astype(np.float64).sum())) < 20.0      # + the quirk's (H-1, 0) deposits
+
+
+# ------------------------------------------------------------------ bf16x6 arithmetic on adversarial operands
+def _conv_err_vs_f64(x, w, k, math):
+    """-> (y, error of the HIP conv / sum_k |x||w| per output, i.e. relative to the condition-independent scale)."""
+    from bmc_hip import ops
+    from bmc_hip.ops import ConvSpec, View
+    ops.set_math(math)
+    with torch.no_grad():
+        y = ops.conv([View(x)], w, None, ConvSpec.dense(x.shape[-1]))
+    xd, wd = x.double().cpu().permute(0, 3, 1, 2), w.double().cpu()
+    ref = F.conv2d(xd, wd, None, padding=k // 2).permute(0, 2, 3, 1)
+    scale = F.conv2d(xd.abs(), wd.abs(), None, padding=k // 2).permute(0, 2, 3, 1)
+    return y, ((y.double().cpu() - ref).abs() / scale.clamp_min(1e-300)).max().item()
+
+
+@pytest.mark.parametrize("k", [3, 1])
+def test_bf16x6_wide_dynamic_range_and_cancellation(k):
+    """bf16x6 (three exact bf16 planes per fp32 operand, six plane products, fp32 accumulation) against float64 on
+    operands a Gaussian test never produces: magnitudes spread over 2^-40 .. 2^40 in BOTH operands (products over
+    2^-80 .. 2^80: the planes' relative weights 1, 2^-8, 2^-16 must hold at every exponent), and exactly cancelling
+    channel pairs (x, -x with equal weights: every plane product has an exact opposite).  Error is measured against
+    sum |x||w| (the scale any fp32 summation's rounding error is proportional to); the bar is the native fp32 MFMA's own
+    error on the same data x 2 -- the mode claims fp32 equivalence, not more."""
+    dev = _gpu()
+    g = torch.Generator().manual_seed(5 + k)
+    B, H, W, Cn = 2, 24, 40, 128
+    mant = lambda *s: (1.0 + torch.rand(*s, generator=g)) * (torch.randint(0, 2, s, generator=g) * 2 - 1)
+    x = (mant(B, H, W, Cn) * torch.exp2(torch.randint(-40, 41, (B, H, W, Cn), generator=g).float())).to(dev)
+    w = (mant(Cn, Cn, k, k) * torch.exp2(torch.randint(-40, 41, (Cn, Cn, k, k), generator=g).float())).to(dev)
+    _, e32 = _conv_err_vs_f64(x, w, k, "fp32")
+    y6, e6 = _conv_err_vs_f64(x, w, k, "bf16x6")
+    print("wide range k=%d: max |err| / sum|x||w|: fp32 %.2e  bf16x6 %.2e" % (k, e32, e6))
+    assert torch.isfinite(y6).all()
+    assert e32 < 2e-6 and e6 < max(2 * e32, 2.5e-7)
+    # exact cancellation: channel 2j+1 = -channel 2j, same weights -> the exact result is 0 everywhere
+    xc = torch.randn(B, H, W, Cn, generator=g).to(dev)
+    xc[..., 1::2] = -xc[..., 0::2]
+    wc = torch.randn(Cn, Cn, k, k, generator=g).to(dev)
+    wc[:, 1::2] = wc[:, 0::2]
+    yc32, c32 = _conv_err_vs_f64(xc, wc, k, "fp32")
+    yc6, c6 = _conv_err_vs_f64(xc, wc, k, "bf16x6")
+    print("cancellation k=%d: max |y| / sum|x||w|: fp32 %.2e  bf16x6 %.2e" % (k, c32, c6))
+    assert c32 < 2e-6 and c6 < max(2 * c32, 2.5e-7)
+
+
+def test_bf16x6_denormals_and_nonfinite_semantics():
+    """Documented exceptional-value behaviour of the split arithmetic (DESIGN.md, bf16-plane modes):
+      * subnormal fp32 operands: each plane is a (sub)normal bf16 the matrix core may flush -- the result may lose them, i.e.
+        differ from float64 by at most K * 2^-126 * max|w| (absolute), never by more;
+      * a +-Inf operand splits into (Inf, NaN, NaN): outputs that touch it are NaN (native fp32 MFMA: +-Inf or NaN),
+        a NaN operand gives NaN in both modes; outputs that do not touch them are unaffected."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from bmc_hip.ops import ConvSpec, View
+    g = torch.Generator().manual_seed(9)
+    B, H, W, Cn, k = 1, 16, 32, 128, 3
+    x = torch.randn(B, H, W, Cn, generator=g)
+    x[:, :, :16] *= 1e-41                     # left half of the image: subnormal activations
+    w = torch.randn(Cn, Cn, k, k, generator=g) / 34.0
+    x, w = x.to(dev), w.to(dev)
+    y6, _ = _conv_err_vs_f64(x, w, k, "bf16x6")
+    ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu(), None, padding=1).permute(0, 2, 3, 1)
+    aerr = (y6.double().cpu() - ref).abs()
+    bound = Cn * k * k * 2.0 ** -126 * w.abs().max().item()
+    assert aerr[:, :, :14].max().item() <= bound, (aerr[:, :, :14].max().item(), bound)          # purely subnormal windows
+    assert (aerr[:, :, 18:] / ref[:, :, 18:].abs().clamp_min(1e-3)).max().item() < 1e-4          # normal windows untouched
+    # non-finite operands
+    x2 = torch.randn(B, H, W, Cn, generator=g).to(dev)
+    x2[0, 3, 5, 7] = float("inf")
+    x2[0, 10, 20, 9] = float("nan")
+    ops.set_math("bf16x6")
+    with torch.no_grad():
+        y = ops.conv([View(x2)], w, None, ConvSpec.dense(Cn))
+    touched = torch.zeros(H, W, dtype=torch.bool)
+    touched[2:5, 4:7] = True
+    touched[9:12, 19:22] = True
+    yc = y[0].cpu()
+    assert torch.isnan(yc[touched]).all()
+    assert torch.isfinite(yc[~touched]).all()
+    ops.set_math("fp32")
+    with torch.no_grad():
+        y32 = ops.conv([View(x2)], w, None, ConvSpec.dense(Cn))[0].cpu()
+    assert (~torch.isfinite(y32[touched])).all() and torch.isfinite(y32[~touched]).all()
+    assert rel_l2(yc[~touched], y32[~touched]) < 1e-5
