@@ -606,7 +606,8 @@ def test_bf16x6_denormals_and_nonfinite_semantics():
     aerr = (y6.double().cpu() - ref).abs()
     bound = Cn * k * k * 2.0 ** -126 * w.abs().max().item()
     assert aerr[:, :, :14].max().item() <= bound, (aerr[:, :, :14].max().item(), bound)          # purely subnormal windows
-    assert (aerr[:, :, 18:] / ref[:, :, 18:].abs().clamp_min(1e-3)).max().item() < 1e-4          # normal windows untouched
+    scale = F.conv2d(x.double().cpu().permute(0, 3, 1, 2).abs(), w.double().cpu().abs(), None, padding=1).permute(0, 2, 3, 1)
+    assert (aerr[:, :, 18:] / scale[:, :, 18:]).max().item() < 2.5e-7                             # normal windows: fp32-class error
     # non-finite operands
     x2 = torch.randn(B, H, W, Cn, generator=g).to(dev)
     x2[0, 3, 5, 7] = float("inf")
