@@ -136,6 +136,7 @@ def _dgrad(g_src, w4, spec, src_index, owner, out, B, residual=None, mask=None, 
 
 
 def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, w_param, b_param, G=1, w_shape=None):
+    # (w_param / b_param: a parameter, None, or for G > 1 a tuple of the G parameters of the weight groups)
     """Weight gradient + bias gradient (column sums of the same A operand, taken from the tiles the pixel-reduction
     GEMM stages anyway) -> (dW, db) for autograd; None where the sums went straight into the leaf parameters' .grad
     (ops.reduce_wgrad).  G > 1 (stacked per-group weights): w_param None, result [G, ...]."""
@@ -197,6 +198,7 @@ class BIETwinFn(torch.autograd.Function):
         ctx.save_for_backward(x12, xs, t12, z12, stats, y12, c12, v12, p, rw1, rw2, wf, gamma, wc, wu, wv1, wv2, beta)
         ctx.owners = (rw1, rw2, wf, wc, wu)
         ctx.params = (rw1, rb1, rw2, rb2, wf, bf, gamma, beta, wc, bc, wu, bu)     # the caller's objects (gradient sinks)
+        ctx.vparams = (wv1, wv2, bv1, bv2)
         ctx.scale = scale
         ctx.fused = fused
         return o12, xs_new
@@ -238,7 +240,8 @@ class BIETwinFn(torch.autograd.Function):
         # ---- unclustering(cat[c1, c2]) + xs: weight gradient
         dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu)
         # ---- value convs (two weight groups)
-        dwv, dbv = _wgrad(X(dv12), [X(x12)], s1, B2, H, W, 1, Cn, dev, None, None, G=2, w_shape=(2, Cn, Cn, 1, 1))
+        dwv, dbv = _wgrad(X(dv12), [X(x12)], s1, B2, H, W, 1, Cn, dev, ctx.vparams[:2], ctx.vparams[2:], G=2,
+                          w_shape=(2, Cn, Cn, 1, 1))
         if ctx.fused:
             # ---- clustering, LayerNorm, convf: ONE data-gradient launch (csrc/chain.hip); y12 holds yhat, stats rstd.
             # dx12 = conv_f^T (second half of its inputs), dxs = skip + conv_f^T (first half) summed over both halves.
@@ -291,8 +294,8 @@ class BIETwinFn(torch.autograd.Function):
         dw1, db1 = _wgrad(X(dt), [X(x12)], s1, B2, H, W, 9, Cn, dev, p_rw1, p_rb1)
         _dgrad(X(dt), w_r1, s1, 0, o_rw1, dx12, B2, residual=g_r, accumulate=True)                       # dx12 += conv1^T + skip
         v = lambda t, ref: None if t is None else t.view(ref.shape)
-        return (dx12, dxs, dw1, db1, dw2, db2, dwf, dbf, dgamma, dbeta, v(dwc, wc), dbc, dwu, dbu,
-                dwv[0].reshape(wv1.shape), dbv[0], dwv[1].reshape(wv2.shape), dbv[1], None, None)
+        gv = (None,) * 4 if dwv is None else (dwv[0].reshape(wv1.shape), dbv[0], dwv[1].reshape(wv2.shape), dbv[1])
+        return (dx12, dxs, dw1, db1, dw2, db2, dwf, dbf, dgamma, dbeta, v(dwc, wc), dbc, dwu, dbu, *gv, None, None)
 
 
 def bie_twin(m, x12, xs):

@@ -82,6 +82,7 @@ _split_w = _sig("bmc_split_weight", [_p, _p, _ll, _i, _i, _p])
 _conv = _sig("bmc_conv", [C.POINTER(ConvArgs), _p])
 _pgemm = _sig("bmc_pgemm", [C.POINTER(PgemmArgs), _p])
 _red_w = _sig("bmc_pgemm_reduce_weight", [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p])
+_red_wg = _sig("bmc_pgemm_reduce_weight_groups", [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p])
 _red_p = _sig("bmc_pgemm_reduce_plain", [_p, _i, _i, _i, _i, _f, _p, _p])
 _colsum = _sig("bmc_colsum", [_p, _ll, _i, _i, _p, _p, _i, _p])
 _relu_bwd = _sig("bmc_relu_bwd", [_p, _p, _p, _ll, _p])
@@ -106,7 +107,8 @@ EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_event
            "bmc_layernorm_fwd", "bmc_layernorm_bwd", "bmc_softmax_fwd", "bmc_softmax_bwd", "bmc_pack_inputs",
            "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr", "bmc_bicubic_resize_fwd", "bmc_bicubic_resize_bwd",
            "bmc_chain_fwd", "bmc_chain_bwd", "bmc_chain_affine_grads", "bmc_group_sum",
-           "bmc_head_mse_fwd", "bmc_head_mse_bwd", "bmc_events_to_stack_polarity", "bmc_events_to_mask"]
+           "bmc_head_mse_fwd", "bmc_head_mse_bwd", "bmc_events_to_stack_polarity", "bmc_events_to_mask",
+           "bmc_pgemm_reduce_weight_groups"]
 
 
 def check(rc, what):

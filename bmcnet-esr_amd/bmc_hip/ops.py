@@ -366,8 +366,21 @@ def sink_group(params):
 
 def reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bias_slabs, w_param, b_param, w_shape):
     """Sum the pixel-reduction GEMM's slabs into the weight (+ bias) gradient.  -> (dw, db) for autograd; entries are
-    None where the gradient went straight into a leaf parameter's .grad (see above)."""
+    None where the gradient went straight into a leaf parameter's .grad (see above).  w_param / b_param may be tuples of
+    G parameters (one per weight group of a grouped launch: v1 / v2, conv_hp / conv_hn)."""
     want_b = bias_slabs is not None
+    if isinstance(w_param, (tuple, list)):
+        ps = list(w_param) + (list(b_param) if want_b else [])
+        sg = sink_group(ps) if 1 < G <= 4 and len(w_param) == G else None
+        if sg is not None:
+            grads, acc = sg
+            PA = C.c_void_p * G
+            dwp = PA(*[g.data_ptr() for g in grads[:G]])
+            dbp = PA(*[g.data_ptr() for g in grads[G:]]) if want_b else None
+            lib.call(lib._red_wg, "bmc_pgemm_reduce_weight_groups", slabs.data_ptr(), nsplit, G, taps, Cout, spec.kpad,
+                     spec.kmap(dev).data_ptr(), spec.cin, dwp, acc, bias_slabs.data_ptr() if want_b else None, dbp, _stream())
+            return None, None
+        w_param = b_param = None
     sg = sink_group([w_param, b_param] if want_b else [w_param]) if G == 1 and w_param is not None else None
     if sg is not None:
         (gw, *rest), acc = sg

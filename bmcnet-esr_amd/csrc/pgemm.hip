@@ -239,9 +239,13 @@ __device__ __forceinline__ float split_sum(const float* p, long long slab, int n
     return t;
 }
 
+// Per-group destinations (weights stacked over groups for ONE launch but owned by separate parameters -- v1 / v2,
+// conv_hp / conv_hn): group g is written to gd.dw[g] / gd.db[g] instead of dw + g * M*Cin*taps / db + g * M.
+struct GroupDst { float* dw[4]; float* db[4]; int n; };
+
 __global__ void reduce_weight_kernel(const float* slabs, int nsplit, int G, int taps, int M, int N, int Mpad, int Npad,
                                      const int* kmap, int Cin, float* dw, int accumulate, const float* bias_slabs,
-                                     float* db, int wblocks) {
+                                     float* db, int wblocks, const GroupDst gd) {
     __shared__ float red[256];
     if ((int)blockIdx.x >= wblocks) {    // trailing blocks: bias gradient db[g][m] = sum over (split, part) partials
         const long long total = (long long)G * M;
@@ -258,7 +262,8 @@ __global__ void reduce_weight_kernel(const float* slabs, int nsplit, int G, int 
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) t += red[k * 32 + threadIdx.x];
-            db[idx] = accumulate ? db[idx] + t : t;
+            float* o = gd.n ? gd.db[g] + m : db + idx;
+            *o = accumulate ? *o + t : t;
         }
         return;
     }
@@ -280,7 +285,7 @@ __global__ void reduce_weight_kernel(const float* slabs, int nsplit, int G, int 
         }
         const float s = split_sum(p, slab, nsplit, red);
         if (threadIdx.x < 32 && ci >= 0) {
-            float* o = dw + (((long long)g * M + m) * Cin + ci) * taps + tap;
+            float* o = (gd.n ? gd.dw[g] : dw + (long long)g * M * Cin * taps) + ((long long)m * Cin + ci) * taps + tap;
             *o = accumulate ? *o + s : s;
         }
     }
@@ -374,9 +379,32 @@ extern "C" int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, in
     const long long total = (long long)G * taps * M * N;
     const int wblocks = (int)((total + 31) / 32 > 8192 ? 8192 : (total + 31) / 32);
     const int bblocks = bias_slabs ? (int)(((long long)G * M + 31) / 32) : 0;
+    GroupDst gd = {};
     hipLaunchKernelGGL(reduce_weight_kernel, dim3(wblocks + bblocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, taps,
-                       M, N, bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, dw, accumulate, bias_slabs, db, wblocks);
+                       M, N, bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, dw, accumulate, bias_slabs, db, wblocks, gd);
     BMC_CHECK_LAUNCH("bmc_pgemm_reduce_weight");
+    return 0;
+}
+
+extern "C" int bmc_pgemm_reduce_weight_groups(const float* slabs, int nsplit, int G, int taps, int M, int N, const int* kmap,
+                                              int Cin, float* const* dw, int accumulate, const float* bias_slabs,
+                                              float* const* db, bmc_stream_t stream) {
+    BMC_CHECK_ARG(slabs && dw && nsplit >= 1 && G >= 1 && G <= 4, "bmc_pgemm_reduce_weight_groups: bad args (1 <= G <= 4)");
+    BMC_CHECK_ARG((bias_slabs == nullptr) == (db == nullptr), "bmc_pgemm_reduce_weight_groups: bias_slabs and db go together");
+    GroupDst gd = {};
+    gd.n = G;
+    for (int g = 0; g < G; ++g) {
+        BMC_CHECK_ARG(dw[g] && (!db || db[g]), "bmc_pgemm_reduce_weight_groups: null destination for group %d", g);
+        gd.dw[g] = dw[g];
+        gd.db[g] = db ? db[g] : nullptr;
+    }
+    const long long total = (long long)G * taps * M * N;
+    const int wblocks = (int)((total + 31) / 32 > 8192 ? 8192 : (total + 31) / 32);
+    const int bblocks = bias_slabs ? (int)(((long long)G * M + 31) / 32) : 0;
+    hipLaunchKernelGGL(reduce_weight_kernel, dim3(wblocks + bblocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, taps,
+                       M, N, bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, nullptr, accumulate, bias_slabs, nullptr,
+                       wblocks, gd);
+    BMC_CHECK_LAUNCH("bmc_pgemm_reduce_weight_groups");
     return 0;
 }
 

@@ -180,6 +180,12 @@ int bmc_pgemm(const bmc_pgemm_args_t* host_args, bmc_stream_t s);
 int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, int taps, int M, int N, const int* kmap,
                             int Cin, float* dw, int accumulate, const float* bias_slabs /* or NULL */,
                             float* db /* [G][M] or NULL */, bmc_stream_t s);
+/* the same with one destination per group (HOST arrays of G <= 4 device pointers): weights that ONE grouped launch stacks
+ * but that belong to separate parameters (v1 / v2, conv_hp / conv_hn) -- each group's sum goes (=|+=) straight to its own
+ * dw[g] [M][Cin][taps] / db[g] [M]. */
+int bmc_pgemm_reduce_weight_groups(const float* slabs, int nsplit, int G, int taps, int M, int N, const int* kmap,
+                                   int Cin, float* const* dw, int accumulate, const float* bias_slabs, float* const* db,
+                                   bmc_stream_t s);
 /* slabs -> out[G][M][N] * scale */
 int bmc_pgemm_reduce_plain(const float* slabs, int nsplit, int G, int M, int N, float scale,
                            float* out, bmc_stream_t s);
