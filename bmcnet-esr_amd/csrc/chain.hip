@@ -27,6 +27,7 @@
 // Weight gradients stay with the pixel-reduction GEMM (pgemm.hip): it reads (dcentre, yhat) and (dz, s0, s1); the
 // LayerNorm affine gradients follow algebraically from its results (bmc_chain_affine_grads below).
 #include "bmc_common.h"
+#include "dma_ring.h"
 
 #ifndef BMC_CHAIN_ABL
 #define BMC_CHAIN_ABL 0     // ablation bits for tools/ builds only: 1 no MFMAs, 2 no DMA issue, 4 no global stores,
@@ -55,26 +56,6 @@ struct ChainK {
     int H, W, tiles_x, tiles_y, nunits;
 };
 
-// 16 bytes per lane from global memory straight into LDS (lane-linear image at the wave-uniform LDS byte address):
-// address = uniform base (SGPR pair) + this lane's 32-bit byte offset.  Inline asm on purpose -- the compiler must not
-// track these as LDS stores (it would drain vmcnt(0) before every later ds_read and the rings could never run ahead);
-// completion is waited for with counted vmcnt (dma_wait) before the barrier that publishes a stage.
-// (readfirstlane: the base pointer and the LDS address are wave-uniform, but must BE in SGPRs; s_nop 4: wait states between
-// the VALU-written SGPRs / m0 and the VMEM instruction -- inline asm is opaque to the hazard recognizer.  m0 is reserved and
-// cannot be named as a clobber; nothing else in this kernel uses it.)
-__device__ __forceinline__ void dma16(const void* gbase, unsigned voff, unsigned lds_addr) {
-    const unsigned long long pv = reinterpret_cast<unsigned long long>(gbase);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pv), hi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
-    const void* const sb = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
-    const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(la) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void dma_wait() {   // all but the newest N vector-memory operations of this wave are done
-    static_assert(N >= 0 && N < 64, "vmcnt range");
-    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
-}
-
 // Two (or more) independent workgroups per CU hide each other's LayerNorm / epilogue / barrier phases (a first version
 // with 32x32x2 MFMAs needed 128 accumulator registers per lane for its two result tiles = one workgroup per CU, and ran
 // its matrix pipes only 60 % busy: every non-MFMA instruction of the single wave per SIMD was exposed).  Both operand
@@ -84,8 +65,6 @@ __device__ __forceinline__ void dma_wait() {   // all but the newest N vector-me
 // ring; all four compute.  Rows are 64 B without padding; the 16-byte quads of a row are XOR-swizzled with
 // SWZ[(row >> 2) & 3] on the DMA's SOURCE address and on the fragment reads (conflict-free ds_read_b128 for the
 // 16-row x 4-quad fragment shape), the LDS destination of a DMA stays lane-linear.
-__device__ __forceinline__ int swz(int row) { return (0x1320 >> (4 * ((row >> 2) & 3))) & 3; }      // {0, 2, 3, 1}
-
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     if (BMC_CHAIN_ABL & 1) { c[0] += a * b; return c; }      // ablation: one VALU fma instead, operands stay live
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

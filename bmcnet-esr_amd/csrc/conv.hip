@@ -503,6 +503,10 @@ extern "C" int bmc_conv(const bmc_conv_args_t* h, bmc_stream_t stream) {
                   "bmc_conv: unknown math mode %d", h->math);
     if (h->math != BMC_MATH_FP32)
         return bmc_conv_bf_launch(k, h->taps, BN, THv, h->math == BMC_MATH_BF16 ? 1 : 3, cus, (hipStream_t)stream);
+    if (h->taps == 1 && !getenv("BMC_NO_CONV1") && bmc_conv1_launch(k, cus, (hipStream_t)stream)) {
+        BMC_CHECK_LAUNCH("bmc_conv (conv1)");
+        return 0;
+    }
     const int per_cu = (BN == 128 && THv == 8) ? 3 : 4;       // resident workgroups per CU (LDS / registers)
     const int max_blocks = cus * per_cu;
     dim3 grid((unsigned)(ntiles < max_blocks ? ntiles : max_blocks)), block(256);

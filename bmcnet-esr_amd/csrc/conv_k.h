@@ -24,3 +24,7 @@ struct ConvK {
 // conv_bf.hip: launch the bf16-plane kernel (planes = 1: bf16 operands; 3: fp32 operands split into three bf16 planes,
 // six plane products -- fp32-equivalent result) for an already validated argument block.
 int bmc_conv_bf_launch(const ConvK& k, int taps, int BN, int TH, int planes, int cus, hipStream_t st);
+
+// conv1.hip: 1x1 convolution on the 16x16x4 fp32 MFMA with LDS-DMA operand rings (large problems).  Returns 1 if it
+// launched the problem, 0 if it is left to conv.hip's kernel.
+int bmc_conv1_launch(ConvK k, int cus, hipStream_t st);

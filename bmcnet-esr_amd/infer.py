@@ -39,6 +39,14 @@ class StreamingSR:
             self.times_ms.append(start.elapsed_time(end))
         return out[-1]
 
+    @staticmethod
+    @torch.no_grad()
+    def esr_mse(pred, gt):
+        """The evaluation metric of infer_BMCNet.py:76-84: bicubic-resize the prediction to the ground truth's size when
+        they differ (:77-78; EventZoom: 124x224 vs 124x222), then the mean squared error."""
+        from bmc_hip import ops
+        return torch.nn.functional.mse_loss(ops.bicubic_resize(pred, gt.shape[-2:]), gt)
+
     def latency_ms(self, skip=1):
         """Mean per-window latency (the reference's `time` metric), ignoring the first `skip` windows."""
         t = self.times_ms[skip:] or self.times_ms

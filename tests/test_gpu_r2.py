@@ -626,3 +626,66 @@ def test_bf16x6_denormals_and_nonfinite_semantics():
         y32 = ops.conv([View(x2)], w, None, ConvSpec.dense(Cn))[0].cpu()
     assert (~torch.isfinite(y32[touched])).all() and torch.isfinite(y32[~touched]).all()
     assert rel_l2(yc[~touched], y32[~touched]) < 1e-5
+
+
+# ------------------------------------------------------------------ conv1.hip: the 16x16x4 / LDS-DMA-ring 1x1 convolution
+def test_conv1_kernel_all_epilogues_vs_old_kernel_and_float64():
+    """Runs in a child process with BMC_CONV1_MIN_TILES=0 (so that small problems take conv1.hip too) and compares, on
+    random 1x1 problems covering every epilogue feature (multi-source, batch maps, per-sample / per-group weights, bias,
+    residual with rotation, ReLU, mask, accumulate, narrow outputs, ragged images), conv1.hip against float64 and against
+    conv.hip's kernel (BMC_NO_CONV1=1)."""
+    _gpu()
+    import subprocess
+    code = r'''
+import os, sys, json
+import torch, torch.nn.functional as F
+sys.path[:0] = [ROOT, os.path.join(ROOT, "bmcnet-esr_amd")]
+from bmc_hip import ops, lib
+from bmc_hip.ops import ConvSpec, View, _src, conv_raw, _packed_weight, coutpad
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(int(os.environ["SEED"]))
+out = []
+for case in range(14):
+    B = int(torch.randint(1, 5, (1,), generator=g)); H = int(torch.randint(3, 30, (1,), generator=g)); W = int(torch.randint(3, 45, (1,), generator=g))
+    nsrc = int(torch.randint(1, 4, (1,), generator=g))
+    nchs = [16 * int(torch.randint(1, 9, (1,), generator=g)) for _ in range(nsrc)]
+    Cout = [128, 128, 32, 64, 16, 256][case % 6]
+    G = [1, B, 1, 1][case % 4] if B > 1 else 1
+    relu, use_res, use_mask, acc, bias = case % 2 == 0, case % 3 == 0, case % 5 == 1, case % 4 == 2, case % 3 != 1
+    xs = [torch.randn(B, H, W, c, generator=g).to(dev) for c in nchs]
+    cin = sum(nchs)
+    w = (torch.randn(G, Cout, cin, 1, generator=g) / cin ** 0.5).to(dev)
+    b = (torch.randn(G, Cout, generator=g) * 0.3).to(dev) if bias else None
+    res = torch.randn(B, H, W, Cout, generator=g).to(dev) if use_res else None
+    mask = torch.randn(B, H, W, Cout, generator=g).to(dev) if use_mask else None
+    base = torch.randn(B, H, W, Cout, generator=g).to(dev)
+    spec = ConvSpec.dense(*nchs)
+    wp = _packed_weight(w.contiguous(), spec, None)
+    y = base.clone()
+    shift = 1 if (use_res and B > 1) else 0
+    conv_raw([_src(t, 0, c, 0, None, 0, B) for t, c in zip(xs, nchs)], wp, spec.kpad * coutpad(Cout), b, Cout if bias else 0,
+             y.data_ptr(), H * W * Cout, Cout, B, H, W, Cout, 1, relu=relu,
+             residual=_src(res, 0, Cout, shift, B, 0, B) if use_res else None, bpg=B // G, accumulate=acc,
+             mask=_src(mask, 0, Cout, 0, None, 0, B) if use_mask else None)
+    xd = torch.cat(xs, -1).double().cpu()
+    wd = w.double().cpu()
+    ref = torch.stack([xd[i] @ wd[(i // (B // G))][:, :, 0].T for i in range(B)])
+    if bias: ref = ref + b.double().cpu()[torch.arange(B) // (B // G)][:, None, None, :]
+    if use_res: ref = ref + torch.roll(res.double().cpu(), -shift, 0)
+    if relu: ref = ref.clamp_min(0)
+    if use_mask: ref = torch.where(mask.double().cpu() > 0, ref, torch.zeros_like(ref))
+    if acc: ref = ref + base.double().cpu()
+    err = ((y.double().cpu() - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+    out.append((err, y.cpu().numpy().tobytes().hex()[:64], float(y.double().sum())))
+print(json.dumps(out))
+'''.replace("ROOT", repr(os.path.dirname(HERE)))
+    res = {}
+    for tag, env in (("conv1", {"BMC_CONV1_MIN_TILES": "0"}), ("old", {"BMC_NO_CONV1": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, SEED="5", **env))
+        assert r.returncode == 0, r.stderr[-3000:]
+        import json
+        res[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    for (e1, _, s1), (e0, _, s0) in zip(res["conv1"], res["old"]):
+        assert e1 < 3e-6 and e0 < 3e-6, (e1, e0)
+        assert abs(s1 - s0) <= 1e-3 * max(1.0, abs(s0))
