@@ -3,10 +3,10 @@
 // projections, softmax(att) . v with per-sample matrices, unclustering, and every 1x1 data gradient
 // (models/submodules.py:65-75 and their backward).  Same semantics as conv.hip's TAPS = 1 path (bmc_conv), different machine
 // mapping, the one chain.hip established for HBM-heavy K <= 256 contractions:
-//   * v_mfma_f32_16x16x4_f32; workgroup = 4 waves = 4 rows x 16 pixels, a wave = 16 pixels x ALL output channels of the
-//     channel tile (NT tiles of 16): 4 NT accumulator registers, 2-3 workgroups per CU;
-//   * both operand streams through swizzled, unpadded LDS rings filled by LDS-DMA (dma_ring.h): X chunks (64 px x 16 ch,
-//     from HBM) 6 chunks ahead, weight slices ([128][16], from L2) 3 steps ahead; waves 0-1 load X, waves 2-3 load W;
+//   * v_mfma_f32_16x16x4_f32; workgroup = 4 waves = 8 rows x 16 pixels, a wave = 2 rows x 16 pixels x ALL output channels
+//     of the channel tile (NT tiles of 16; a weight fragment feeds both rows): 8 NT accumulator registers, 2 workgroups per CU;
+//   * both operand streams through swizzled, unpadded LDS rings filled by LDS-DMA (dma_ring.h): X chunks (128 px x 16 ch,
+//     from HBM) 3 chunks ahead, weight slices ([128][16], from L2) 2 steps ahead; waves 0-1 load X, waves 2-3 load W;
 //     raw barriers, counted vmcnt -- the prefetch survives tile boundaries and epilogues;
 //   * epilogue = all loads, then all stores, 16 bytes per lane (lane = one pixel x 4 consecutive channels per tile).
 // conv.hip's 32x32x2 kernel keeps the small problems (few tiles: its 4-row / 64-channel tile shapes fill the chip better).
@@ -18,12 +18,12 @@
 namespace {
 
 constexpr int CK = BMC_CK;
-constexpr int TW = 16, TH = 4, NPX = TW * TH;
+constexpr int TW = 16, MP = 2, TH = 4 * MP, NPX = TW * TH;      // workgroup tile: 8 rows x 16 pixels, MP = 2 rows per wave
 
 template <int NT>
 __global__ __launch_bounds__(256, 2) void conv1_kernel(const ConvK a) {
     constexpr int BN = 16 * NT;                   // output channels per channel tile
-    constexpr int DX = 6, NXR = 8, DW = 3, NWR = 5;
+    constexpr int DX = 3, NXR = 5, DW = 2, NWR = 4;      // ring depths: 2 workgroups per CU must fit 160 KB of LDS
     constexpr int XSLOT = NPX * CK, WSLOT = BN * CK;
     constexpr int NDX = NPX / 32;                 // DMA instructions (16 rows = 1 KB) per X wave and chunk
     constexpr int NDW = (BN + 31) / 32;           // ... per W wave and slice
@@ -145,18 +145,25 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const ConvK a) {
 
     // ---- fragments
     const int qoff = (lg ^ swz(lp)) * 4;
-    const int arow = (16 * wave + lp) * CK + qoff;
+    const int arow = (16 * MP * wave + lp) * CK + qoff;        // + 16 m rows for the wave's m-th pixel row
     const int brow = lp * CK + qoff;
-    f32x4 afA, afB, bfA[NT], bfB[NT];
-    auto read_a = [&](const float* xb, f32x4& af) { af = *reinterpret_cast<const f32x4*>(xb + arow); };
+    f32x4 afA[MP], afB[MP], bfA[NT], bfB[NT];
+    auto read_a = [&](const float* xb, f32x4 (&af)[MP]) {
+#pragma unroll
+        for (int m = 0; m < MP; ++m) af[m] = *reinterpret_cast<const f32x4*>(xb + arow + 16 * m * CK);
+    };
     auto read_b = [&](const float* wb, f32x4 (&bf)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) bf[t] = *reinterpret_cast<const f32x4*>(wb + brow + 16 * t * CK);
     };
-    f32x4 acc[NT];
+    f32x4 acc[MP][NT];
     auto init_acc = [&]() {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(init_lds + 16 * t + 4 * lg);
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(init_lds + 16 * t + 4 * lg);
+#pragma unroll
+            for (int m = 0; m < MP; ++m) acc[m][t] = v;
+        }
     };
 
     int gs = 0;        // global step: X chunk gs sits in ring slot gs % NXR, weight slice gs in slot gs % NWR
@@ -169,80 +176,98 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const ConvK a) {
             if (wl_cnt - (gs + 1) >= DW) dma_wait<NDW * (DW - 1)>(); else dma_wait<0>();
         }
     };
-    auto step = [&](const f32x4& af, const f32x4 (&bf)[NT], f32x4& afn, f32x4 (&bfn)[NT]) {
+    auto step = [&](const f32x4 (&af)[MP], const f32x4 (&bf)[NT], f32x4 (&afn)[MP], f32x4 (&bfn)[NT]) {
         loader();
         ring_publish();                      // stage gs + 1 is in LDS for everybody
         if (gs + 1 < total_steps) {
             read_b(Wb + ((gs + 1) % NWR) * WSLOT, bfn);
             read_a(Xb + ((gs + 1) % NXR) * XSLOT, afn);
         }
+        // a weight fragment feeds the wave's MP pixel rows: MP independent chains per tile (dependent MFMAs >= 64 cycles apart)
 #pragma unroll
-        for (int t = 0; t < NT; t += 2)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t][j], af[j], acc[t], 0, 0, 0);
-                acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t + 1][j], af[j], acc[t + 1], 0, 0, 0);
-            }
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < MP; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t][j], af[m][j], acc[m][t], 0, 0, 0);
         ++gs;
     };
 
     // ---- epilogue: bias / residual / ReLU / mask / accumulate; ALL loads before ALL stores (vmcnt is in-order and counts
     //      stores: a load behind a store would wait for the store's round trip)
     auto epilogue = [&](const TileIt& it) {
-        const int y = it.ty * TH + wave, x = it.tx * TW + lp;
-        const bool pok = y < a.H && x < a.W;
-        const int pix = y * a.W + x;
         const int g = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
         const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
         float* const outb = a.out + (long long)it.b * a.out_batch_stride;
         const float* const resb = a.residual.ptr ? src_batch_ptr(a.residual, it.b) : nullptr;
         const float* const maskb = a.mask.ptr ? src_batch_ptr(a.mask, it.b) : nullptr;
         const int co0 = it.nt * BN + 4 * lg;
-        bool ok[NT];
+        const int x = it.tx * TW + lp;
+        bool ok[MP][NT];
+        int pix[MP];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) ok[t] = pok && co0 + 16 * t < a.Cout;
-        auto fetch = [&](const float* base, long long off, f32x4 (&d)[NT], float fill) {
+        for (int m = 0; m < MP; ++m) {
+            const int y = it.ty * TH + MP * wave + m;
+            pix[m] = y * a.W + x;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                d[t] = f32x4{fill, fill, fill, fill};
-                if (ok[t]) d[t] = *reinterpret_cast<const f32x4*>(base + off + co0 + 16 * t);
-            }
+            for (int t = 0; t < NT; ++t) ok[m][t] = y < a.H && x < a.W && co0 + 16 * t < a.Cout;
+        }
+        auto fetch = [&](const float* base, int stride, f32x4 (&d)[MP][NT], float fill) {
+#pragma unroll
+            for (int m = 0; m < MP; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    d[m][t] = f32x4{fill, fill, fill, fill};
+                    if (ok[m][t]) d[m][t] = *reinterpret_cast<const f32x4*>(base + (long long)pix[m] * stride + co0 + 16 * t);
+                }
         };
         if (biasg && !bias_pre) {
-            f32x4 d[NT];
-            fetch(biasg, 0, d, 0.f);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] += d[t];
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 d = co0 + 16 * t < a.Cout ? *reinterpret_cast<const f32x4*>(biasg + co0 + 16 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < MP; ++m) acc[m][t] += d;
+            }
         }
         if (resb) {
-            f32x4 d[NT];
-            fetch(resb, (long long)pix * a.residual.pix_stride, d, 0.f);
+            f32x4 d[MP][NT];
+            fetch(resb, a.residual.pix_stride, d, 0.f);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] += d[t];
+            for (int m = 0; m < MP; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] += d[m][t];
         }
         if (a.relu) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int m = 0; m < MP; ++m)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[t][k] = fmaxf(acc[t][k], 0.f);
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[m][t][k] = fmaxf(acc[m][t][k], 0.f);
         }
         if (maskb) {
-            f32x4 d[NT];
-            fetch(maskb, (long long)pix * a.mask.pix_stride, d, 1.f);
+            f32x4 d[MP][NT];
+            fetch(maskb, a.mask.pix_stride, d, 1.f);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int m = 0; m < MP; ++m)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[t][k] = d[t][k] > 0.f ? acc[t][k] : 0.f;
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[m][t][k] = d[m][t][k] > 0.f ? acc[m][t][k] : 0.f;
         }
         if (a.accumulate) {
-            f32x4 d[NT];
-            fetch(outb, (long long)pix * a.out_pix_stride, d, 0.f);
+            f32x4 d[MP][NT];
+            fetch(outb, a.out_pix_stride, d, 0.f);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] += d[t];
+            for (int m = 0; m < MP; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] += d[m][t];
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (ok[t]) *reinterpret_cast<f32x4*>(outb + (long long)pix * a.out_pix_stride + co0 + 16 * t) = acc[t];
+        for (int m = 0; m < MP; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (ok[m][t]) *reinterpret_cast<f32x4*>(outb + (long long)pix[m] * a.out_pix_stride + co0 + 16 * t) = acc[m][t];
         init_acc();
     };
 
