@@ -16,6 +16,14 @@ __device__ __forceinline__ void dma16(const void* gbase, unsigned voff, unsigned
     const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(la) : "memory");
 }
+// The same with a full per-lane 64-bit source address (boundary tiles: lanes outside the image point at a zero buffer).
+// Every LDS-DMA of these kernels goes through one of the two asm forms, so that every write of m0 is in hand-written
+// asm: mixing them with __builtin_amdgcn_global_load_lds (whose m0 setup the compiler may hoist, believing an asm
+// statement leaves m0 alone -- it cannot be declared as a clobber) would be a latent mis-addressing hazard.
+__device__ __forceinline__ void dma16v(const void* vaddr, unsigned lds_addr) {
+    const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(la) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void dma_wait() {   // all but the newest N vector-memory operations of this wave are done
     static_assert(N >= 0 && N < 64, "vmcnt range");

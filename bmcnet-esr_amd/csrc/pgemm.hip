@@ -9,6 +9,7 @@
 // go to slabs and are summed by a second kernel in a fixed order (deterministic, no float atomics).
 #include "bmc_common.h"
 #include "pgemm_k.h"
+#include "dma_ring.h"
 
 namespace {
 
@@ -130,9 +131,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
             }
             const float* src = a.zeros;
             if (ok && m0 + c4 < a.M) src = ab + pix * a.a.pix_stride + m0 + c4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + buf * BUF + (i * 512 + wave * 64) * 4),
-                                             16, 0, 0);
+            dma16v(src, (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + buf * BUF + (i * 512 + wave * 64) * 4));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {            // X tile: [108 halo px][64 ch] (+ padding lanes) or [64 px][128 ch]
@@ -157,9 +156,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
                     if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; }
                 src = src_batch_ptr(S, b) + pix * S.pix_stride + ch;
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + (2 + buf) * BUF + (i * 512 + wave * 64) * 4),
-                                             16, 0, 0);
+            dma16v(src, (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + (2 + buf) * BUF + (i * 512 + wave * 64) * 4));
         }
     };
 
