@@ -10,9 +10,11 @@ Collect on the GPU box (separate --pmc passes, the program directly after `--`, 
             python3 bench.py --steps 1 --warmup 1 --math $m --no-cpu-baseline --no-bf16x6
       done
     done
-    python tools/pmc_summary.py gpurun_out r02
+    python tools/pmc_summary.py gpurun_out r02        # -> gpurun_out/r02_pmc_summary.json, then copied to profiles/
 
-Per kernel: launches, mean duration, in-kernel clock (GRBM_GUI_ACTIVE / 8 XCDs / duration), MFMA-busy fraction
+Per kernel: launches, mean duration, clock during the profiled dispatch (GRBM_GUI_ACTIVE / 8 XCDs / duration; reads high on
+dispatches shorter than ~0.3 ms and, profiled kernels being serialised, is NOT the clock the chip holds in the un-profiled
+step -- that one comes from in-kernel s_memtime stamps), MFMA-busy fraction
 (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 4 SIMDs * CUs)), HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE
 (KiB counters; FETCH_SIZE reports half of a wide coalesced read stream on gfx950) and the derived GB/s."""
 import json
@@ -45,7 +47,7 @@ def short(name):
     return sym.replace(" ", "")
 
 
-def main(root, tag):
+def main(root, tag, steps=3):      # bench.py --steps 1 --warmup 1 runs 3 steps: warm-up, timed, instrumented (roofline block)
     out = {"_comment": __doc__.split("\n\n")[0] + " Counters: rocprofv3 --pmc, one pass per counter group; "
            "FETCH_SIZE doubled (gfx950), KiB -> bytes; clock = GRBM_GUI_ACTIVE / 8 / duration."}
     for mode in ("fp32", "bf16x6"):
@@ -72,7 +74,7 @@ def main(root, tag):
             w = {k: a[0] / a[1] for k, a in m["_w"].items() if a[1]}
             if "avg_us" not in w or m["launches"] < 2:
                 continue
-            e = {"launches_per_step": m["launches"], "avg_launch_us": round(w["avg_us"], 2)}
+            e = {"launches_per_step": round(m["launches"] / steps, 1), "avg_launch_us": round(w["avg_us"], 2)}
             if "GRBM_GUI_ACTIVE" in w:
                 cyc = w["GRBM_GUI_ACTIVE"] / 8.0
                 e["in_kernel_clock_GHz"] = round(cyc / w["avg_us"] / 1e3, 3)
@@ -92,10 +94,10 @@ def main(root, tag):
                 e["hbm_GBps"] = round((rd + wr) / w["avg_us"] / 1e3, 1)
             res[kern] = e
         out[mode] = dict(sorted(res.items(), key=lambda kv: -kv[1]["launches_per_step"] * kv[1]["avg_launch_us"]))
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "%s_pmc_summary.json" % tag)
+    path = os.path.join(root, "%s_pmc_summary.json" % tag)      # on the GPU box only gpurun_out/ travels back: copy to profiles/
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path, {m: len(out.get(m, {})) for m in ("fp32", "bf16x6")})
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r02")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r02", int(sys.argv[3]) if len(sys.argv) > 3 else 3)
