@@ -689,3 +689,25 @@ print(json.dumps(out))
     for (e1, _, s1), (e0, _, s0) in zip(res["conv1"], res["old"]):
         assert e1 < 3e-6 and e0 < 3e-6, (e1, e0)
         assert abs(s1 - s0) <= 1e-3 * max(1.0, abs(s0))
+
+
+# ------------------------------------------------------------------ streaming inference: HIP-graph replay per window
+def test_streaming_inference_graph_replay_matches_eager():
+    """infer.StreamingSR(graph=True): from the third window on a window is one HIP-graph replay with the input and the
+    recurrent state in static buffers -- same predictions as the eager loop, bit for bit, over 7 windows."""
+    dev = _gpu()
+    from infer import StreamingSR
+    from models.BMCNet import BMCNet
+    torch.manual_seed(4)
+    scale, n_c, n_b, B, H, W = 4, 32, 2, 1, 45, 80
+    m = BMCNet(scale, n_c, n_b).to(dev)
+    scaled_init(m, 2.0)
+    g = torch.Generator().manual_seed(6)
+    frames = torch.poisson(torch.full((B, 8, 2, H, W), 0.284), generator=g).to(dev)
+    eager, graph = StreamingSR(m, n_c, scale), StreamingSR(m, n_c, scale, graph=True)
+    for i in range(7):
+        x = frames[:, i:i + 2].transpose(1, 2)
+        pe = eager.step(x).clone()
+        pg = graph.step(x).clone()
+        assert torch.equal(pe, pg), i
+    assert graph._graph is not None
