@@ -28,8 +28,12 @@ FUSE_CHAIN = os.environ.get("BMC_FUSE_CHAIN", "1") != "0"
 _CHAIN_CACHE = {}
 
 
+# bf16x6 is an fp32-equivalent mode: the (native fp32) fused chain is a valid member of it
+CHAIN_IN_BF16X6 = os.environ.get("BMC_CHAIN_BF16X6", "1") != "0"
+
+
 def chain_supported(Cn):
-    return FUSE_CHAIN and ops.MATH == 0 and Cn in (32, 64, 128)
+    return FUSE_CHAIN and (ops.MATH == 0 or (ops.MATH == 3 and CHAIN_IN_BF16X6)) and Cn in (32, 64, 128)
 
 
 def _chain_streams(wf, wc, Cn):

@@ -8,6 +8,17 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// 16 bytes from GLOBAL memory.  A pointer that reached the kernel through LDS or a select (descriptor tables, "this pixel
+// or the zero constant") is a generic pointer to the compiler, and a load through it is a flat_load: that counts on vmcnt
+// AND lgkmcnt and may return out of order, so every wait for one is vmcnt(0) + lgkmcnt(0) -- a prefetch ring of depth one.
+// The address-space cast makes it a global_load, whose waits count.
+__device__ __forceinline__ f32x4 ldg16(const void* p) {
+    return *(const __attribute__((address_space(1))) f32x4*)(unsigned long long)p;
+}
+__device__ __forceinline__ void stg16(void* p, f32x4 v) {
+    *(__attribute__((address_space(1))) f32x4*)(unsigned long long)p = v;
+}
+
 void bmc_set_error(const char* fmt, ...);
 
 #define BMC_CHECK_ARG(cond, ...)          \

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainK a) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const f32x4 gq = *reinterpret_cast<const f32x4*>(img + 2 * C + 16 * t + 4 * lg);
-                    const f32x4 yq = *reinterpret_cast<const f32x4*>(pok ? yh + 16 * t : g_zero4c);
+                    const f32x4 yq = ldg16(pok ? yh + 16 * t : g_zero4c);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float g = Ra[t][k] * gq[k];
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainK a) {
                 const float m1 = wsum(s1) * (1.f / C), m2 = wsum(s2) * (1.f / C);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const f32x4 yq = *reinterpret_cast<const f32x4*>(pok ? yh + 16 * t : g_zero4c);
+                    const f32x4 yq = ldg16(pok ? yh + 16 * t : g_zero4c);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) Ra[t][k] = rstd * (Ra[t][k] - yq[k] * m2 - m1);
                 }
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainK a) {
             if (a.res.ptr && pok) {
                 const float* rp = src_batch_ptr(a.res, ep_it.b) + (long long)pix * a.res.pix_stride + 4 * lg;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) Rt[t] = *reinterpret_cast<const f32x4*>(rp + 16 * t);
+                for (int t = 0; t < NT; ++t) Rt[t] = ldg16(rp + 16 * t);
             }
             reg_steps(Rz, Rt, more_units);
             store_tile(Rt, a.out2 + (long long)ep_it.b * img_elems * C);

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
         for (int n = 0; n < NXLD; ++n) {
             const float* src = xok[n] ? base + (long long)xpix[n] * spix : g_zero4;
             if (BMC_DIAG_MODE & (2 | 16)) src = g_zero4;
-            xr[slot][n] = *reinterpret_cast<const f32x4*>(src);
+            xr[slot][n] = ldg16(src);
         }
         c_in += CK;
         if (++xl_chunk == a.nchunks) {
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
             // no branch around the load (a divergent branch makes the compiler serialise the loads with vmcnt(0)):
             // lanes past the slice re-read its last piece and never store it
             const int ec = (n + 1) * 256 <= BN * 4 ? e : (e < BN * 4 ? e : BN * 4 - 1);
-            wr[n] = *reinterpret_cast<const f32x4*>(p + ec * 4);
+            wr[n] = ldg16(p + ec * 4);
         }
         if (++wl_step == nsteps) {
             wl_tile += t_stride;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
                         d[rq] = f32x4{fill, fill, fill, fill};
-                        if (ok[rq]) d[rq] = *reinterpret_cast<const f32x4*>(base + off + co0 + 32 * u + 8 * rq);
+                        if (ok[rq]) d[rq] = ldg16(base + off + co0 + 32 * u + 8 * rq);
                     }
                 };
                 if (biasg && !bias_pre) {     // (otherwise the accumulators started from the bias)

@@ -32,7 +32,8 @@ extern "C" int bmc_cstamp_read(unsigned long long* host, int n) {
 #define ST(v)
 #endif
 #ifndef BMC_BF_ABL
-#define BMC_BF_ABL 0   // ablation bits for experiment builds (tools/): 1 no epilogue stores, 4 no MFMAs, 8 no weight loads, 16 no activation loads
+#define BMC_BF_ABL 0   // ablation bits for experiment builds (tools/): 1 no epilogue stores, 4 no MFMAs, 8 no weight loads, 16 no activation loads (reads a zero constant: the
+                       // chip then clocks ~1.3x higher on the all-zero MFMA operands -- not a latency measurement), 32 no halo split + store
 #endif
 
 namespace {
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
                 // (s_nop: a VALU-written SGPR -- the readfirstlane above -- needs 5 wait states before a VMEM instruction may
                 //  use it as its scalar base, and the hazard recognizer does not look inside inline asm)
                 if constexpr (ASMX) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(xr[slot][n]) : "v"(xoffb[n]), "s"(sb) : "memory");
-                else xr[slot][n] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sb) + xoffb[n]);
+                else xr[slot][n] = ldg16(reinterpret_cast<const char*>(sb) + xoffb[n]);
             }
         } else {
             const float* base = sbase + c_in + q * 4;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
                 const float* src = xok[n] ? base + (long long)xpix[n] * spix : g_zero4;
                 if (BMC_BF_ABL & 16) src = g_zero4;
                 if constexpr (ASMX) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[slot][n]) : "v"(src) : "memory");
-                else xr[slot][n] = *reinterpret_cast<const f32x4*>(src);
+                else xr[slot][n] = ldg16(src);
             }
         }
         c_in += CK;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
         for (int n = 0; n < NXLD; ++n) asm volatile("" : "+v"(xr[slot][n]));
     };
     auto store_x_item = [&](int slot, int buf, int n) {
+        if (BMC_BF_ABL & 32) return;
         const int e = xt + 128 * n, hp = e >> 2;
         if ((n + 1) * 128 <= NHALO * 4 || hp < NHALO) {
             u32x2 pl[NP];
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
         }
     };
     auto mma = [&](int pw, int px) {
+        if (BMC_BF_ABL & 4) return;
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(256, (BN == 128 && (TH == 8 || NP == 3)) ? 2 : 3) v
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
                         d[rq] = f32x4{fill, fill, fill, fill};
-                        if (ok[rq]) d[rq] = *reinterpret_cast<const f32x4*>(base + off + co0 + 32 * u + 8 * rq);
+                        if (ok[rq]) d[rq] = ldg16(base + off + co0 + 32 * u + 8 * rq);
                     }
                 };
                 if (biasg && !bias_pre) {     // (otherwise the accumulators started from the bias)

@@ -124,9 +124,9 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
             const char* const xbt = uniform_ptr(src_batch_ptr(xs, b) +
                                                 (TAPS == 9 ? (long long)(y0 - 1) * a.W + (x0 - 1) : (long long)p0) * xs.pix_stride);
 #pragma unroll
-            for (int i = 0; i < NAL; ++i) ar[slot][i] = *reinterpret_cast<const f32x4*>(abt + fa_off[i]);
+            for (int i = 0; i < NAL; ++i) ar[slot][i] = ldg16(abt + fa_off[i]);
 #pragma unroll
-            for (int i = 0; i < NXL; ++i) xr[slot][i] = *reinterpret_cast<const f32x4*>(xbt + fx_off[i]);
+            for (int i = 0; i < NXL; ++i) xr[slot][i] = ldg16(xbt + fx_off[i]);
             return;
         }
 #pragma unroll
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
             }
             ok = ok && m0 + c4 < a.M;
             const float* src = ok ? ab + pix * a.a.pix_stride + m0 + c4 : a.zeros;
-            ar[slot][i] = *reinterpret_cast<const f32x4*>(src);
+            ar[slot][i] = ldg16(src);
         }
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
             for (int si = 1; si < BMC_MAX_SRC; ++si)
                 if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; }
             const float* src = ok ? src_batch_ptr(S, b) + pix * S.pix_stride + ch : a.zeros;
-            xr[slot][i] = *reinterpret_cast<const f32x4*>(src);
+            xr[slot][i] = ldg16(src);
         }
     };
     // bias gradient = column sums of A: a thread always holds the same 4 channels ((tid & 31) * 4), so it adds up its
