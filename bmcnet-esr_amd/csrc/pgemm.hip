@@ -30,7 +30,14 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
     constexpr int XSH = TAPS == 9 ? 4 : 5;                              // log2(float4 per X row)
     constexpr int BUF = 2048 * 4;                                       // floats per LDS buffer (2048 float4)
     __shared__ __attribute__((aligned(16))) float lds[4 * BUF];         // A[2], X[2]  (128 KB)
+    // the source table, read with a per-lane index by the boundary-tile path: from LDS (indexing the by-value kernel
+    // argument made the compiler keep a copy of it in scratch memory)
+    __shared__ SrcDev tab[BMC_MAX_SRC];
     const int tid = threadIdx.x, lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < BMC_MAX_SRC; ++i)
+        if (tid == i) tab[i] = a.src[i];
+    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int mw = wave & 3, nw = wave >> 2;
@@ -57,11 +64,11 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
     // the tile's first (halo) pixel, pixel coordinates inside the tile -- and interior tiles whose channels all exist in
     // ONE source are filled with "uniform base (SGPR pair) + per-lane 32-bit offset" DMA: no VALU per piece.
     // the source that holds this workgroup's block of columns [n0, n0 + XCH) -- if one source holds all of it
-    SrcDev xs = a.src[0];
-    int xch0 = n0;
+    int xsi = 0, xch0 = n0;
 #pragma unroll
     for (int si = 1; si < BMC_MAX_SRC; ++si)
-        if (xch0 >= xs.nch && si < a.nsrc) { xch0 -= xs.nch; xs = a.src[si]; }
+        if (xsi == si - 1 && xch0 >= tab[si - 1].nch && si < a.nsrc) { xch0 -= tab[si - 1].nch; xsi = si; }
+    const SrcDev xs = tab[xsi];
     const bool x_one_src = xch0 + XCH <= xs.nch;
     int a_off[4], x_off[4], a_yx[4], x_yx[4];
 #pragma unroll
@@ -150,10 +157,11 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
             int ch = n0 + c4;
             const float* src = a.zeros;
             if (ok && ch < a.N) {
-                SrcDev S = a.src[0];
+                int s_i = 0;
 #pragma unroll
                 for (int si = 1; si < BMC_MAX_SRC; ++si)
-                    if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; }
+                    if (s_i == si - 1 && ch >= tab[si - 1].nch && si < a.nsrc) { ch -= tab[si - 1].nch; s_i = si; }
+                const SrcDev S = tab[s_i];
                 src = src_batch_ptr(S, b) + pix * S.pix_stride + ch;
             }
             dma16v(src, (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + (2 + buf) * BUF + (i * 512 + wave * 64) * 4));

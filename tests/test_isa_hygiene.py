@@ -1,0 +1,112 @@
+"""Properties of the compiled gfx950 code that the kernels' performance design relies on, checked on the device
+assembly (hipcc cross-compiles here without a GPU; nothing is executed):
+
+* no flat_load / flat_store in the MFMA kernels: a flat access counts on vmcnt AND lgkmcnt and may complete out of order,
+  so every wait for one is vmcnt(0) + lgkmcnt(0) -- it silently turns a prefetch ring into depth one (bmc_common.h: ldg16);
+* no scratch memory (spills, or a by-value kernel argument indexed per lane) beyond the one known 8-byte SGPR spill;
+* m0 is touched only inside the hand-written LDS-DMA asm (dma_ring.h, pgemm.hip, conv_bf.hip write it without being able
+  to declare the clobber: VERDICT r1 item 12) -- if a compiler upgrade starts using m0 itself, this fails loudly;
+* register budgets: the occupancy each __launch_bounds__ was written for is what the compiler delivered.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "bmcnet-esr_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+FILES = ["conv", "conv_bf", "pgemm", "pgemm_bf", "chain", "conv1"]
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def _kernels(path):
+    """-> {mangled name: dict(vgprs, scratch, occupancy, flat, m0_outside_asm)}"""
+    out, cur, body, in_asm = {}, None, None, False
+    for ln in open(path):
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            cur = m.group(1)
+            body = out[cur] = {"flat": 0, "m0": 0}
+            in_asm = False
+            continue
+        if body is None:
+            continue
+        if "#ASMSTART" in ln:
+            in_asm = True
+        elif "#ASMEND" in ln:
+            in_asm = False
+        code = ln.split(";")[0]
+        if re.search(r"\bflat_(load|store|atomic)", code):
+            body["flat"] += 1
+        if not in_asm and re.search(r"\bm0\b", code):
+            body["m0"] += 1
+        m = re.match(r"^; (NumVgprs|ScratchSize|Occupancy): (\d+)", ln)
+        if m:
+            body[m.group(1)] = int(m.group(2))
+            if m.group(1) == "Occupancy":
+                body = None
+    return out
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    d = tmp_path_factory.mktemp("isa")
+    res = {}
+    procs = []
+    for f in FILES:
+        o = os.path.join(d, f + ".s")
+        procs.append((f, o, subprocess.Popen(
+            [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
+             "--cuda-device-only", "-o", o, os.path.join(CSRC, f + ".hip")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for f, o, p in procs:
+        log = p.communicate()[0].decode()
+        assert p.returncode == 0, log
+        res[f] = _kernels(o)
+    shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
+def _all(isa):
+    for f, ks in isa.items():
+        for name, k in ks.items():
+            if "NumVgprs" in k:
+                yield f, name, k
+
+
+def test_no_flat_memory_instructions(isa):
+    bad = [(f, n, k["flat"]) for f, n, k in _all(isa) if k["flat"]]
+    assert not bad, bad
+
+
+def test_no_scratch(isa):
+    allowed = {"conv_kernelILi9ELi128ELi8E": 8}     # two SGPRs parked in a VGPR lane: no memory traffic in the loop
+    bad = []
+    for f, n, k in _all(isa):
+        lim = max([v for key, v in allowed.items() if key in n] + [0])
+        if k["ScratchSize"] > lim:
+            bad.append((f, n, k["ScratchSize"]))
+    assert not bad, bad
+
+
+def test_m0_only_inside_handwritten_asm(isa):
+    bad = [(f, n, k["m0"]) for f, n, k in _all(isa) if k["m0"]]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("frag,min_occ", [
+    ("conv_kernelILi9ELi128ELi8E", 3),          # three workgroups (12 waves) per CU: <= 170 VGPRs
+    ("pgemm_dma_kernelILi9E", 2),               # 8-wave workgroup, 144 accumulators: <= 256 VGPRs
+    ("chain_kernelILi8ELb0E", 2), ("chain_kernelILi8ELb1E", 2),   # two workgroups per CU hide each other's LayerNorm phases
+    ("conv1_kernelILi8E", 2),
+    ("conv_bf_kernelILi9ELi128ELi8ELi3E", 2), ("pgemm_bf9x3_kernel", 3),
+])
+def test_occupancy_budgets(isa, frag, min_occ):
+    hits = [(n, k) for _, n, k in _all(isa) if frag in n]
+    assert hits, frag
+    for n, k in hits:
+        assert k["Occupancy"] >= min_occ, (n, k)
+        assert k["ScratchSize"] <= 8, (n, k)
