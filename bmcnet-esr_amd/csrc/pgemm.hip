@@ -296,6 +296,84 @@ __global__ void reduce_weight_kernel(const float* slabs, int nsplit, int G, int 
     }
 }
 
+// The same reduction, 16 bytes per lane: a thread owns four consecutive columns n of one (group, tap, row) and sums
+// them over the splits in a fixed order (P = 1, 2, 4 or 8 threads share the splits when there are many; their partial
+// sums meet in LDS, again in a fixed order).  The 32-outputs-per-block kernel above spent its time waiting for two
+// dependent 4-byte loads per thread (27 us per launch at the C2 shapes, 715 launches per step); used when N % 4 == 0.
+__global__ void reduce_weight4_kernel(const float* slabs, int nsplit, int G, int taps, int M, int N, int Mpad, int Npad,
+                                      const int* kmap, int Cin, float* dw, int accumulate, const float* bias_slabs,
+                                      float* db, int wblocks, const GroupDst gd, int P) {
+    __shared__ f32x4 red4[256];
+    __shared__ float red[256];
+    if ((int)blockIdx.x >= wblocks) {    // trailing blocks: bias gradient (as in reduce_weight_kernel)
+        const long long total = (long long)G * M;
+        const long long idx = (long long)(blockIdx.x - wblocks) * 32 + (threadIdx.x & 31);
+        const int g = idx < total ? (int)(idx / M) : 0, m = idx < total ? (int)(idx % M) : 0;
+        const int part = threadIdx.x >> 5;
+        float s = 0.f;
+        if (idx < total)
+            for (int i = part; i < nsplit * 4; i += 8) s += bias_slabs[(((long long)(i >> 2) * G + g) * 4 + (i & 3)) * Mpad + m];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < 32 && idx < total) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 32 + threadIdx.x];
+            float* o = gd.n ? gd.db[g] + m : db + idx;
+            *o = accumulate ? *o + t : t;
+        }
+        return;
+    }
+    const int per = 256 / P, ol = threadIdx.x % per, part = threadIdx.x / per;
+    const int n4s = N / 4;
+    const long long total4 = (long long)G * taps * M * n4s;
+    const long long slab = (long long)G * taps * Mpad * Npad;
+    const long long nchunk = (total4 + per - 1) / per;
+    for (long long chunk = blockIdx.x; chunk < nchunk; chunk += wblocks) {
+        const long long idx = chunk * per + ol;
+        const bool live = idx < total4;
+        int n = 0, m = 0, tap = 0, g = 0;
+        if (live) {
+            n = (int)(idx % n4s) * 4;
+            long long r = idx / n4s;
+            m = r % M; r /= M;
+            tap = r % taps;
+            g = r / taps;
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            const float* p = slabs + (((long long)g * taps + tap) * Mpad + m) * Npad + n;
+            int i = part;
+            for (; i + 3 * P < nsplit; i += 4 * P) {     // four loads in flight, added in split order
+                const f32x4 v0 = ldg16(p + (long long)i * slab), v1 = ldg16(p + (long long)(i + P) * slab);
+                const f32x4 v2 = ldg16(p + (long long)(i + 2 * P) * slab), v3 = ldg16(p + (long long)(i + 3 * P) * slab);
+                acc += v0; acc += v1; acc += v2; acc += v3;
+            }
+            for (; i < nsplit; i += P) acc += ldg16(p + (long long)i * slab);
+        }
+        if (P > 1) {
+            red4[threadIdx.x] = acc;
+            __syncthreads();
+            if (part == 0) {
+                acc = red4[ol];
+                for (int k = 1; k < P; ++k) acc += red4[k * per + ol];
+            }
+            __syncthreads();
+        }
+        if (live && part == 0) {
+            float* const base = (gd.n ? gd.dw[g] : dw + (long long)g * M * Cin * taps) + (long long)m * Cin * taps + tap;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ci = kmap ? kmap[n + k] : n + k;
+                if (ci >= 0) {
+                    float* o = base + (long long)ci * taps;
+                    *o = accumulate ? *o + acc[k] : acc[k];
+                }
+            }
+        }
+    }
+}
+
 __global__ void reduce_plain_kernel(const float* slabs, int nsplit, int G, int M, int N, int Mpad, int Npad, float scale,
                                     float* out) {
     __shared__ float red[256];
@@ -376,6 +454,8 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
     return 0;
 }
 
+static int reduce_parts(int nsplit) { return nsplit <= 24 ? 1 : nsplit <= 48 ? 2 : nsplit <= 96 ? 4 : 8; }
+
 extern "C" int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, int taps, int M, int N, const int* kmap,
                                        int Cin, float* dw, int accumulate, const float* bias_slabs, float* db,
                                        bmc_stream_t stream) {
@@ -385,8 +465,16 @@ extern "C" int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, in
     const int wblocks = (int)((total + 31) / 32 > 8192 ? 8192 : (total + 31) / 32);
     const int bblocks = bias_slabs ? (int)(((long long)G * M + 31) / 32) : 0;
     GroupDst gd = {};
-    hipLaunchKernelGGL(reduce_weight_kernel, dim3(wblocks + bblocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, taps,
-                       M, N, bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, dw, accumulate, bias_slabs, db, wblocks, gd);
+    if (N % 4 == 0) {
+        const int P = reduce_parts(nsplit), per = 256 / P;
+        const long long nchunk = ((long long)G * taps * M * (N / 4) + per - 1) / per;
+        const int wb4 = (int)(nchunk > 8192 ? 8192 : nchunk);
+        hipLaunchKernelGGL(reduce_weight4_kernel, dim3(wb4 + bblocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, taps,
+                           M, N, bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, dw, accumulate, bias_slabs, db, wb4, gd, P);
+    } else
+        hipLaunchKernelGGL(reduce_weight_kernel, dim3(wblocks + bblocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G,
+                           taps, M, N, bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, dw, accumulate, bias_slabs, db,
+                           wblocks, gd);
     BMC_CHECK_LAUNCH("bmc_pgemm_reduce_weight");
     return 0;
 }
@@ -406,9 +494,17 @@ extern "C" int bmc_pgemm_reduce_weight_groups(const float* slabs, int nsplit, in
     const long long total = (long long)G * taps * M * N;
     const int wblocks = (int)((total + 31) / 32 > 8192 ? 8192 : (total + 31) / 32);
     const int bblocks = bias_slabs ? (int)(((long long)G * M + 31) / 32) : 0;
-    hipLaunchKernelGGL(reduce_weight_kernel, dim3(wblocks + bblocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, taps,
-                       M, N, bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, nullptr, accumulate, bias_slabs, nullptr,
-                       wblocks, gd);
+    if (N % 4 == 0) {
+        const int P = reduce_parts(nsplit), per = 256 / P;
+        const long long nchunk = ((long long)G * taps * M * (N / 4) + per - 1) / per;
+        const int wb4 = (int)(nchunk > 8192 ? 8192 : nchunk);
+        hipLaunchKernelGGL(reduce_weight4_kernel, dim3(wb4 + bblocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G, taps,
+                           M, N, bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, nullptr, accumulate, bias_slabs, nullptr,
+                           wb4, gd, P);
+    } else
+        hipLaunchKernelGGL(reduce_weight_kernel, dim3(wblocks + bblocks), dim3(256), 0, (hipStream_t)stream, slabs, nsplit, G,
+                           taps, M, N, bmc_round_up(M, 32), bmc_round_up(N, 32), kmap, Cin, nullptr, accumulate, bias_slabs,
+                           nullptr, wblocks, gd);
     BMC_CHECK_LAUNCH("bmc_pgemm_reduce_weight_groups");
     return 0;
 }
