@@ -341,6 +341,20 @@ __global__ void reduce_weight4_kernel(const float* slabs, int nsplit, int G, int
             g = r / taps;
         }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // destinations (and, when accumulating, their present values: loaded beside the slabs, not after them)
+        float* o[4] = {nullptr, nullptr, nullptr, nullptr};
+        float old[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live && part == 0) {
+            float* const base = (gd.n ? gd.dw[g] : dw + (long long)g * M * Cin * taps) + (long long)m * Cin * taps + tap;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ci = kmap ? kmap[n + k] : n + k;
+                if (ci >= 0) {
+                    o[k] = base + (long long)ci * taps;
+                    if (accumulate) old[k] = *o[k];
+                }
+            }
+        }
         if (live) {
             const float* p = slabs + (((long long)g * taps + tap) * Mpad + m) * Npad + n;
             int i = part;
@@ -360,17 +374,9 @@ __global__ void reduce_weight4_kernel(const float* slabs, int nsplit, int G, int
             }
             __syncthreads();
         }
-        if (live && part == 0) {
-            float* const base = (gd.n ? gd.dw[g] : dw + (long long)g * M * Cin * taps) + (long long)m * Cin * taps + tap;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ci = kmap ? kmap[n + k] : n + k;
-                if (ci >= 0) {
-                    float* o = base + (long long)ci * taps;
-                    *o = accumulate ? *o + acc[k] : acc[k];
-                }
-            }
-        }
+        for (int k = 0; k < 4; ++k)
+            if (o[k]) *o[k] = old[k] + acc[k];
     }
 }
 
@@ -454,7 +460,8 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
     return 0;
 }
 
-static int reduce_parts(int nsplit) { return nsplit <= 24 ? 1 : nsplit <= 48 ? 2 : nsplit <= 96 ? 4 : 8; }
+// threads sharing one output's splits: at most four loads per thread, all in flight at once (the kernel is latency-bound)
+static int reduce_parts(int nsplit) { return nsplit <= 4 ? 1 : nsplit <= 8 ? 2 : nsplit <= 16 ? 4 : 8; }
 
 extern "C" int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, int taps, int M, int N, const int* kmap,
                                        int Cin, float* dw, int accumulate, const float* bias_slabs, float* db,

@@ -358,7 +358,9 @@ __global__ __launch_bounds__(768, 1) void pgemm_bf9x3_kernel(const PgemmK a) {
                 if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; si_sel = si; }
             x_si[i2] = si_sel;
             x_yx[i2] = (hy << 16) | hx;
-            x_off[i2] = ((hy * a.W + hx) * S.pix_stride + ch) * 4;    // bytes from the halo's first pixel (y0-1, x0-1)
+            // bytes from the halo's first pixel (y0-1, x0-1); lanes of the last, partial item beyond the halo re-read that
+            // pixel (their data is never stored): one halo row further down can be past the end of the tensor
+            x_off[i2] = ((hp < NHALO ? hy * a.W + hx : 0) * S.pix_stride + ch) * 4;
             x_lds[i2] = NP * APL + hp * XST + c4 * 2;
         }
         // every channel of this workgroup's blocks exists and its 32 columns lie in the first source: no per-lane select
@@ -396,8 +398,7 @@ __global__ __launch_bounds__(768, 1) void pgemm_bf9x3_kernel(const PgemmK a) {
         // idiom: the compiler believes the register is written AT the asm; were it ever to copy the value elsewhere before
         // the wait (it does not: the `+v` pin after the wait keeps def and use in one register), the copy would be stale --
         // the parity tests would show garbage, not a small error.  The common case
-        // costs no VALU: uniform base (SGPR pair) + the item's 32-bit byte offset; lanes of the last, partial X item
-        // beyond the halo read a few in-image bytes that are never stored.  (s_nop 4: the scalar base may have been produced
+        // costs no VALU: uniform base (SGPR pair) + the item's 32-bit byte offset.  (s_nop 4: the scalar base may have been produced
         // by a VALU readfirstlane; 5 wait states are required before VMEM uses it and inline asm is opaque to the hazard pass.)
         auto load_item = [&](const TileP& t, int it) {
             if (it < NAL) {

@@ -711,3 +711,19 @@ def test_streaming_inference_graph_replay_matches_eager():
         pg = graph.step(x).clone()
         assert torch.equal(pe, pg), i
     assert graph._graph is not None
+
+
+# ------------------------------------------------------------------ no kernel reads past the end of an operand
+@pytest.mark.parametrize("math", ["fp32", "bf16x6", "bf16"])
+def test_no_reads_past_operand_end(math):
+    """The conv fuzz shapes (1-5 sources, 3..90 pixel sides, fwd + data + weight gradients) with every operand placed so
+    that it ENDS at the end of its own 2 MiB-multiple hipMalloc (caching allocator off, tools/fuzz_repro.py): an interior
+    tile's fast path that fetches one halo row too many -- harmless inside the caching allocator's big blocks, a page fault
+    when the tensor happens to close a mapping (found that way in pgemm_bf9x3_kernel) -- aborts the child process."""
+    _gpu()
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "fuzz_repro.py"), math],
+                       capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PYTORCH_NO_HIP_MEMORY_CACHING="1", PYTORCH_NO_CUDA_MEMORY_CACHING="1", FZ_END="1",
+                                FZ_SEEDS="2"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("done"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
