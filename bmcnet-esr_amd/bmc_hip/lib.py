@@ -44,7 +44,7 @@ class ConvArgs(C.Structure):
 class PgemmArgs(C.Structure):
     _fields_ = [("a", Src), ("nsrc", C.c_int), ("src", Src * MAX_SRC), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("taps", C.c_int), ("batch_per_group", C.c_int), ("slabs", C.c_void_p), ("nsplit", C.c_int),
-                ("zeros", C.c_void_p), ("bias_slabs", C.c_void_p), ("math", C.c_int)]
+                ("zeros", C.c_void_p), ("bias_slabs", C.c_void_p), ("math", C.c_int), ("tap_groups", C.c_int)]
 
 
 class ChainFwdArgs(C.Structure):

@@ -262,6 +262,9 @@ def _zeros(device):
     return z
 
 
+TAP_SPLIT_TILES = int(os.environ.get("BMC_TAP_SPLIT_TILES", 8))
+
+
 def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, device, flops=0.0, want_bias=False):
     """Returns (slabs, nsplit, G), or with want_bias (slabs, nsplit, G, bias_slabs): per-workgroup column sums of the
     A operand (bias-gradient partials) for bmc_pgemm_reduce_weight."""
@@ -279,6 +282,12 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
     other = G * ((mpad + 127) // 128) * n_nblk
     target = int(os.environ.get("BMC_PGEMM_TARGET", target))
     nsplit = max(1, min(bpg * tiles, target // max(other, 1)))
+    # small images: fewer than TAP_SPLIT_TILES pixel tiles per workgroup -> one tap row per workgroup, a third of the splits
+    # (every split writes a whole slab: at 31x56 the slab writes cost as much as the MFMAs; bmc_pgemm_args_t.tap_groups)
+    tap_groups = 1
+    if taps == 9 and MATH == 0 and bpg * tiles < TAP_SPLIT_TILES * nsplit and nsplit >= 3:
+        tap_groups = 3
+        nsplit = max(1, min(bpg * tiles, target // max(other * 3, 1)))
     slabs = torch.empty(nsplit * G * taps * mpad * npad, device=device, dtype=torch.float32)
     p = lib.PgemmArgs()
     p.a = a_src
@@ -291,6 +300,7 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
     p.nsplit = nsplit
     p.zeros = _zeros(device).data_ptr()
     p.math = MATH
+    p.tap_groups = tap_groups
     bslabs = None
     if want_bias:
         bslabs = torch.empty(nsplit * G * 4 * mpad, device=device, dtype=torch.float32)

@@ -15,6 +15,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 ldg16(const void* p) {
     return *(const __attribute__((address_space(1))) f32x4*)(unsigned long long)p;
 }
+__device__ __forceinline__ float ldg4(const void* p) { return *(const __attribute__((address_space(1))) float*)(unsigned long long)p; }
+__device__ __forceinline__ void stg4(void* p, float v) { *(__attribute__((address_space(1))) float*)(unsigned long long)p = v; }
 __device__ __forceinline__ void stg16(void* p, f32x4 v) {
     *(__attribute__((address_space(1))) f32x4*)(unsigned long long)p = v;
 }

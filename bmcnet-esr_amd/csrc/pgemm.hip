@@ -21,7 +21,11 @@ namespace {
 // ds_write): the fill of pixel tile t+1 is in flight under the MFMAs of tile t, one barrier per tile.  The LDS images
 // are lane-linear ([px][128] for A, [halo px][64] or [px][128] for X); pixels outside the image and channels beyond
 // M / N are sourced from a small zero buffer.
-template <int TAPS>
+// TG = taps per workgroup: 9, or 3 (one tap ROW per workgroup, a.tap_groups = 3): small problems, where 256 workgroups
+// are only reached by cutting the pixel axis into ~128 splits and every split writes a whole [taps][M][N] slab -- at
+// 31x56 the slab writes took as long as the MFMAs, and the reduction read 75 MB per weight gradient.  Three times the
+// workgroups per split = a third of the splits = a third of the slab bytes, for three times the (cheap) tile fills.
+template <int TAPS, int TG = TAPS>
 __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
     constexpr int HWD = PT_W + 2, HHT = PT_H + 2;
     constexpr int NHALO = TAPS == 9 ? HWD * HHT : PT;                   // 108 halo pixels or 64 pixels
@@ -44,6 +48,8 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
 
     int bid = blockIdx.x;
     const int split = bid % a.nsplit; bid /= a.nsplit;
+    const int tg = TG == TAPS ? 0 : bid % (TAPS / TG);      // tap row of this workgroup
+    if (TG != TAPS) bid /= TAPS / TG;
     const int nb = bid % a.n_nblk; bid /= a.n_nblk;
     const int mb = bid % a.n_mblk;
     const int g = bid / a.n_mblk;
@@ -51,9 +57,9 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
     const bool wave_active = m0 + 32 * mw < a.Mpad;
     const int HWp = a.H * a.W;
 
-    f32x16 acc[TAPS * NT];
+    f32x16 acc[TG * NT];
 #pragma unroll
-    for (int t = 0; t < TAPS * NT; ++t)
+    for (int t = 0; t < TG * NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
     __syncthreads();
     // bias gradient = column sums of A over pixels: the first n-block adds up its A tiles straight from LDS
     // (thread -> channel tid & 127, rows (tid >> 7) * 16 .. + 16); 4 partial rows per workgroup go to bias_slabs
-    const bool do_bias = a.bias_slabs != nullptr && nb == 0;
+    const bool do_bias = a.bias_slabs != nullptr && nb == 0 && tg == 0;
     float bsum = 0.f;
     int it = 0;
     for (int tile = split; tile < ntiles; tile += a.nsplit, ++it) {
@@ -187,12 +193,12 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
         }
         if (wave_active) {
             const float* const ap = lds + cur * BUF + lh * 128 + 32 * mw + li;
-            const float* const xp = lds + (2 + cur) * BUF + lh * XCH + 32 * NT * nw + li;
+            const float* const xp = lds + (2 + cur) * BUF + lh * XCH + 32 * NT * nw + li + (TG == TAPS ? 0 : tg * HWD * XCH);
 #pragma unroll
             for (int q = 0; q < PT / 2; ++q) {
                 const float av = ap[2 * q * 128];
 #pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap)
+                for (int tap = 0; tap < TG; ++tap)       // (TG = 3: tap row tg is folded into xp)
 #pragma unroll
                     for (int u = 0; u < NT; ++u) {
                         int off;
@@ -209,9 +215,9 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
     if (do_bias && m0 + (tid & 127) < a.Mpad)
         a.bias_slabs[(((long long)split * a.G + g) * 4 + (tid >> 7)) * a.Mpad + m0 + (tid & 127)] = bsum;
     if (wave_active) {
-        float* const sl = a.slabs + (((long long)split * a.G + g) * TAPS) * a.Mpad * a.Npad;
+        float* const sl = a.slabs + (((long long)split * a.G + g) * TAPS + (TG == TAPS ? 0 : tg * TG)) * a.Mpad * a.Npad;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap)
+        for (int tap = 0; tap < TG; ++tap)
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
                 const int n = n0 + 32 * NT * nw + 32 * u + li;
@@ -351,7 +357,7 @@ __global__ void reduce_weight4_kernel(const float* slabs, int nsplit, int G, int
                 const int ci = kmap ? kmap[n + k] : n + k;
                 if (ci >= 0) {
                     o[k] = base + (long long)ci * taps;
-                    if (accumulate) old[k] = *o[k];
+                    if (accumulate) old[k] = ldg4(o[k]);
                 }
             }
         }
@@ -376,7 +382,7 @@ __global__ void reduce_weight4_kernel(const float* slabs, int nsplit, int G, int
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (o[k]) *o[k] = old[k] + acc[k];
+            if (o[k]) stg4(o[k], old[k] + acc[k]);
     }
 }
 
@@ -407,6 +413,8 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
     BMC_CHECK_ARG(h != nullptr, "bmc_pgemm: null args");
     BMC_CHECK_ARG(h->nsrc >= 1 && h->nsrc <= BMC_MAX_SRC, "bmc_pgemm: nsrc=%d out of range", h->nsrc);
     BMC_CHECK_ARG(h->taps == 1 || h->taps == 9, "bmc_pgemm: taps must be 1 or 9");
+    BMC_CHECK_ARG(h->tap_groups == 0 || h->tap_groups == 1 || (h->tap_groups == 3 && h->taps == 9 && h->math == BMC_MATH_FP32),
+                  "bmc_pgemm: tap_groups must be 0, 1, or 3 (3: taps = 9 in fp32 only)");
     BMC_CHECK_ARG(h->batch_per_group >= 1 && h->B % h->batch_per_group == 0, "bmc_pgemm: B %% batch_per_group != 0");
     BMC_CHECK_ARG(h->nsplit >= 1 && h->slabs, "bmc_pgemm: nsplit/slabs");
     BMC_CHECK_ARG(h->zeros != nullptr, "bmc_pgemm: the zero buffer is required");
@@ -447,8 +455,13 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
         k.n_nblk = (k.Npad + 63) / 64;
         k.tiles_x = (h->W + PT_W - 1) / PT_W; k.tiles_y = (h->H + PT_H - 1) / PT_H;
         k.tiles_per_img = k.tiles_x * k.tiles_y;
-        dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * k.nsplit));
-        hipLaunchKernelGGL(pgemm_dma_kernel<9>, grid, dim3(512), 0, st, k);
+        if (h->tap_groups == 3) {
+            dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * 3 * k.nsplit));
+            hipLaunchKernelGGL((pgemm_dma_kernel<9, 3>), grid, dim3(512), 0, st, k);
+        } else {
+            dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * k.nsplit));
+            hipLaunchKernelGGL(pgemm_dma_kernel<9>, grid, dim3(512), 0, st, k);
+        }
     } else {
         k.n_nblk = (k.Npad + 127) / 128;
         k.tiles_x = k.tiles_y = 0;

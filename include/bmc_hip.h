@@ -174,6 +174,9 @@ typedef struct bmc_pgemm_args {
                                    taken from the A tiles the kernel stages anyway; summed by bmc_pgemm_reduce_weight */
     int math;                   /* BMC_MATH_* as for bmc_conv; bf16 modes: v_mfma_f32_32x32x16_bf16 on planes read
                                    with the transposing LDS load */
+    int tap_groups;             /* 0 / 1: a workgroup accumulates all taps; 3 (taps = 9, fp32 only): one tap row per
+                                   workgroup = three times the workgroups per pixel split, for small images (fewer,
+                                   smaller slab writes); same slab layout */
 } bmc_pgemm_args_t;
 int bmc_pgemm(const bmc_pgemm_args_t* host_args, bmc_stream_t s);
 /* slabs -> dW[Cout][Cin][taps] (nn.Conv2d layout) through kmap; beta 0/1 = overwrite/accumulate */
