@@ -422,6 +422,10 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
                     const float* const wb = Wb + (gs & 1) * WBUF;
                     read_frags(xb, wb, tap_off(tap), 1, af1, bf1);
                     if (has_next) store_w((gs + 1) & 1);
+                    // the slice after that: its loads go out as soon as the staging registers are free (a full step to land
+                    // from L2; issued after the barrier they had half a step, and the store above waited for them: 4 % of the
+                    // kernel by the no-weight-loads ablation)
+                    if (gs + 2 < total_steps) load_w();
                     if (last_tap && gc + 1 < total_chunks) store_x(0, (gc + 1) & 1);
                     mfma16(af0, bf0);
                     __syncthreads();
@@ -429,7 +433,6 @@ __global__ __launch_bounds__(256, (BN == 128 && TH == 8) ? 3 : 4) void conv_kern
                         const float* const xbn = last_tap ? Xb + ((gc + 1) & 1) * XBUF : xb;
                         read_frags(xbn, Wb + ((gs + 1) & 1) * WBUF, tap_off(last_tap ? 0 : tap + 1), 0, af0, bf0);
                     }
-                    if (gs + 2 < total_steps) load_w();
                     // the next chunk's halo tile is written to LDS at the top of this chunk's last tap: issue its
                     // global loads right at the chunk's first step (8 steps of MFMAs to land from HBM)
                     if (tap == 0 && gc + 1 < total_chunks) load_x(0);
