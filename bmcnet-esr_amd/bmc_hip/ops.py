@@ -285,7 +285,7 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
     # small images: fewer than TAP_SPLIT_TILES pixel tiles per workgroup -> one tap row per workgroup, a third of the splits
     # (every split writes a whole slab: at 31x56 the slab writes cost as much as the MFMAs; bmc_pgemm_args_t.tap_groups)
     tap_groups = 1
-    if taps == 9 and MATH == 0 and bpg * tiles < TAP_SPLIT_TILES * nsplit and nsplit >= 3:
+    if taps == 9 and MATH in (0, 1) and bpg * tiles < TAP_SPLIT_TILES * nsplit and nsplit >= 3:
         tap_groups = 3
         nsplit = max(1, min(bpg * tiles, target // max(other * 3, 1)))
     slabs = torch.empty(nsplit * G * taps * mpad * npad, device=device, dtype=torch.float32)

@@ -413,8 +413,8 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
     BMC_CHECK_ARG(h != nullptr, "bmc_pgemm: null args");
     BMC_CHECK_ARG(h->nsrc >= 1 && h->nsrc <= BMC_MAX_SRC, "bmc_pgemm: nsrc=%d out of range", h->nsrc);
     BMC_CHECK_ARG(h->taps == 1 || h->taps == 9, "bmc_pgemm: taps must be 1 or 9");
-    BMC_CHECK_ARG(h->tap_groups == 0 || h->tap_groups == 1 || (h->tap_groups == 3 && h->taps == 9 && h->math == BMC_MATH_FP32),
-                  "bmc_pgemm: tap_groups must be 0, 1, or 3 (3: taps = 9 in fp32 only)");
+    BMC_CHECK_ARG(h->tap_groups == 0 || h->tap_groups == 1 || (h->tap_groups == 3 && h->taps == 9 && h->math != BMC_MATH_BF16X6),
+                  "bmc_pgemm: tap_groups must be 0, 1, or 3 (3: taps = 9, fp32 or bf16 arithmetic)");
     BMC_CHECK_ARG(h->batch_per_group >= 1 && h->B % h->batch_per_group == 0, "bmc_pgemm: B %% batch_per_group != 0");
     BMC_CHECK_ARG(h->nsplit >= 1 && h->slabs, "bmc_pgemm: nsplit/slabs");
     BMC_CHECK_ARG(h->zeros != nullptr, "bmc_pgemm: the zero buffer is required");
@@ -435,6 +435,7 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
     k.slabs = h->slabs; k.nsplit = h->nsplit; k.zeros = h->zeros; k.bias_slabs = h->bias_slabs;
     k.M = h->a.nch; k.Mpad = bmc_round_up(k.M, 32); k.N = N; k.Npad = bmc_round_up(N, 32);
     k.G = h->B / h->batch_per_group;
+    k.tap_groups = h->tap_groups == 3 ? 3 : 1;
     k.n_mblk = (k.Mpad + 127) / 128;
     hipStream_t st = (hipStream_t)stream;
     BMC_CHECK_ARG(h->math == BMC_MATH_FP32 || h->math == BMC_MATH_BF16 || h->math == BMC_MATH_BF16X6,

@@ -61,6 +61,10 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
 
     int bid = blockIdx.x;
     const int split = bid % a.nsplit; bid /= a.nsplit;
+    // one tap ROW per workgroup (a.tap_groups = 3; 3x3, one plane): small images, a third of the pixel splits (pgemm.hip)
+    const bool wg_taps = TAPS == 9 && !TSPLIT && a.tap_groups == 3;
+    const int tgw = wg_taps ? bid % 3 : 0;
+    if (wg_taps) bid /= 3;
     const int nb = bid % a.n_nblk; bid /= a.n_nblk;
     const int mb = bid % a.n_mblk;
     const int g = bid / a.n_mblk;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
     };
     // bias gradient = column sums of A: a thread always holds the same 4 channels ((tid & 31) * 4), so it adds up its
     // own fp32 registers; 16 threads per channel quad are folded to 4 partial rows per workgroup at the end
-    const bool do_bias = a.bias_slabs != nullptr && nb == 0;
+    const bool do_bias = a.bias_slabs != nullptr && nb == 0 && tgw == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     auto store_tile = [&](int slot) {
         int vt = tid;
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
 
     // taps of this wave: tap_lo .. tap_lo + ntap - 1 (wave-uniform; one code path and ONE accumulator set for both tap
     // groups -- separate instantiations per group make the register allocator keep two accumulator sets)
-    const int tap_lo = TSPLIT ? 5 * tw : 0, ntap = TSPLIT ? (tw ? 4 : 5) : TAPS;
+    const int tap_lo = TSPLIT ? 5 * tw : 3 * tgw, ntap = TSPLIT ? (tw ? 4 : 5) : (wg_taps ? 3 : TAPS);
     auto compute = [&]() {
         int toff[NTAP];   // byte offset of the tap's first halo row
 #pragma unroll
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
             for (int p = 0; p < NP; ++p) af[p] = frag(a_lane + p * APL + kg * 16 * AST, AST);
 #pragma unroll
             for (int ti = 0; ti < NTAP; ++ti) {
-                if (TSPLIT && ti >= ntap) continue;
+                if ((TSPLIT || TAPS == 9) && ti >= ntap) continue;
 #pragma unroll
                 for (int u = 0; u < NT; ++u) {
                     const unsigned char* const xrow = x_lane + (TAPS == 9 ? kg * HWD * XST : kg * 16 * XST) + toff[ti] + 64 * u;
@@ -598,7 +602,8 @@ int bmc_pgemm_cols(int taps, int math) {   // columns of C per workgroup (the ho
 }
 
 int bmc_pgemm_bf_launch(const PgemmK& k, int taps, int planes, hipStream_t st) {
-    dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * k.nsplit)), block(512);
+    const int tgs = (taps == 9 && planes == 1 && k.tap_groups == 3) ? 3 : 1;
+    dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * tgs * k.nsplit)), block(512);
     if (taps == 9) {
         if (planes == 3) hipLaunchKernelGGL(pgemm_bf9x3_kernel, grid, dim3(768), 0, st, k);
         else hipLaunchKernelGGL((pgemm_bf_kernel<9, 1>), grid, block, 0, st, k);

@@ -17,6 +17,7 @@ struct PgemmK {
     int M, Mpad, N, Npad;
     int n_nblk, n_mblk, G;
     int tiles_x, tiles_y, tiles_per_img;
+    int tap_groups;      // 3: one tap row per workgroup (bmc_pgemm_args_t.tap_groups), else all taps
 };
 
 // pgemm_bf.hip: bf16-plane variant (planes = 1: bf16 operands; 3: exact 3-way split, six plane products).

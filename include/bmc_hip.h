@@ -174,7 +174,7 @@ typedef struct bmc_pgemm_args {
                                    taken from the A tiles the kernel stages anyway; summed by bmc_pgemm_reduce_weight */
     int math;                   /* BMC_MATH_* as for bmc_conv; bf16 modes: v_mfma_f32_32x32x16_bf16 on planes read
                                    with the transposing LDS load */
-    int tap_groups;             /* 0 / 1: a workgroup accumulates all taps; 3 (taps = 9, fp32 only): one tap row per
+    int tap_groups;             /* 0 / 1: a workgroup accumulates all taps; 3 (taps = 9, fp32 or bf16 arithmetic): one tap row per
                                    workgroup = three times the workgroups per pixel split, for small images (fewer,
                                    smaller slab writes); same slab layout */
 } bmc_pgemm_args_t;
