@@ -185,9 +185,9 @@ class BIETwinFn(torch.autograd.Function):
             _conv([X(y12)], d(wc).reshape(1, Cn, Cn, 1), s1, wc, d(bc), c12, B2)
         # values: v1 on the first half, v2 on the second (two weight groups)
         v12 = new(B2)
-        wv = torch.stack([d(wv1).reshape(Cn, Cn, 1), d(wv2).reshape(Cn, Cn, 1)])
-        bv = torch.stack([d(bv1), d(bv2)])
-        _conv([X(x12)], wv, s1, None, bv, v12, B2, bpg=n)
+        wv = ops.stacked((wv1, wv2), lambda: torch.stack([d(wv1).reshape(Cn, Cn, 1), d(wv2).reshape(Cn, Cn, 1)]))
+        bv = ops.stacked((bv1, bv2), lambda: torch.stack([d(bv1), d(bv2)]))
+        _conv([X(x12)], wv, s1, wv, bv, v12, B2, bpg=n)
         # channel attention per sample
         slabs, nsplit, G = pgemm_raw(X(c12), [X(v12)], B2, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * B2 * H * W * Cn * Cn)
         att = torch.empty((B2, Cn, Cn), device=dev, dtype=torch.float32)
@@ -222,7 +222,8 @@ class BIETwinFn(torch.autograd.Function):
         g_x = dxs_new.contiguous() if dxs_new is not None else torch.zeros_like(xs)
         w_r1, w_r2 = rw1.detach().reshape(1, Cn, Cn, 9), rw2.detach().reshape(1, Cn, Cn, 9)
         w_f, w_c, w_u = (rw.detach().reshape(1, Cn, k, 1) for rw, k in ((wf, 2 * Cn), (wc, Cn), (wu, 2 * Cn)))
-        w_v = torch.stack([wv1.detach().reshape(Cn, Cn, 1), wv2.detach().reshape(Cn, Cn, 1)])
+        # (keyed by the caller's parameter objects: the saved tensors are fresh aliases in every backward)
+        w_v = ops.stacked(ctx.vparams[:2], lambda: torch.stack([wv1.detach().reshape(Cn, Cn, 1), wv2.detach().reshape(Cn, Cn, 1)]))
 
         # ---- out = P v (+ rotated residual): dP, dv
         slabs, nsplit, G = pgemm_raw(X(g_o), [X(v12)], B2, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * B2 * H * W * Cn * Cn)
@@ -265,10 +266,10 @@ class BIETwinFn(torch.autograd.Function):
                      gamma.detach().data_ptr(), beta.detach().data_ptr(), Cn, o_w.data_ptr(),
                      o_b.data_ptr() if o_b is not None else None, o_g.data_ptr(), o_bt.data_ptr(), acc, _stream())
             dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf)
-            _dgrad(X(dv12), w_v, s1, 0, None, dx12, B2, bpg=n, accumulate=True)                          # dx12 += value convs
+            _dgrad(X(dv12), w_v, s1, 0, w_v, dx12, B2, bpg=n, accumulate=True)                          # dx12 += value convs
         else:
             dx12 = new(B2)
-            _dgrad(X(dv12), w_v, s1, 0, None, dx12, B2, bpg=n)                                           # dx12  =
+            _dgrad(X(dv12), w_v, s1, 0, w_v, dx12, B2, bpg=n)                                           # dx12  =
             # ---- clustering, LayerNorm, convf
             dwc, dbc = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev, p_wc, p_bc)
             dy12 = new(B2)

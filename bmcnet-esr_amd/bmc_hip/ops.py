@@ -184,6 +184,27 @@ def _cache_put(spec: ConvSpec, kind, owner, packed):
         spec._packs[(kind, id(owner))] = (weakref.ref(owner), owner._version, packed)
 
 
+_STACKS = {}
+
+
+def stacked(owners, build):
+    """A tensor derived from several parameters (the stacked per-group weights of a grouped launch), rebuilt only when
+    one of them changed: keyed by their ids, validated by weak references and version counters like the pack cache --
+    and, being one persistent object per parameter set, a valid pack-cache owner itself.  (Per step and BIE call this
+    saves two torch.stack launches, a pack and, in the bf16-plane modes, a plane split: ~600 tiny launches per step.)"""
+    key = tuple(id(o) for o in owners)
+    vers = tuple(o._version for o in owners)
+    hit = _STACKS.get(key)
+    if hit is not None and hit[1] == vers and all(r() is o for r, o in zip(hit[0], owners)):
+        return hit[2]
+    t = build()
+    if len(_STACKS) > 256:
+        for k in [k for k, v in _STACKS.items() if any(r() is None for r in v[0])]:
+            del _STACKS[k]
+    _STACKS[key] = (tuple(weakref.ref(o) for o in owners), vers, t)
+    return t
+
+
 def _packed_weight(w4: torch.Tensor, spec: ConvSpec, owner):
     """[G,Cout,Cin,taps] -> MFMA staging layout (bmc_pack_weight).  owner: the parameter tensor w4 was derived
     from (cache key), or None for no caching."""
