@@ -433,19 +433,21 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainK a) {
 //   dW_c[co][ci] = gamma[ci] G[co][ci] + dbc[co] beta[ci]        (y = yhat*gamma + beta)
 //   dgamma[ci]   = sum_co W_c[co][ci] G[co][ci]                    (= sum_px dy*yhat, dy = W_c^T dcentre)
 //   dbeta[ci]    = sum_co W_c[co][ci] dbc[co]                      (= sum_px dy)
-// Block = 32 columns ci x 8 row groups (co = part, part + 8, ...): partial column sums meet in LDS.  Results are written
+// Block = 32 columns ci x 32 row groups (co = part, part + 32, ...: four dependent global round trips per thread, the
+// kernel is pure latency): partial column sums meet in LDS.  Results are written
 // (accumulate = 0) or added (1) to dwc / dgamma / dbeta (dwc may be G itself); dbc_out, if given, receives dbc the same
 // way (the clustering bias gradient on its way to its accumulator).
-__global__ void affine_grads_kernel(const float* G, const float* __restrict__ dbc, const float* __restrict__ Wc,
+__global__ __launch_bounds__(1024) void affine_grads_kernel(const float* G, const float* __restrict__ dbc, const float* __restrict__ Wc,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, int C, float* dwc,
                                     float* __restrict__ dbc_out, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                     int accumulate) {
-    __shared__ float red[2][8][32];
+    constexpr int NPART = 32;
+    __shared__ float red[2][NPART][32];
     const int cl = threadIdx.x & 31, part = threadIdx.x >> 5, ci = blockIdx.x * 32 + cl;
     float dg = 0.f, db = 0.f;
     if (ci < C) {
         const float gm = gamma[ci], bt = beta[ci];
-        for (int co = part; co < C; co += 8) {
+        for (int co = part; co < C; co += NPART) {
             const float g = G[co * C + ci], w = Wc[co * C + ci], d = dbc[co];
             dg += w * g;
             db += w * d;
@@ -459,7 +461,7 @@ __global__ void affine_grads_kernel(const float* G, const float* __restrict__ db
     if (part == 0 && ci < C) {
         float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { a += red[0][k][cl]; b += red[1][k][cl]; }
+        for (int k = 0; k < NPART; ++k) { a += red[0][k][cl]; b += red[1][k][cl]; }
         dgamma[ci] = accumulate ? dgamma[ci] + a : a;
         dbeta[ci] = accumulate ? dbeta[ci] + b : b;
         if (dbc_out) dbc_out[ci] = accumulate ? dbc_out[ci] + dbc[ci] : dbc[ci];
@@ -540,7 +542,7 @@ extern "C" int bmc_chain_affine_grads(const float* G, const float* dbc, const fl
                                       int C, float* dwc, float* dbc_out, float* dgamma, float* dbeta, int accumulate,
                                       bmc_stream_t stream) {
     BMC_CHECK_ARG(G && dbc && Wc && gamma && beta && dwc && dgamma && dbeta && C > 0, "bmc_chain_affine_grads: bad arguments");
-    hipLaunchKernelGGL(affine_grads_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, G, dbc, Wc, gamma, beta, C, dwc, dbc_out,
+    hipLaunchKernelGGL(affine_grads_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, G, dbc, Wc, gamma, beta, C, dwc, dbc_out,
                        dgamma, dbeta, accumulate);
     BMC_CHECK_LAUNCH("bmc_chain_affine_grads");
     return 0;
