@@ -105,3 +105,25 @@ def test_unsupported_shapes_fail_loudly():
         BMCNet(3, 16, 1)       # odd scales: scale^2 is not a multiple of 4
     with pytest.raises(NotImplementedError):
         BMCNet(4, 8, 1)        # n_c = 8 is not a multiple of 16
+
+
+def test_stacked_weight_cache_follows_parameter_versions():
+    """ops.stacked: the stacked per-group weights (v1 / v2) are rebuilt exactly when one of the parameters changed (version
+    counter) or is another object (ids can be recycled: weak references), never otherwise."""
+    from bmc_hip import ops
+    a, b = torch.nn.Parameter(torch.randn(4, 4)), torch.nn.Parameter(torch.randn(4, 4))
+    calls = []
+
+    def build():
+        calls.append(1)
+        return torch.stack([a.detach(), b.detach()])
+    s0 = ops.stacked((a, b), build)
+    assert ops.stacked((a, b), build) is s0 and len(calls) == 1
+    with torch.no_grad():
+        a.add_(1.0)                                  # what optimizer.step() does: same object, new version
+    s1 = ops.stacked((a, b), build)
+    assert s1 is not s0 and len(calls) == 2 and torch.equal(s1[0], a.detach())
+    c = torch.nn.Parameter(torch.randn(4, 4))
+    s2 = ops.stacked((c, b), lambda: torch.stack([c.detach(), b.detach()]))
+    assert s2 is not s1 and torch.equal(s2[0], c.detach())
+    assert ops.stacked((a, b), build) is s1 and len(calls) == 2
