@@ -32,6 +32,9 @@ _CHAIN_CACHE = {}
 CHAIN_IN_BF16X6 = os.environ.get("BMC_CHAIN_BF16X6", "1") != "0"
 
 
+FUSE_FIRST = os.environ.get("BMC_FUSE_FIRST", "1") != "0"      # BIEFirstFn for the last block's local BIE
+
+
 def chain_supported(Cn):
     return FUSE_CHAIN and (ops.MATH == 0 or (ops.MATH == 3 and CHAIN_IN_BF16X6)) and Cn in (32, 64, 128)
 
@@ -301,6 +304,113 @@ class BIETwinFn(torch.autograd.Function):
         v = lambda t, ref: None if t is None else t.view(ref.shape)
         gv = (None,) * 4 if dwv is None else (dwv[0].reshape(wv1.shape), dbv[0], dwv[1].reshape(wv2.shape), dbv[1])
         return (dx12, dxs, dw1, db1, dw2, db2, dwf, dbf, dgamma, dbeta, v(dwc, wc), dbc, dwu, dbu, *gv, None, None)
+
+
+class BIEFirstFn(torch.autograd.Function):
+    """BIETwinFn without everything that only feeds its SECOND output (the last ParallelBlk of the backbone never reads it,
+    models/BMCNet.py:75-82): x12 [2n,H,W,C] = [first; second], xs [n,H,W,C] ->
+        o1 = softmax(att1) v1(first) + Res(second)   [n],   xs_new = unclustering(cat[c1, c2]) + xs   [n].
+    The residual block runs on the second half only, values / Gram / softmax / attention on the first half only; both
+    centres are still needed (unclustering) and come from the one fused chain launch.  Needs the fused chain."""
+
+    @staticmethod
+    def forward(ctx, x12, xs, rw1, rb1, rw2, rb2, wf, bf, gamma, beta, wc, bc, wu, bu, wv1, bv1, scale, eps):
+        _need_gpu(x12)
+        x12, xs = x12.contiguous(), xs.contiguous()
+        B2, H, W, Cn = x12.shape
+        n = B2 // 2
+        dev = x12.device
+        s1, s2 = _dense_spec(Cn), _spec2(Cn)
+        new = lambda b: torch.empty((b, H, W, Cn), device=dev, dtype=torch.float32)
+        X = lambda t, **k: _src(t, 0, Cn, k.get("shift", 0), k.get("mod"), k.get("b0", 0), k.get("B", t.shape[0]))
+        d = lambda t: t.detach()
+        second = X(x12, b0=n, B=n)
+        t2, r2 = new(n), new(n)
+        _conv([second], d(rw1).reshape(1, Cn, Cn, 9), s1, rw1, d(rb1), t2, n, relu=True)
+        _conv([X(t2)], d(rw2).reshape(1, Cn, Cn, 9), s1, rw2, d(rb2), r2, n, residual=second)
+        yhat, rstd, c12 = chain_fwd(X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2), wf, d(bf), d(gamma), d(beta), wc, d(bc), eps,
+                                    B2, H, W, Cn, dev)
+        v1 = new(n)
+        _conv([X(x12, b0=0, B=n)], d(wv1).reshape(1, Cn, Cn, 1), s1, wv1, d(bv1), v1, n)
+        slabs, nsplit, G = pgemm_raw(X(c12, b0=0, B=n), [X(v1)], n, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * n * H * W * Cn * Cn)
+        att = torch.empty((n, Cn, Cn), device=dev, dtype=torch.float32)
+        lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, scale, att.data_ptr(), _stream())
+        p = torch.empty_like(att)
+        lib.call(lib._sm_fwd, "bmc_softmax_fwd", att.data_ptr(), n * Cn, Cn, p.data_ptr(), _stream())
+        o1 = new(n)
+        _conv([X(v1)], p.view(n, Cn, Cn, 1), s1, None, None, o1, n, residual=X(r2), bpg=1)
+        xs_new = new(n)
+        _conv([X(c12, b0=0, B=n), X(c12, b0=n, B=n)], d(wu).reshape(1, Cn, 2 * Cn, 1), s2, wu, d(bu), xs_new, n, residual=X(xs))
+        ctx.save_for_backward(x12, xs, t2, yhat, rstd, c12, v1, p, rw1, rw2, wf, gamma, wc, wu, wv1, beta)
+        ctx.owners = (rw1, rw2, wf, wc, wu, wv1)
+        ctx.params = (rw1, rb1, rw2, rb2, wf, bf, gamma, beta, wc, bc, wu, bu, wv1, bv1)     # the caller's objects (gradient sinks)
+        ctx.scale = scale
+        return o1, xs_new
+
+    @staticmethod
+    def backward(ctx, do1, dxs_new):
+        x12, xs, t2, yhat, rstd, c12, v1, p, rw1, rw2, wf, gamma, wc, wu, wv1, beta = ctx.saved_tensors
+        o_rw1, o_rw2, o_wf, o_wc, o_wu, o_wv1 = ctx.owners
+        p_rw1, p_rb1, p_rw2, p_rb2, p_wf, p_bf, p_gamma, p_beta, p_wc, p_bc, p_wu, p_bu, p_wv1, p_bv1 = ctx.params
+        B2, H, W, Cn = x12.shape
+        n = B2 // 2
+        dev = x12.device
+        s1, s2 = _dense_spec(Cn), _spec2(Cn)
+        new = lambda b: torch.empty((b, H, W, Cn), device=dev, dtype=torch.float32)
+        X = lambda t, **k: _src(t, 0, Cn, k.get("shift", 0), k.get("mod"), k.get("b0", 0), k.get("B", t.shape[0]))
+        g_o = do1.contiguous() if do1 is not None else torch.zeros_like(v1)
+        g_x = dxs_new.contiguous() if dxs_new is not None else torch.zeros_like(xs)
+        w_r1, w_r2 = rw1.detach().reshape(1, Cn, Cn, 9), rw2.detach().reshape(1, Cn, Cn, 9)
+        w_v1 = wv1.detach().reshape(1, Cn, Cn, 1)
+        # ---- o1 = P v1 + r2: dP, softmax, Gram
+        slabs, nsplit, G = pgemm_raw(X(g_o), [X(v1)], n, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * n * H * W * Cn * Cn)
+        dp = torch.empty_like(p)
+        lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, 1.0, dp.data_ptr(), _stream())
+        da = torch.empty_like(p)
+        lib.call(lib._sm_bwd, "bmc_softmax_bwd", p.data_ptr(), dp.data_ptr(), n * Cn, Cn, ctx.scale, da.data_ptr(), _stream())
+        #   dv1[b]     = P_b^T g_o[b] + da_b^T c1[b]
+        #   dcentre[b] = (b < n: da_b v1[b]) + W_u[:, half(b)]^T g_x[b mod n]     (the second half has no attention term: a zero matrix)
+        dv1, dc12 = new(n), new(B2)
+        w_dv = torch.cat([p.transpose(1, 2), da.transpose(1, 2)], 2).view(n, Cn, 2 * Cn, 1)
+        _conv([X(g_o), X(c12, b0=0, B=n)], w_dv, s2, None, None, dv1, n, bpg=1)
+        w_ut = wu.detach().view(Cn, 2, Cn).permute(1, 2, 0).repeat_interleave(n, 0)           # [B2, C (c_i), C (co)]
+        w_dc = torch.cat([torch.cat([da, torch.zeros_like(da)], 0), w_ut], 2).view(B2, Cn, 2 * Cn, 1)
+        _conv([X(v1, mod=n, B=B2), X(g_x, mod=n, B=B2)], w_dc, s2, None, None, dc12, B2, bpg=1)
+        dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu)
+        dwv1, dbv1 = _wgrad(X(dv1), [X(x12, b0=0, B=n)], s1, n, H, W, 1, Cn, dev, p_wv1, p_bv1)
+        # ---- clustering, LayerNorm, convf (csrc/chain.hip), as in BIETwinFn
+        dz12, dx12, dxs = chain_bwd(X(dc12), yhat, rstd, gamma.detach(), wf, wc, X(g_x), n, H, W, Cn, dev)
+        Gm, dbc_t = _wgrad(X(dc12), [X(yhat)], s1, B2, H, W, 1, Cn, dev, None, None, w_shape=(Cn, Cn))
+        sg = ops.sink_group([p_wc, p_bc, p_gamma, p_beta])
+        if sg is not None:
+            (o_w, o_b, o_g, o_bt), acc = sg
+            dwc = dbc = dgamma = dbeta = None
+        else:
+            o_w, o_b, acc = Gm, None, 0
+            o_g = dgamma = torch.empty(Cn, device=dev, dtype=torch.float32)
+            o_bt = dbeta = torch.empty(Cn, device=dev, dtype=torch.float32)
+            dwc, dbc = Gm, dbc_t
+        lib.call(lib._chain_affine, "bmc_chain_affine_grads", Gm.data_ptr(), dbc_t.data_ptr(), wc.detach().data_ptr(),
+                 gamma.detach().data_ptr(), beta.detach().data_ptr(), Cn, o_w.data_ptr(),
+                 o_b.data_ptr() if o_b is not None else None, o_g.data_ptr(), o_bt.data_ptr(), acc, _stream())
+        dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf)
+        _dgrad(X(dv1), w_v1, s1, 0, o_wv1, dx12, n, accumulate=True)                                     # dx12[first] += value conv
+        # ---- residual block (second half), upstream gradient = g_o
+        dw2, db2 = _wgrad(X(g_o), [X(t2)], s1, n, H, W, 9, Cn, dev, p_rw2, p_rb2)
+        dt = new(n)
+        _dgrad(X(g_o), w_r2, s1, 0, o_rw2, dt, n, mask=X(t2))
+        dw1, db1 = _wgrad(X(dt), [X(x12, b0=n, B=n)], s1, n, H, W, 9, Cn, dev, p_rw1, p_rb1)
+        _dgrad(X(dt), w_r1, s1, 0, o_rw1, dx12, n, residual=X(g_o), accumulate=True, out_b0=n)           # dx12[second] += conv1^T + skip
+        v = lambda t, ref: None if t is None else t.view(ref.shape)
+        return (dx12, dxs, dw1, db1, dw2, db2, dwf, dbf, dgamma, dbeta, v(dwc, wc), dbc, dwu, dbu, v(dwv1, wv1), dbv1, None, None)
+
+
+def bie_first(m, x12, xs):
+    """m: models.submodules.BIE; -> (o1, xs_new) (BIEFirstFn)."""
+    r = m.conv1
+    return BIEFirstFn.apply(x12, xs, r.conv1.weight, r.conv1.bias, r.conv2.weight, r.conv2.bias, m.convf1.weight,
+                            m.convf1.bias, m.norm_s.weight, m.norm_s.bias, m.clustering.weight, m.clustering.bias,
+                            m.unclustering.weight, m.unclustering.bias, m.v1.weight, m.v1.bias, m.scale, m.norm_s.eps)
 
 
 def bie_twin(m, x12, xs):

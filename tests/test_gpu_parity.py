@@ -561,6 +561,49 @@ def test_fused_twin_bie_matches_unfused_autograd_path():
         assert rel_l2(ga, gb) < 5e-5
 
 
+def test_fused_first_output_bie_matches_unfused_autograd_path():
+    """bmc_hip.bie.BIEFirstFn (the last block's local BIE: only the first output) against forward_pair(need_second=False)
+    composed from the generic autograd Functions: outputs, input gradients and every parameter gradient that exists
+    (v2 gets none in either path)."""
+    dev = _gpu()
+    from bmc_hip import bie, ops
+    from models.submodules import BIE
+    ops.set_math("fp32")
+    torch.manual_seed(8)
+    Cn, B, H, W = 32, 2, 13, 21
+    assert bie.chain_supported(Cn)
+    m = BIE(Cn).to(dev)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(4.0).add_(0.05 * torch.randn_like(p))
+    x12 = torch.randn(2 * B, H, W, Cn, device=dev)
+    xs = torch.randn(B, H, W, Cn, device=dev)
+    go, gx = torch.randn(B, H, W, Cn, device=dev), torch.randn(B, H, W, Cn, device=dev)
+
+    def unfused(a, b):
+        o1, _, s = m.forward_pair(a[:B], a[B:], b, need_second=False)
+        return o1, s
+    res = []
+    for fn in (unfused, m.forward_first):
+        a, b = x12.clone().requires_grad_(), xs.clone().requires_grad_()
+        for p in m.parameters():
+            p.grad = None
+        o, s = fn(a, b)
+        torch.autograd.backward([o, s], [go, gx])
+        res.append((o.detach(), s.detach(), a.grad, b.grad, {k: (p.grad.clone() if p.grad is not None else None)
+                                                               for k, p in m.named_parameters()}))
+    for i in range(4):
+        assert rel_l2(res[1][i], res[0][i]) < 2e-5, i
+    n = 0
+    for k in res[0][4]:
+        ga, gb = res[1][4][k], res[0][4][k]
+        assert (ga is None) == (gb is None), k
+        if ga is not None:
+            assert rel_l2(ga, gb) < 5e-5, k
+            n += 1
+    assert n == 14 and res[0][4]["v2.weight"] is None
+
+
 @pytest.mark.parametrize("math", ["fp32", "bf16x6"])
 def test_training_reduces_loss_and_matches_oracle_trajectory(math):
     """Three optimizer steps of the reference's recipe (Adam lr=1e-4, wd=1e-5, amsgrad; train.py:647-656) on the HIP

@@ -5,10 +5,10 @@ R=$PWD; O=$R/gpurun_out/r02; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
 python bench.py > $O/r02_bench_default.json 2> $O/default.err
-python bench.py --height 31 --width 56 --math bf16 > $O/r02_bench_config3_bf16.json 2>> $O/default.err
-python bench.py --height 31 --width 56 --math bf16 --graph > $O/r02_bench_config3_bf16_graph.json 2>> $O/default.err
-python bench.py --height 31 --width 56 > $O/r02_bench_config3_fp32.json 2>> $O/default.err
-python bench.py --height 31 --width 56 --graph > $O/r02_bench_config3_fp32_graph.json 2>> $O/default.err
+python bench.py --height 31 --width 56 --math bf16 --warmup 3 --steps 10 > $O/r02_bench_config3_bf16.json 2>> $O/default.err
+python bench.py --height 31 --width 56 --math bf16 --graph --warmup 3 --steps 10 > $O/r02_bench_config3_bf16_graph.json 2>> $O/default.err
+python bench.py --height 31 --width 56 --warmup 3 --steps 10 > $O/r02_bench_config3_fp32.json 2>> $O/default.err
+python bench.py --height 31 --width 56 --graph --warmup 3 --steps 10 > $O/r02_bench_config3_fp32_graph.json 2>> $O/default.err
 python bench.py --height 180 --width 190 --seql 17 --batch 8 --recompute --steps 3 --warmup 1 > $O/r02_bench_config4.json 2>> $O/default.err
 python bench.py --math bf16x6 > $O/r02_bench_bf16x6.json 2>> $O/default.err
 cd /tmp
