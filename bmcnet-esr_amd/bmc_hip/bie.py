@@ -93,11 +93,13 @@ def chain_fwd(s0, s1, wf, bf, gamma, beta, wc, bc, eps, B, H, W, Cn, dev):
     return yhat, rstd, centre
 
 
-def chain_bwd(dc, yhat, rstd, gamma, wf, wc, add, n, H, W, Cn, dev):
-    """-> (dz [2n,H,W,C], ds1 [2n,H,W,C], ds0 [n,H,W,C]); dc: lib.Src over 2n launch batches, add: lib.Src or None."""
+def chain_bwd(dc, yhat, rstd, gamma, wf, wc, add, n, H, W, Cn, dev, ds1=None):
+    """-> (dz [2n,H,W,C], ds1 [2n,H,W,C], ds0 [n,H,W,C]); dc: lib.Src over 2n launch batches, add: lib.Src or None;
+    ds1: optional preallocated destination."""
     _, bwd = _chain_streams(wf, wc, Cn)
     dz = torch.empty((2 * n, H, W, Cn), device=dev, dtype=torch.float32)
-    ds1 = torch.empty((2 * n, H, W, Cn), device=dev, dtype=torch.float32)
+    if ds1 is None:
+        ds1 = torch.empty((2 * n, H, W, Cn), device=dev, dtype=torch.float32)
     ds0 = torch.empty((n, H, W, Cn), device=dev, dtype=torch.float32)
     a = lib.ChainBwdArgs()
     a.dcentre = dc
@@ -208,6 +210,7 @@ class BIETwinFn(torch.autograd.Function):
         ctx.vparams = (wv1, wv2, bv1, bv2)
         ctx.scale = scale
         ctx.fused = fused
+        ctx.gslot = getattr(x12, "_bmc_gslot", None)     # (set before .contiguous(): see the top of this function)
         return o12, xs_new
 
     @staticmethod
@@ -253,7 +256,8 @@ class BIETwinFn(torch.autograd.Function):
         if ctx.fused:
             # ---- clustering, LayerNorm, convf: ONE data-gradient launch (csrc/chain.hip); y12 holds yhat, stats rstd.
             # dx12 = conv_f^T (second half of its inputs), dxs = skip + conv_f^T (first half) summed over both halves.
-            dz12, dx12, dxs = chain_bwd(X(dc12), y12, stats, gamma.detach(), wf, wc, X(g_x), n, H, W, Cn, dev)
+            dz12, dx12, dxs = chain_bwd(X(dc12), y12, stats, gamma.detach(), wf, wc, X(g_x), n, H, W, Cn, dev,
+                                        ds1=ops.grad_slot(ctx.gslot, x12))
             # G = dc^T yhat and the clustering bias gradient (temporaries: dW_c, dgamma, dbeta follow from them)
             Gm, dbc_t = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev, None, None, w_shape=(Cn, Cn))
             sg = ops.sink_group([p_wc, p_bc, p_gamma, p_beta])
@@ -271,7 +275,7 @@ class BIETwinFn(torch.autograd.Function):
             dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf)
             _dgrad(X(dv12), w_v, s1, 0, w_v, dx12, B2, bpg=n, accumulate=True)                          # dx12 += value convs
         else:
-            dx12 = new(B2)
+            dx12 = ops.grad_slot(ctx.gslot, x12)
             _dgrad(X(dv12), w_v, s1, 0, w_v, dx12, B2, bpg=n)                                           # dx12  =
             # ---- clustering, LayerNorm, convf
             dwc, dbc = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev, p_wc, p_bc)
@@ -448,6 +452,16 @@ class Unstack2Fn(torch.autograd.Function):
         ctx.n = n
         ctx.shape = t.shape
         return t[:n], t[n:]
+
+    @staticmethod
+    def unstack(t):
+        """apply() + the gradient-pair tags on the two views (ops.GradPair): consumers that know the protocol write their
+        input gradients into the halves of one buffer, and backward below hands it on without a copy."""
+        a, b = Unstack2Fn.apply(t)
+        if ops.GRAD_PAIRS and t.requires_grad:
+            pair = ops.GradPair(t.shape[0] // 2, t.shape)
+            a._bmc_gslot, b._bmc_gslot = (pair, 0), (pair, 1)
+        return a, b
 
     @staticmethod
     def backward(ctx, g1, g2):

@@ -619,6 +619,40 @@ def _wgrad_plain(g, x, spec, w_param, b_param, taps):
     return reduce_wgrad(slabs, nsplit, 1, taps, Cout, spec, dev, bsl, w_param, b_param, w_param.shape)
 
 
+GRAD_PAIRS = os.environ.get("BMC_GRAD_PAIRS", "1") != "0"
+
+
+class GradPair:
+    """Where the consumers of the two halves of an un-stacked tensor (bie.Unstack2Fn) put their input gradients: the halves
+    of ONE lazily allocated buffer, so that Unstack2Fn.backward returns it as it is instead of concatenating two tensors
+    (41 full-size copies per C2 step).  The forward tags the two output views (`_bmc_gslot = (pair, half)`); a consumer that
+    knows the protocol (ResBlockFn, BIETwinFn) writes into grad_slot(...) -- any other consumer, or a view with several
+    consumers, simply produces an ordinary gradient and the concatenation happens as before."""
+    __slots__ = ("n", "shape", "buf", "taken")
+
+    def __init__(self, n, shape):
+        self.n, self.shape, self.buf, self.taken = n, tuple(shape), None, [False, False]
+
+    def half(self, i, like):
+        """Each half is handed out ONCE (a view with two protocol-aware consumers, or a second backward through a retained
+        graph, gets an ordinary tensor: two writers must never share a destination)."""
+        if self.taken[i]:
+            return torch.empty_like(like)
+        self.taken[i] = True
+        if self.buf is None:
+            self.buf = torch.empty(self.shape, device=like.device, dtype=like.dtype)
+        return self.buf[i * self.n:(i + 1) * self.n]
+
+
+def grad_slot(tag, like):
+    """tag: what the forward found on its input (`getattr(x, "_bmc_gslot", None)`); -> the tensor to write dx into."""
+    if tag is None:
+        return torch.empty_like(like)
+    pair, i = tag
+    t = pair.half(i, like)
+    return t if t.shape == like.shape else torch.empty_like(like)
+
+
 class OutSlot:
     """Where a Function should put its result: batches [b0, b0 + B) of a preallocated buffer (kept out of autograd's
     sight on purpose -- see bie.Stack2Fn)."""
@@ -649,6 +683,7 @@ class ResBlockFn(torch.autograd.Function):
         ctx.spec, ctx.taps = spec, taps
         ctx.owners = (w1, w2)
         ctx.params = (w1, b1, w2, b2)
+        ctx.gslot = getattr(x, "_bmc_gslot", None)
         return y
 
     @staticmethod
@@ -673,7 +708,7 @@ class ResBlockFn(torch.autograd.Function):
         dx = None
         if need[0]:   # dx = conv1^T(dt) + g (skip path): residual epilogue
             w1t = _packed_weight_t(w1.detach().reshape(1, Cn, Cn, taps), spec, 0, ctx.owners[0])
-            dx = torch.empty_like(g)
+            dx = grad_slot(ctx.gslot, g)
             conv_raw([_src(dt, 0, Cn, 0, None, 0, B)], w1t, c16 * taps * nkpad, None, 0, dx.data_ptr(), H * W * Cn, Cn, B, H, W,
                      Cn, taps, residual=gs, flops=fl)
         return dx, dw1, db1, dw2, db2, None, None

@@ -42,7 +42,7 @@ class ParallelBlk(nn.Module):
             a = self.conv1.forward_nhwc(x12, out=slot)
             b = self.conv1_st.forward_nhwc(xst12, out=ops.OutSlot(slot.t, B2))
             o, xsst12 = self.lBIE.forward_twin(bie.Stack2Fn.apply(a, b, slot), xsst12)
-            x12, xst12 = bie.Unstack2Fn.apply(o)
+            x12, xst12 = bie.Unstack2Fn.unstack(o)
         elif bie.FUSE_FIRST and bie.chain_supported(x12.shape[-1]):
             # the same with only the first output of the local BIE (one fused node again: BIE.forward_first)
             B2 = x12.shape[0]
