@@ -458,9 +458,10 @@ class Unstack2Fn(torch.autograd.Function):
         """apply() + the gradient-pair tags on the two views (ops.GradPair): consumers that know the protocol write their
         input gradients into the halves of one buffer, and backward below hands it on without a copy."""
         a, b = Unstack2Fn.apply(t)
-        if ops.GRAD_PAIRS and t.requires_grad:
+        if ops.GRAD_PAIRS and t.requires_grad and a.grad_fn is not None:
             pair = ops.GradPair(t.shape[0] // 2, t.shape)
             a._bmc_gslot, b._bmc_gslot = (pair, 0), (pair, 1)
+            a.grad_fn.pair = pair        # backward drops the pair's reference to the buffer (graph nodes outlive their backward)
         return a, b
 
     @staticmethod
@@ -471,6 +472,12 @@ class Unstack2Fn(torch.autograd.Function):
             # the two gradients already lie back to back in one buffer (ops.StackViewsFn.backward hands out such views)
             out = torch.empty(0, device=g1.device, dtype=g1.dtype)
             out.set_(g1.untyped_storage(), g1.storage_offset(), tuple(ctx.shape), torch.empty(ctx.shape, device="meta").stride())
+            pair = getattr(ctx, "pair", None)
+            if pair is not None:
+                pair.buf = None          # `out` owns the storage from here on
             return out
+        pair = getattr(ctx, "pair", None)
+        if pair is not None:
+            pair.buf = None
         z = lambda: torch.zeros((ctx.n,) + tuple(ctx.shape[1:]), device=(g1 if g1 is not None else g2).device)
         return torch.cat([g1 if g1 is not None else z(), g2 if g2 is not None else z()], 0)
