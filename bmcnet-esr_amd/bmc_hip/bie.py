@@ -130,7 +130,7 @@ def _conv(srcs, w4, spec, owner, bias, out, B, relu=False, residual=None, mask=N
     wp = _packed_weight(w4, spec, owner)
     conv_raw(srcs, wp, spec.kpad * taps * coutpad(Cout), bias, Cout if bias is not None else 0,
              out.data_ptr() + 4 * out_b0 * H * W * Co, H * W * Co, Co, B, H, W, Cout, taps, relu=relu, residual=residual,
-             bpg=bpg, accumulate=accumulate, mask=mask, flops=2.0 * B * H * W * Cout * taps * spec.cin)
+             bpg=bpg, accumulate=accumulate, mask=mask, flops=2.0 * B * H * W * Cout * taps * spec.kreal)
 
 
 def _dgrad(g_src, w4, spec, src_index, owner, out, B, residual=None, mask=None, bpg=None, accumulate=False, out_b0=0):
@@ -150,7 +150,7 @@ def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, w_param, b_param, G=1,
     GEMM stages anyway) -> (dW, db) for autograd; None where the sums went straight into the leaf parameters' .grad
     (ops.reduce_wgrad).  G > 1 (stacked per-group weights): w_param None, result [G, ...]."""
     slabs, nsplit, _, bsl = pgemm_raw(a_src, x_srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
-                                      flops=2.0 * B * H * W * Cout * taps * spec.cin, want_bias=True)
+                                      flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)
     return ops.reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bsl, w_param, b_param,
                             w_shape if w_shape is not None else w_param.shape)
 
@@ -190,8 +190,8 @@ class BIETwinFn(torch.autograd.Function):
             _conv([X(y12)], d(wc).reshape(1, Cn, Cn, 1), s1, wc, d(bc), c12, B2)
         # values: v1 on the first half, v2 on the second (two weight groups)
         v12 = new(B2)
-        wv = ops.stacked((wv1, wv2), lambda: torch.stack([d(wv1).reshape(Cn, Cn, 1), d(wv2).reshape(Cn, Cn, 1)]))
-        bv = ops.stacked((bv1, bv2), lambda: torch.stack([d(bv1), d(bv2)]))
+        wv = ops.stacked((wv1, wv2), lambda: torch.stack([d(wv1).reshape(Cn, Cn, 1), d(wv2).reshape(Cn, Cn, 1)]), "v1x1")
+        bv = ops.stacked((bv1, bv2), lambda: torch.stack([d(bv1), d(bv2)]), "stack")
         _conv([X(x12)], wv, s1, wv, bv, v12, B2, bpg=n)
         # channel attention per sample
         slabs, nsplit, G = pgemm_raw(X(c12), [X(v12)], B2, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * B2 * H * W * Cn * Cn)
@@ -229,7 +229,7 @@ class BIETwinFn(torch.autograd.Function):
         w_r1, w_r2 = rw1.detach().reshape(1, Cn, Cn, 9), rw2.detach().reshape(1, Cn, Cn, 9)
         w_f, w_c, w_u = (rw.detach().reshape(1, Cn, k, 1) for rw, k in ((wf, 2 * Cn), (wc, Cn), (wu, 2 * Cn)))
         # (keyed by the caller's parameter objects: the saved tensors are fresh aliases in every backward)
-        w_v = ops.stacked(ctx.vparams[:2], lambda: torch.stack([wv1.detach().reshape(Cn, Cn, 1), wv2.detach().reshape(Cn, Cn, 1)]))
+        w_v = ops.stacked(ctx.vparams[:2], lambda: torch.stack([wv1.detach().reshape(Cn, Cn, 1), wv2.detach().reshape(Cn, Cn, 1)]), "v1x1")
 
         # ---- out = P v (+ rotated residual): dP, dv
         slabs, nsplit, G = pgemm_raw(X(g_o), [X(v12)], B2, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * B2 * H * W * Cn * Cn)

@@ -92,14 +92,21 @@ class ConvSpec:
     """sources: list of per-source lists giving, for each physical channel of the
     source window, the reference input-channel index it carries (or -1 = padding)."""
 
-    def __init__(self, sources: Sequence[Sequence[int]]):
+    def __init__(self, sources: Sequence[Sequence[int]], cin: Optional[int] = None):
+        """cin: input channels of the weight tensor the launch is given (default: just enough for the channels the sources
+        name).  A spec may name only PART of them -- one launch of a convolution that is evaluated as several launches over
+        channel subsets of ONE parameter (Backbone.conv_fs): packing reads, and the weight gradient writes, only the named
+        columns of the full [Cout, cin, kh, kw] tensor."""
         self.nch = [len(s) for s in sources]
         for n in self.nch:
             assert n % CK == 0, "source channel windows must be multiples of 16"
         flat = [c for s in sources for c in s]
         self.kpad = len(flat)
         self.kmap_host = flat
-        self.cin = max(flat) + 1
+        self.cin = max(flat) + 1 if cin is None else cin
+        assert self.cin > max(flat)
+        self.covers_all = set(range(self.cin)) <= set(flat)     # does a weight gradient through this spec define every column?
+        self.kreal = sum(1 for c in flat if c >= 0)             # input channels the launch really contracts (algorithmic FLOPs)
         self.real_nch = [sum(1 for c in src if c >= 0) for src in sources]
         self._kmap = {}
         self._packs = {}
@@ -171,7 +178,7 @@ def _cache_get(spec: ConvSpec, kind, owner):
     if owner is None:
         return None
     hit = spec._packs.get((kind, id(owner)))
-    if hit is not None and hit[0]() is owner and hit[1] == owner._version:
+    if hit is not None and hit[0]() is owner and hit[1] == (owner._version, _EPOCH):
         return hit[2]
     return None
 
@@ -181,18 +188,35 @@ def _cache_put(spec: ConvSpec, kind, owner, packed):
         if len(spec._packs) > 64:       # stale entries of dead owners
             for k in [k for k, v in spec._packs.items() if v[0]() is None]:
                 del spec._packs[k]
-        spec._packs[(kind, id(owner))] = (weakref.ref(owner), owner._version, packed)
+        spec._packs[(kind, id(owner))] = (weakref.ref(owner), (owner._version, _EPOCH), packed)
 
 
 _STACKS = {}
 
 
-def stacked(owners, build):
+def invalidate_caches():
+    """Drop every cached derived-weight tensor (packed / transposed / plane-split images, stacked group weights, the fused
+    chain's weight streams).  The caches are validated by parameter identity + version counter, which every in-place
+    torch op and every optimizer step bumps -- but writes through `.data` (p.data.copy_(), p.data.mul_(), EMA / weight-swap
+    utilities, the reference's own initialize_weights idiom, models/submodules.py:107-124) do NOT: call this after them.
+    load_state_dict() copies with copy_() under no_grad and is tracked."""
+    global _EPOCH
+    _EPOCH += 1
+    _STACKS.clear()
+    from . import bie
+    bie._CHAIN_CACHE.clear()
+
+
+_EPOCH = 0      # bumped by invalidate_caches(): part of every pack-cache validation (the packs hang off ConvSpec objects)
+
+
+def stacked(owners, build, tag=""):
     """A tensor derived from several parameters (the stacked per-group weights of a grouped launch), rebuilt only when
-    one of them changed: keyed by their ids, validated by weak references and version counters like the pack cache --
-    and, being one persistent object per parameter set, a valid pack-cache owner itself.  (Per step and BIE call this
-    saves two torch.stack launches, a pack and, in the bf16-plane modes, a plane split: ~600 tiny launches per step.)"""
-    key = tuple(id(o) for o in owners)
+    one of them changed: keyed by `tag` (the layout `build` produces) and their ids, validated by weak references and
+    version counters like the pack cache -- and, being one persistent object per parameter set, a valid pack-cache owner
+    itself.  (Per step and BIE call this saves two torch.stack launches, a pack and, in the bf16-plane modes, a plane
+    split: ~600 tiny launches per step.)"""
+    key = (tag,) + tuple(id(o) for o in owners)
     vers = tuple(o._version for o in owners)
     hit = _STACKS.get(key)
     if hit is not None and hit[1] == vers and all(r() is o for r, o in zip(hit[0], owners)):
@@ -371,17 +395,36 @@ ACCUM_PARAM_GRADS = os.environ.get("BMC_ACCUM_GRADS", "1") != "0"
 
 
 def is_sink(p):
-    return ACCUM_PARAM_GRADS and p is not None and p.is_leaf and p.requires_grad and p.is_contiguous()
+    """May a launch add its weight gradient straight into p.grad?  Only for contiguous leaf parameters, and only when nobody
+    is listening on autograd for them: a parameter with tensor hooks or post-accumulate-grad hooks keeps the autograd
+    route (the hooks fire only when autograd accumulates), unless the hook's owner declared that it stages sink gradients
+    itself (parallel.GradAllReducer sets p._bmc_sink_aware).  Not detectable from here, hence documented in INTEGRATION.md:
+    torch DDP / FSDP (hooks on the AccumulateGrad nodes) and torch.autograd.grad(loss, params) need BMC_ACCUM_GRADS=0 /
+    set_accumulate_param_grads(False)."""
+    if not (ACCUM_PARAM_GRADS and p is not None and p.is_leaf and p.requires_grad and p.is_contiguous()):
+        return False
+    if (p._post_accumulate_grad_hooks or p._backward_hooks) and not getattr(p, "_bmc_sink_aware", False):
+        return False
+    return True
 
 
-def sink_group(params):
+def set_accumulate_param_grads(on: bool):
+    """Switch the direct-to-.grad route for leaf parameters (default on; BMC_ACCUM_GRADS=0 at import time switches it off)."""
+    global ACCUM_PARAM_GRADS
+    ACCUM_PARAM_GRADS = bool(on)
+
+
+def sink_group(params, full=True):
     """params: the parameters ONE launch writes gradients for (it has one accumulate flag for all of them).
     -> ([their .grad tensors], accumulate) if every one is a leaf parameter, else None.  First use in a step allocates
-    the accumulators (accumulate = 0: the launch overwrites them); mixed states are aligned by zero-filling."""
+    the accumulators (accumulate = 0: the launch overwrites them); mixed states are aligned by zero-filling.
+    full=False: the launch defines only part of the gradient (ConvSpec.covers_all is false): new accumulators start as zeros."""
     if not all(is_sink(p) for p in params):
         return None
+    for p in params:        # seen by parallel.GradAllReducer.finish(): this gradient did not (only) come through autograd
+        p._bmc_sink_touched = True
     missing = [p.grad is None for p in params]
-    if all(missing):
+    if all(missing) and full:
         for p in params:
             p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
         acc = 0
@@ -400,9 +443,10 @@ def reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bias_slabs, w_param, b
     None where the gradient went straight into a leaf parameter's .grad (see above).  w_param / b_param may be tuples of
     G parameters (one per weight group of a grouped launch: v1 / v2, conv_hp / conv_hn)."""
     want_b = bias_slabs is not None
+    full = spec.covers_all
     if isinstance(w_param, (tuple, list)):
         ps = list(w_param) + (list(b_param) if want_b else [])
-        sg = sink_group(ps) if 1 < G <= 4 and len(w_param) == G else None
+        sg = sink_group(ps, full) if 1 < G <= 4 and len(w_param) == G else None
         if sg is not None:
             grads, acc = sg
             PA = C.c_void_p * G
@@ -412,7 +456,7 @@ def reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bias_slabs, w_param, b
                      spec.kmap(dev).data_ptr(), spec.cin, dwp, acc, bias_slabs.data_ptr() if want_b else None, dbp, _stream())
             return None, None
         w_param = b_param = None
-    sg = sink_group([w_param, b_param] if want_b else [w_param]) if G == 1 and w_param is not None else None
+    sg = sink_group([w_param, b_param] if want_b else [w_param], full) if G == 1 and w_param is not None else None
     if sg is not None:
         (gw, *rest), acc = sg
         gb = rest[0] if want_b else None
@@ -420,7 +464,7 @@ def reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bias_slabs, w_param, b
                  spec.kmap(dev).data_ptr(), spec.cin, gw.data_ptr(), acc, bias_slabs.data_ptr() if want_b else None,
                  gb.data_ptr() if want_b else None, _stream())
         return None, None
-    dw = torch.empty(G * Cout * spec.cin * taps, device=dev, dtype=torch.float32)
+    dw = (torch.empty if full else torch.zeros)(G * Cout * spec.cin * taps, device=dev, dtype=torch.float32)
     db = torch.empty((G, Cout), device=dev, dtype=torch.float32) if want_b else None
     lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, G, taps, Cout, spec.kpad,
              spec.kmap(dev).data_ptr(), spec.cin, dw.data_ptr(), 0, bias_slabs.data_ptr() if want_b else None,
@@ -432,11 +476,11 @@ def reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bias_slabs, w_param, b
 # convolution (3x3 / 1x1, multi-source, grouped weights)
 # --------------------------------------------------------------------------
 class ConvMeta:
-    __slots__ = ("spec", "views", "B", "relu", "G", "res", "cache", "taps", "out")
+    __slots__ = ("spec", "views", "B", "relu", "G", "res", "cache", "taps", "out", "ngp")
 
-    def __init__(self, spec, views, B, relu, G, res, cache, taps, out=None):
-        self.spec, self.views, self.B, self.relu, self.G, self.res, self.cache, self.taps, self.out = \
-            spec, views, B, relu, G, res, cache, taps, out
+    def __init__(self, spec, views, B, relu, G, res, cache, taps, out=None, ngp=0):
+        self.spec, self.views, self.B, self.relu, self.G, self.res, self.cache, self.taps, self.out, self.ngp = \
+            spec, views, B, relu, G, res, cache, taps, out, ngp
 
 
 class ConvFn(torch.autograd.Function):
@@ -445,7 +489,10 @@ class ConvFn(torch.autograd.Function):
     (torch.bmm(softmax, v) of models/submodules.py:72-73 is the G = B, 1x1 case)."""
 
     @staticmethod
-    def forward(ctx, meta: ConvMeta, weight, bias, res_t, *src_ts):
+    def forward(ctx, meta: ConvMeta, weight, bias, res_t, *rest):
+        # rest = the source tensors, then (meta.ngp of them) the parameters behind a stacked per-group weight: G weights,
+        # then G biases -- `weight` / `bias` are then detached stacks of them (ops.stacked) and the gradients go to these
+        src_ts, gps = (rest[:len(rest) - meta.ngp], rest[len(rest) - meta.ngp:]) if meta.ngp else (rest, ())
         for t in src_ts:
             _need_gpu(t)
         t0 = src_ts[0]
@@ -467,9 +514,11 @@ class ConvFn(torch.autograd.Function):
         cp = coutpad(Cout)
         conv_raw(srcs, wp, meta.spec.kpad * taps * cp, bias.detach() if bias is not None else None, Cout,
                  out.data_ptr(), H * W * Cout, Cout, B, H, W, Cout, taps, relu=meta.relu, residual=res,
-                 bpg=B // G, flops=2.0 * B * H * W * Cout * taps * meta.spec.cin)
+                 bpg=B // G, flops=2.0 * B * H * W * Cout * taps * meta.spec.kreal)
         ctx.meta = meta
         ctx.params = (weight, bias)  # the objects the caller passed (leaf parameters take their gradients directly)
+        if meta.ngp:
+            ctx.params = (tuple(gps[:G]), tuple(gps[G:]) if len(gps) > G else None)
         ctx.w_owner = ck            # identity of the parameter object (saved_tensors may hand back a new wrapper)
         ctx.has_bias = bias is not None
         ctx.has_res = res_t is not None
@@ -488,6 +537,12 @@ class ConvFn(torch.autograd.Function):
         w4 = weight.detach().reshape(G, Cout, spec.cin, taps).contiguous()
         ck = ctx.w_owner
         need = ctx.needs_input_grad
+        ngp = meta.ngp
+        nsrc = len(src_ts)
+        if ngp:      # (weight, bias) are detached stacks: what asks for the gradients are the parameters behind them
+            need = list(need)
+            need[1] = any(need[4 + nsrc:4 + nsrc + G])
+            need[2] = any(need[4 + nsrc + G:])
         dw = db = dres = None
         bias_done = False
         # ---- weight gradient: pixel-reduction GEMM  dW[co][k][tap] = sum_px g[px][co] * x[px+tap][k]
@@ -496,7 +551,7 @@ class ConvFn(torch.autograd.Function):
             a_src = _src(g, 0, Cout, 0, None, 0, B)
             wb = ctx.has_bias and need[2]
             r_pg = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
-                             flops=2.0 * B * H * W * Cout * taps * spec.cin, want_bias=wb)
+                             flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=wb)
             slabs, nsplit = r_pg[0], r_pg[1]
             wp_, bp_ = ctx.params
             dw, db = reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, r_pg[3] if wb else None, wp_, bp_ if wb else None,
@@ -588,6 +643,11 @@ class ConvFn(torch.autograd.Function):
             conv_raw([gsrc], wt, c16 * taps * nkpad, None, 0, dx.data_ptr() + 4 * (b0 * H * W * Ct + c0), H * W * Ct, Ct,
                      nb, H, W, nch, taps, bpg=nb // G, flops=2.0 * nb * H * W * spec.real_nch[i] * taps * Cout)
             dsrcs.append(dx)
+        if ngp:      # gradients of the stacked weights' owners: None when they went straight into .grad, else the stack's slices
+            wps, bps = ctx.params
+            gw = [None] * G if dw is None else [dw[i].reshape(wps[i].shape) for i in range(G)]
+            gb = [] if bps is None else ([None] * G if db is None else [db[i] for i in range(G)])
+            return (None, None, None, dres, *dsrcs, *gw, *gb)
         return (None, dw, db, dres, *dsrcs)
 
 
@@ -605,6 +665,25 @@ def conv(views: Sequence[View], weight, bias, spec: ConvSpec, *, B=None, relu=Fa
     return ConvFn.apply(meta, weight, bias, res_t, *[v.t for v in views])
 
 
+def conv_groups(views: Sequence[View], weights, biases, spec: ConvSpec, *, B=None, relu=False, residual=None, out=None):
+    """One launch over G = len(weights) batch groups, group g convolving with the PARAMETERS weights[g] / biases[g]
+    (equal shapes; models/BMCNet.py:79-80: conv_hp / conv_hn): the stacked operands are cached per parameter version
+    (`stacked`), and the weight / bias gradients of the launch go to the parameters themselves -- straight into their .grad
+    where they are leaves (bmc_pgemm_reduce_weight_groups), through autograd otherwise."""
+    G = len(weights)
+    B = views[0].t.shape[0] if B is None else B
+    w0 = weights[0]
+    taps = w0.shape[-1] * w0.shape[-2]
+    wst = stacked(tuple(weights), lambda: torch.stack([w.detach() for w in weights]), "stack")
+    bst = stacked(tuple(biases), lambda: torch.stack([b.detach() for b in biases]), "stack") if biases is not None else None
+    res_t, res_meta = None, None
+    if residual is not None:
+        res_t, res_meta = residual.t, (residual.shift, residual.mod)
+    gps = tuple(weights) + (tuple(biases) if biases is not None else ())
+    meta = ConvMeta(spec, [v.meta() for v in views], B, relu, G, res_meta, True, taps, out, ngp=len(gps))
+    return ConvFn.apply(meta, wst, bst, res_t, *[v.t for v in views], *gps)
+
+
 # --------------------------------------------------------------------------
 # fused residual block (models/submodules.py:17-35): both ReLU-backward and the skip-path gradient add live in
 # convolution epilogues, so the backward is exactly 2 data-gradient + 2 weight-gradient launches (+ bias sums)
@@ -615,7 +694,7 @@ def _wgrad_plain(g, x, spec, w_param, b_param, taps):
     B, H, W, Cout = g.shape
     dev = g.device
     slabs, nsplit, _, bsl = pgemm_raw(_src(g, 0, Cout, 0, None, 0, B), [_src(x, 0, x.shape[3], 0, None, 0, B)], B, H, W, taps,
-                                      B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.cin, want_bias=True)
+                                      B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)
     return reduce_wgrad(slabs, nsplit, 1, taps, Cout, spec, dev, bsl, w_param, b_param, w_param.shape)
 
 

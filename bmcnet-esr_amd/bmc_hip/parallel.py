@@ -47,6 +47,12 @@ class GradAllReducer:
         self.deferred = False        # a second backward before step() was detected (gradient accumulation)
         self.cuda = dev.type == "cuda"
         self.side = torch.cuda.Stream(device=dev) if self.cuda else None
+        # gloo with device buckets (the world-size-2 test of the HIP path on ONE GPU; RCCL refuses two ranks on one device):
+        # the bucket travels through host memory -- independent of whether this gloo build takes device tensors
+        self.host_stage = self.cuda and dist.is_initialized() and dist.get_backend(group) == "gloo"
+        for p in self.params:
+            p._bmc_sink_aware = True          # bmc_hip.ops.is_sink: our hooks do not need the autograd route (finish() stages)
+            p._bmc_sink_touched = False
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         if optimizer is not None:
             optimizer.register_step_pre_hook(lambda *_: self.finish())
@@ -61,6 +67,11 @@ class GradAllReducer:
             self.deferred = True
         self.seen.add(p)
         if self.deferred:
+            return
+        if getattr(p, "_bmc_sink_touched", False):
+            # a kernel has already added into this parameter's .grad during THIS backward (bmc_hip.ops.sink_group) and now
+            # autograd accumulates into it too: more sink adds may follow, so the bucket is not complete when its hook
+            # count says so.  Leave it to finish().
             return
         bi, off = self.slot[p]
         self.flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
@@ -79,6 +90,11 @@ class GradAllReducer:
     def _launch(self, bi):
         if not dist.is_initialized():
             return
+        if self.host_stage:
+            host = self.flat[bi].cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat[bi].copy_(host)
+            return
         if self.cuda:
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
@@ -95,11 +111,19 @@ class GradAllReducer:
         nb = len(self.buckets)
         active = [any(p.grad is not None for p in self.buckets[bi]) for bi in range(nb)]
         for bi in range(nb):
-            if not active[bi] or (not self.deferred and self.pending[bi] == 0):
-                continue                                   # nothing to do / complete and already in flight
+            if not active[bi]:
+                continue
+            # a bucket the hooks completed is in flight and final -- unless a kernel added into one of its parameters' .grad
+            # behind autograd's back (sink route): such a bucket is re-staged from .grad, whatever its hook count says
+            sunk = any(getattr(p, "_bmc_sink_touched", False) for p in self.buckets[bi])
+            if not self.deferred and self.pending[bi] == 0 and not sunk:
+                continue
+            launched = self.pending[bi] == 0 and not self.deferred
             w = self.works[bi]
-            if w is not None:                              # (cannot happen today: a launched bucket has pending == 0)
+            if w is not None:
                 w.wait(); self.works[bi] = None
+            if launched and self.cuda:
+                torch.cuda.current_stream().wait_stream(self.side)
             for p in self.buckets[bi]:
                 o = self.slot[p][1]
                 dst = self.flat[bi][o:o + p.numel()]
@@ -107,6 +131,12 @@ class GradAllReducer:
                     dst.zero_()
                 elif p.grad.data_ptr() != dst.data_ptr():
                     dst.copy_(p.grad.reshape(-1))
+                elif launched and self.world > 1:
+                    # .grad IS the bucket (zero_grad(set_to_none=False) keeps last step's views) and an all-reduce of the
+                    # half-finished bucket has already summed other ranks' data into it: the local gradient is gone
+                    raise RuntimeError("GradAllReducer: a parameter received gradients both through autograd and straight "
+                                       "from the kernels while its .grad aliases the reduction bucket; use "
+                                       "optimizer.zero_grad(set_to_none=True) or BMC_ACCUM_GRADS=0")
             self._launch(bi)
         self._join()
         for bi in range(nb):
@@ -122,6 +152,8 @@ class GradAllReducer:
         self.works = [None] * nb
         self.seen = set()
         self.deferred = False
+        for p in self.params:
+            p._bmc_sink_touched = False
 
 
 def reduce_tensor(t: torch.Tensor, group=None) -> torch.Tensor:

@@ -52,6 +52,8 @@ struct SrcDev {
     int batch_shift;
     int batch_mod;
 };
+// the kernels keep tables of these in LDS, sized as 8 floats per entry (conv.hip, conv1.hip, chain.hip)
+static_assert(sizeof(SrcDev) == 32 && alignof(SrcDev) == 8, "SrcDev must stay 32 bytes: LDS source tables are sized by it");
 static inline SrcDev to_dev(const bmc_src_t& s) {
     SrcDev d;
     d.ptr = s.ptr; d.batch_stride = s.batch_stride; d.pix_stride = s.pix_stride; d.nch = s.nch;

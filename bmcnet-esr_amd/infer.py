@@ -8,7 +8,14 @@ import torch
 class StreamingSR:
     """graph=True: from the third window on, a window is ONE HIP-graph replay (the ~300 kernel launches of a window are
     captured once, input and recurrent state live in static buffers) -- at small sensor sizes the eager window is bound by
-    the host's launch rate, not by the GPU."""
+    the host's launch rate, not by the GPU.
+
+    The tensor step() returns belongs to the caller in both modes: in graph mode it is a copy of the static prediction
+    buffer (the next replay overwrites that buffer).  The captured graph is tied to the input shape and to the
+    parameter values it was captured with (the packed weight images are baked into it): a different input shape raises,
+    a parameter update (load_state_dict, optimizer step, in-place edit -- anything that bumps a parameter's version
+    counter) makes the next step() capture afresh; edits through `.data` bypass the counters -- call reset() or
+    invalidate() after them."""
 
     def __init__(self, model, n_c=128, scale=4, plain=False, graph=False):
         self.model = model.eval()
@@ -17,10 +24,20 @@ class StreamingSR:
         self.reset()
 
     def reset(self):
+        """Forget the recurrent state, the timings and the captured graph with its static buffers."""
         self.state = None
         self.times_ms = []
-        self._graph = self._x_static = self._out_static = None
         self._calls = 0
+        self.invalidate()
+
+    def invalidate(self):
+        """Drop the captured graph (the next graph-mode step() captures again); the recurrent state is kept."""
+        if getattr(self, "_graph", None) is not None and self.state is not None:
+            self.state = tuple(t.clone() for t in self._state_static)      # the state outlives the static buffers
+        self._graph = self._x_static = self._state_static = self._stamp = None
+
+    def _weights_stamp(self):
+        return tuple((id(p), p._version) for p in self.model.parameters())
 
     def _capture(self, x):
         """Capture `state <- model(x_static, state, False)` with the state in static buffers."""
@@ -38,11 +55,16 @@ class StreamingSR:
             for dst, src in zip(self._state_static, out):
                 dst.copy_(src)
         self._graph = g
+        self._stamp = self._weights_stamp()
 
     @torch.no_grad()
     def step(self, x, timed=True):
-        """x [B,2,T>=2,H,W] on the GPU (inp_cnt.transpose(1,2) of the reference) -> HR prediction [B,2,sH,sW]."""
+        """x [B,2,T>=2,H,W] on the GPU (inp_cnt.transpose(1,2) of the reference; T = 3 with the reference's default
+        SEQN, infer_BMCNet.py:147 -- only frames 0 and 1 are read, models/BMCNet.py:106-107) -> HR prediction [B,2,sH,sW]."""
         B, _, _, H, W = x.shape
+        if self.state is not None and tuple(self.state[0].shape) != (B, self.n_c, H, W):
+            raise RuntimeError("StreamingSR: input %s does not match the carried state %s; call reset() to start a new "
+                               "sequence" % (tuple(x.shape), tuple(self.state[0].shape)))
         start = end = None
         if timed:
             start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -55,21 +77,28 @@ class StreamingSR:
             else:
                 out = self.model(x, z(self.n_c), z(self.n_c), z(self.n_c), z(2 * self.scale ** 2), True)
             self.state = tuple(out)
+            pred = out[-1]
         elif self.use_graph and self._calls >= 3:
+            if self._graph is not None and self._stamp != self._weights_stamp():
+                self.invalidate()                           # the graph replays the OLD packed weights
             if self._graph is None:
                 self._capture(x)
+            if tuple(x.shape) != tuple(self._x_static.shape):
+                raise RuntimeError("StreamingSR(graph=True): input shape %s differs from the captured %s; call reset()"
+                                   % (tuple(x.shape), tuple(self._x_static.shape)))
             self._x_static.copy_(x)
             self._graph.replay()
             self.state = tuple(self._state_static)
-            out = self.state
+            pred = self._state_static[-1].clone()           # the caller's own copy: the next replay rewrites the buffer
         else:
             out = self.model(x, *self.state, False)
             self.state = tuple(out)
+            pred = out[-1]
         if timed:
             end.record()
             end.synchronize()
             self.times_ms.append(start.elapsed_time(end))
-        return out[-1]
+        return pred
 
     @staticmethod
     @torch.no_grad()
@@ -78,6 +107,15 @@ class StreamingSR:
         they differ (:77-78; EventZoom: 124x224 vs 124x222), then the mean squared error."""
         from bmc_hip import ops
         return torch.nn.functional.mse_loss(ops.bicubic_resize(pred, gt.shape[-2:]), gt)
+
+    @staticmethod
+    @torch.no_grad()
+    def bicubic_mse(inp_cnt, gt, gt_size=None):
+        """The baseline metric of infer_BMCNet.py:79,85: the LR count image of the window's middle frame (inp_cnt[:, 1],
+        [B,2,H,W]) bicubic-upsampled to gt_sensor_resolution (default: the ground truth's size) against the ground truth."""
+        from bmc_hip import ops
+        size = tuple(gt.shape[-2:]) if gt_size is None else tuple(gt_size)
+        return torch.nn.functional.mse_loss(ops.bicubic_resize(inp_cnt.contiguous(), size), gt)
 
     def latency_ms(self, skip=1):
         """Mean per-window latency (the reference's `time` metric), ignoring the first `skip` windows."""

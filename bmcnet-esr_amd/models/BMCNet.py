@@ -102,8 +102,11 @@ class Backbone(nn.Module):
         self._sp_fps = ConvSpec([pad16([-1] * r + rng(0, r)), rng(r, n_c)])
         # conv_fs is applied three times to cat[xp_st, xn_st, h*, o] with only h* changing (models/BMCNet.py:70-73):
         # the contribution of the shared 2*n_c + 2*s2 input channels is computed once (with the bias), the h* part per call
-        self._sp_fs_shared = ConvSpec([rng(0, n_c), rng(n_c, n_c), padk(2 * n_c, s2), padk(2 * n_c + s2, s2)])
-        self._sp_fs = ConvSpec([rng(0, n_c), rng(n_c, n_c), rng(2 * n_c, n_c), padk(3 * n_c, s2), padk(3 * n_c + s2, s2)])
+        # (both launches take the PARAMETER conv_fs.weight and name their columns of it: no per-window slice / cat copies,
+        # the packs are cached per optimizer step and both weight gradients add straight into conv_fs.weight.grad)
+        cin_fs = 3 * n_c + 2 * s2
+        self._sp_fs_shared = ConvSpec([rng(0, n_c), rng(n_c, n_c), padk(3 * n_c, s2), padk(3 * n_c + s2, s2)], cin=cin_fs)
+        self._sp_fs_h = ConvSpec([rng(2 * n_c, n_c)], cin=cin_fs)
         self._sp_h = ConvSpec.dense(n_c)
         self._sp_o = ConvSpec.dense(n_c, n_c)
         self.n_c = n_c
@@ -119,13 +122,11 @@ class Backbone(nn.Module):
         s12 = ops.conv([View(xin12), View(hpn)], self.conv_fps.weight, self.conv_fps.bias, self._sp_fps,
                        relu=True)                                          # [xp_s; xn_s]
         # conv_fs on cat[xp_st, xn_st, h*, o] for h* = hp, hn, hs: one launch over 3B
-        n_c = self.n_c
         wfs = self.conv_fs.weight
-        w_shared = torch.cat([wfs[:, :2 * n_c], wfs[:, 3 * n_c:]], 1)      # input channels of xp_st, xn_st, o
-        shared = ops.conv([View(st12, b0=0), View(st12, b0=B), View(o12, b0=0), View(o12, b0=B)], w_shared,
-                          self.conv_fs.bias, self._sp_fs_shared, B=B, cache=False)
-        fs3 = ops.conv([View(h3)], wfs[:, 2 * n_c:3 * n_c].contiguous(), None, self._sp_h, B=3 * B, relu=True,
-                       residual=View(shared, mod=B), cache=False)          # [xs_p_st; xs_n_st; xs]
+        shared = ops.conv([View(st12, b0=0), View(st12, b0=B), View(o12, b0=0), View(o12, b0=B)], wfs,
+                          self.conv_fs.bias, self._sp_fs_shared, B=B)      # input channels of xp_st, xn_st, o (+ the bias)
+        fs3 = ops.conv([View(h3)], wfs, None, self._sp_fs_h, B=3 * B, relu=True,
+                       residual=View(shared, mod=B))                       # + those of h*: [xs_p_st; xs_n_st; xs]
         sst12, xs = fs3[:2 * B], fs3[2 * B:]
         n_layers = len(self.para_reschunk)
         for i, layer in enumerate(self.para_reschunk):      # x*_st of the last block is never read: skip what only feeds it
@@ -134,9 +135,8 @@ class Backbone(nn.Module):
         # (ops.stack_states recognises the adjacent views)
         hbuf = torch.empty((3 * B,) + tuple(xs.shape[1:]), device=xs.device, dtype=xs.dtype)
         x_h = ops.conv([View(xs)], self.conv_hs.weight, self.conv_hs.bias, self._sp_h, relu=True, out=ops.OutSlot(hbuf, 0))
-        hw = torch.stack([self.conv_hp.weight, self.conv_hn.weight])
-        hb = torch.stack([self.conv_hp.bias, self.conv_hn.bias])
-        x_hpn = ops.conv([View(sst12)], hw, hb, self._sp_h, relu=True, G=2, cache=False, out=ops.OutSlot(hbuf, B))
+        x_hpn = ops.conv_groups([View(sst12)], (self.conv_hp.weight, self.conv_hn.weight), (self.conv_hp.bias, self.conv_hn.bias),
+                                self._sp_h, relu=True, out=ops.OutSlot(hbuf, B))
         x_hp, x_hn = bie.Unstack2Fn.apply(x_hpn)
         w_o, b_o = self.conv_o.weight, self.conv_o.bias
         if self.cop != 2 * self.s2:        # x2 SR: 8 output channels -> computed as 16 (zero rows), the head reads the first 8

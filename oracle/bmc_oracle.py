@@ -242,9 +242,105 @@ def augment_flags(seed, mechanisms=("Horizontal", "Vertical", "Polarity"), probs
 # --------------------------------------------------------------------------
 # building blocks (models/submodules.py)
 # --------------------------------------------------------------------------
+# --------------------------------------------------------------------------
+# operand rounding: the contract of the kernels' BMC_MATH_BF16 mode (include/bmc_hip.h), BASELINE configs[3]
+# --------------------------------------------------------------------------
+# With operand_rounding("bf16") active, EVERY matrix contraction of the path -- each 3x3 / 1x1 convolution and each bmm,
+# in its forward, its data gradient and its weight gradient -- rounds BOTH of its operands to bf16 (round to nearest even
+# of the float32 value) and accumulates exactly (here: in the tensors' own dtype, float64 in the tests).  Everything else
+# (bias / residual adds, ReLU, LayerNorm, softmax, the attention scale, pixel shuffles, resizes, the loss) stays unrounded,
+# and so do the stored activations: only what enters a matrix product is rounded, each time it enters one.  That is NOT
+# the autograd derivative of a forward with rounded operands (which would contract the unrounded upstream gradient): the
+# backward contractions are specified here, as the kernels compute them -- gradients are operands too.
+_OPERAND_ROUND = None
+
+
+class operand_rounding:
+    """Context manager: `with operand_rounding("bf16"): ...` (None = the reference's plain float arithmetic)."""
+
+    def __init__(self, mode):
+        if mode not in (None, "bf16"):
+            raise ValueError("operand_rounding: unknown mode %r" % (mode,))
+        self.mode = mode
+
+    def __enter__(self):
+        global _OPERAND_ROUND
+        self.prev, _OPERAND_ROUND = _OPERAND_ROUND, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _OPERAND_ROUND
+        _OPERAND_ROUND = self.prev
+        return False
+
+
+def round_bf16(t: torch.Tensor) -> torch.Tensor:
+    """Nearest bf16 (ties to even) of the float32 value of every element, returned in t's dtype."""
+    return t.detach().to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+class _RoundedConv2d(torch.autograd.Function):
+    """y = conv2d(r(x), r(w)) + b;  dx = conv2d^T(r(g), r(w));  dw = sum_px r(g) r(x);  db = sum_px g  (r = round_bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xr, wr = round_bf16(x), round_bf16(w)
+        ctx.save_for_backward(xr, wr)
+        ctx.has_bias = b is not None
+        if x.dtype != torch.float64:
+            return F.conv2d(xr, wr, b, stride=1, padding=w.shape[-1] // 2)
+        # float64 (the precision the GPU tests check against): ATen's double convolution is a slow path on CPU; the same
+        # sums as one matrix product over unfolded patches are ~5x faster
+        B, _, H, W = xr.shape
+        k = wr.shape[-1]
+        cols = xr.reshape(B, xr.shape[1], H * W) if k == 1 else F.unfold(xr, k, padding=k // 2)
+        y = torch.matmul(wr.reshape(wr.shape[0], -1), cols).reshape(B, wr.shape[0], H, W)
+        return y + b.view(1, -1, 1, 1) if b is not None else y
+
+    @staticmethod
+    def backward(ctx, g):
+        xr, wr = ctx.saved_tensors
+        gr = round_bf16(g)
+        pad = wr.shape[-1] // 2
+        dx = torch.nn.grad.conv2d_input(xr.shape, wr, gr, stride=1, padding=pad) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv2d_weight(xr, wr.shape, gr, stride=1, padding=pad) if ctx.needs_input_grad[1] else None
+        db = g.sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+class _RoundedBmm(torch.autograd.Function):
+    """C = bmm(r(A), r(B));  dA = bmm(r(G), r(B)^T);  dB = bmm(r(A)^T, r(G))."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ar, br = round_bf16(a), round_bf16(b)
+        ctx.save_for_backward(ar, br)
+        return torch.bmm(ar, br)
+
+    @staticmethod
+    def backward(ctx, g):
+        ar, br = ctx.saved_tensors
+        gr = round_bf16(g)
+        da = torch.bmm(gr, br.transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        db = torch.bmm(ar.transpose(1, 2), gr) if ctx.needs_input_grad[1] else None
+        return da, db
+
+
+def conv2d(x: torch.Tensor, w: torch.Tensor, b) -> torch.Tensor:
+    """Same-padding stride-1 convolution under the active operand rounding."""
+    if _OPERAND_ROUND == "bf16":
+        return _RoundedConv2d.apply(x, w, b)
+    return F.conv2d(x, w, b, stride=1, padding=w.shape[-1] // 2)
+
+
+def bmm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    if _OPERAND_ROUND == "bf16":
+        return _RoundedBmm.apply(a, b)
+    return torch.bmm(a, b)
+
+
 def conv(p: Params, name: str, x: torch.Tensor) -> torch.Tensor:
-    w = p[name + ".weight"]
-    return F.conv2d(x, w, p[name + ".bias"], stride=1, padding=w.shape[-1] // 2)
+    return conv2d(x, p[name + ".weight"], p[name + ".bias"])
 
 
 def res_block(p: Params, name: str, x: torch.Tensor) -> torch.Tensor:
@@ -278,10 +374,10 @@ def bie(p: Params, name: str, x_1, x_2, x_s):
     v1 = conv(p, name + ".v1", x_1).reshape(b, c, h * w)
     v2 = conv(p, name + ".v2", x_2).reshape(b, c, h * w)
     s = c ** -0.5
-    a1 = torch.softmax(torch.bmm(c1, v1.transpose(1, 2)) * s, dim=-1)
-    a2 = torch.softmax(torch.bmm(c2, v2.transpose(1, 2)) * s, dim=-1)
-    o1 = torch.bmm(a1, v1).reshape(b, c, h, w)
-    o2 = torch.bmm(a2, v2).reshape(b, c, h, w)
+    a1 = torch.softmax(bmm(c1, v1.transpose(1, 2)) * s, dim=-1)      # the scale multiplies the product, unrounded (:69-70)
+    a2 = torch.softmax(bmm(c2, v2.transpose(1, 2)) * s, dim=-1)
+    o1 = bmm(a1, v1).reshape(b, c, h, w)
+    o2 = bmm(a2, v2).reshape(b, c, h, w)
     xs_new = conv(p, name + ".unclustering",
                   torch.cat([c1.reshape(b, c, h, w), c2.reshape(b, c, h, w)], dim=1)) + x_s
     return o1 + r2, o2 + r1, xs_new
@@ -391,10 +487,14 @@ def bmcnet_backbone(p: Params, x1p, x1n, x2p, x2n, hp, hn, hs, o, scale: int):
     return x_h, x_h_p, x_h_n, x_o
 
 
-def bmcnet_forward(p: Params, x, x_h, x_h_p, x_h_n, x_o, init: bool, scale: int = 4, repeat: int = 3):
+def bmcnet_forward(p: Params, x, x_h, x_h_p, x_h_n, x_o, init: bool, scale: int = 4, repeat: int = 3, operand_round=None):
     """One recurrent window -- models/BMCNet.py:95-121.
     x [B,2,T>=2,H,W]; x_o is [B,2*s*s,H,W] when init else the previous HR
-    prediction [B,2,sH,sW]."""
+    prediction [B,2,sH,sW].  operand_round="bf16": see operand_rounding above (the backward of the returned tensors
+    carries the rounding rule with it: the custom Functions are in the graph)."""
+    if operand_round is not None:
+        with operand_rounding(operand_round):
+            return bmcnet_forward(p, x, x_h, x_h_p, x_h_n, x_o, init, scale, repeat)
     f1, f2 = x[:, :, 0], x[:, :, 1]
     rep = lambda t: t.repeat(1, repeat, 1, 1)
     x1p, x1n = rep(f1[:, 0:1]), rep(f1[:, 1:2])
@@ -442,11 +542,14 @@ def plain_forward(p: Params, x, x_h, x_o, init: bool, scale: int = 4, repeat: in
 # training step (train.py:202-237) and optimiser (config/train_nfs.yml:28-34)
 # --------------------------------------------------------------------------
 def bptt_loss(p: Params, inp_windows: Sequence[torch.Tensor], gt_windows: Sequence[torch.Tensor],
-              n_c: int, scale: int = 4, plain: bool = False):
+              n_c: int, scale: int = 4, plain: bool = False, operand_round=None):
     """Sum over windows of mean-squared error between the SR prediction and
     the HR count image, recurrent state carried without detach --
     train.py:205-234.  inp_windows[i] is [B,2(pol),T,H,W] (already transposed
     as train.py:211 does), gt_windows[i] is [B,2,sH,sW]."""
+    if operand_round is not None:
+        with operand_rounding(operand_round):
+            return bptt_loss(p, inp_windows, gt_windows, n_c, scale, plain)
     B, _, _, H, W = inp_windows[0].shape
     z = lambda c: torch.zeros(B, c, H, W, dtype=inp_windows[0].dtype)
     h, hp, hn, pred = z(n_c), z(n_c), z(n_c), z(2 * scale * scale)
@@ -463,6 +566,29 @@ def bptt_loss(p: Params, inp_windows: Sequence[torch.Tensor], gt_windows: Sequen
             sp = bicubic_resize(pred, gt.shape[-2:])
         loss = loss + F.mse_loss(sp, gt)
     return loss, preds, (h, hp, hn)
+
+
+@torch.no_grad()
+def infer_windows(p: Params, frames: torch.Tensor, gts: torch.Tensor, n_c: int, scale: int = 4, seqn: int = 3, gt_size=None):
+    """The body of the reference's inference loop -- infer_BMCNet.py:44-86: windows of `seqn` frames (default SEQN = 3,
+    :147; only frames 0 and 1 of a window are read by the model, models/BMCNet.py:106-107), zero state before the first
+    window (:55-60), (h, hp, hn, prediction) carried (:62-63); per window the metrics esr_mse = MSE(prediction resized to
+    the ground truth's size when they differ, gt) (:76-78,84) and the baseline bicubic_mse =
+    MSE(bicubic(inp_cnt[:, 1] -> gt_sensor_resolution), gt) (:79,85).  frames [B,L,2,H,W], gts [B,L,2,gh,gw].
+    -> list of (prediction, esr_mse, bicubic_mse) per window."""
+    B, L, _, H, W = frames.shape
+    gt_size = tuple(gts.shape[-2:]) if gt_size is None else tuple(gt_size)
+    z = lambda c: torch.zeros(B, c, H, W, dtype=frames.dtype)
+    h, hp, hn, pred = z(n_c), z(n_c), z(n_c), z(2 * scale * scale)
+    out = []
+    for i in range(L - seqn + 1):
+        x = frames[:, i:i + seqn].transpose(1, 2)
+        gt = gts[:, i + 1]
+        h, hp, hn, pred = bmcnet_forward(p, x, h, hp, hn, pred, i == 0, scale)
+        esr = pred if tuple(pred.shape[-2:]) == tuple(gt.shape[-2:]) else bicubic_resize(pred, gt.shape[-2:])
+        base = bicubic_resize(frames[:, i + 1], gt_size)
+        out.append((pred, F.mse_loss(esr, gt), F.mse_loss(base, gt)))
+    return out
 
 
 def adam_amsgrad_step(params, grads, state, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5):

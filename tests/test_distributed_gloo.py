@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -207,3 +208,151 @@ def test_two_rank_gradient_accumulation_is_reduced_once():
     for r in range(2):
         for a, b in zip(res[r][1], ref):
             assert np.allclose(a, b, rtol=2e-4, atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The sink route (bmc_hip.ops.sink_group): the HIP kernels add weight gradients straight into .grad and hand autograd
+# None, so no post-accumulate hook fires for those parameters.  Emulated here on CPU with a Function that follows the
+# same protocol, including a parameter that takes BOTH routes in one backward (nothing enforces that no
+# parameter does).
+class SinkMatmul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        ctx.param = w
+        return x @ w
+
+    @staticmethod
+    def backward(ctx, g):
+        from bmc_hip import ops
+        x, w = ctx.saved_tensors
+        gw = x.t() @ g
+        sg = ops.sink_group([ctx.param])
+        if sg is None:
+            return g @ w.t(), gw
+        (dst,), acc = sg
+        dst.add_(gw) if acc else dst.copy_(gw)
+        return g @ w.t(), None
+
+
+class SinkNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(11)
+        self.a = torch.nn.Parameter(torch.randn(8, 8, generator=g) * 0.3)       # sink route, shared by three uses
+        self.b = torch.nn.Parameter(torch.randn(8, generator=g) * 0.1)          # autograd route
+        self.mixed = torch.nn.Parameter(torch.randn(8, 8, generator=g) * 0.3)   # sink route early, autograd route late
+        self.c = torch.nn.Parameter(torch.randn(8, 4, generator=g) * 0.3)       # sink route
+
+    def forward(self, x, sink=True):
+        mm = SinkMatmul.apply if sink else torch.matmul
+        h = mm(x, self.mixed)
+        for _ in range(3):
+            h = torch.tanh(mm(h, self.a) + self.b)
+        h = h @ self.mixed                    # the late autograd use: its AccumulateGrad runs BEFORE the early sink add
+        return mm(h, self.c)
+
+
+def _sink_worker(rank, world, port, q, accum):
+    sys.path.insert(0, os.path.join(ROOT, "bmcnet-esr_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bmc_hip import ops
+    from bmc_hip.parallel import GradAllReducer
+    ops.set_accumulate_param_grads(accum)
+    net = SinkNet()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2, weight_decay=1e-5, amsgrad=True)
+    red = GradAllReducer(net, opt, bucket_mb=1e-4)          # one parameter per bucket: hooks launch whatever they complete
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(8, 8, generator=g); y = torch.randn(8, 4, generator=g)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    for _ in range(3):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(net(xs), ys).backward()
+        opt.step()
+    # one more step with .grad left aliasing the buckets (set_to_none=False): legal -- a Function that sinks into a
+    # parameter has it as an input, so autograd runs the parameter's AccumulateGrad (and our hook) only after that
+    # Function's backward: a hook never fires before a sink add of the same backward
+    opt.zero_grad(set_to_none=False)
+    torch.nn.functional.mse_loss(net(xs), ys).backward()
+    opt.step()
+    q.put((rank, [p.detach().numpy().copy() for p in net.parameters()]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("accum", [True, False])
+def test_two_rank_sink_route_and_mixed_route_parameters(accum):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sink_worker, args=(r, 2, port, q, accum)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    net = SinkNet()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2, weight_decay=1e-5, amsgrad=True)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(8, 8, generator=g); y = torch.randn(8, 4, generator=g)
+    for _ in range(4):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(net(x, sink=False), y).backward()        # full batch, plain autograd
+        opt.step()
+    ref = [p.detach().numpy() for p in net.parameters()]
+    for r in range(2):
+        for a, b in zip(res[r][1], ref):
+            assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b)
+
+
+def test_reducer_refuses_a_sink_add_behind_a_launched_aliased_bucket():
+    """The one order the reducer cannot repair (and that no Function of this repo can produce, see above): a bucket that its
+    hooks completed and launched, then a kernel adding into a .grad that IS the bucket.  finish() must raise, not average
+    garbage.  Driven by hand in one process with a pretended world size."""
+    sys.path.insert(0, os.path.join(ROOT, "bmcnet-esr_amd"))
+    from bmc_hip import ops
+    from bmc_hip.parallel import GradAllReducer
+    ops.set_accumulate_param_grads(True)
+    net = SinkNet()
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    red = GradAllReducer(net, opt, bucket_mb=1e-4)
+    red.world = 2
+    x = torch.randn(4, 8)
+    net(x).sum().backward()
+    opt.step()                                   # .grad are views of the buckets from here on
+    opt.zero_grad(set_to_none=False)
+    p = net.c
+    assert p.grad.data_ptr() == red.flat[red.slot[p][0]][red.slot[p][1]:].data_ptr()
+    red._on_grad(p)                              # "autograd finished this parameter": its bucket is complete and launched
+    assert red.pending[red.slot[p][0]] == 0
+    (dst,), acc = ops.sink_group([p])            # ... and then a kernel adds into it
+    dst.add_(1.0)
+    with pytest.raises(RuntimeError, match="aliases the reduction bucket"):
+        red.finish()
+
+
+def test_hooked_parameters_keep_the_autograd_route():
+    """bmc_hip.ops.is_sink: a parameter with somebody else's tensor hook or post-accumulate hook must get its gradient
+    through autograd (the hook would never fire otherwise); the reducer's own hooks do not count."""
+    sys.path.insert(0, os.path.join(ROOT, "bmcnet-esr_amd"))
+    from bmc_hip import ops
+    from bmc_hip.parallel import GradAllReducer
+    ops.set_accumulate_param_grads(True)
+    net = SinkNet()
+    assert ops.is_sink(net.a) and ops.is_sink(net.c)
+    fired = []
+    net.c.register_post_accumulate_grad_hook(lambda p: fired.append("post"))
+    net.a.register_hook(lambda g: fired.append("tensor") or g)
+    assert not ops.is_sink(net.c) and not ops.is_sink(net.a)
+    net(torch.randn(4, 8)).sum().backward()
+    assert "post" in fired and "tensor" in fired and net.c.grad is not None
+    net2 = SinkNet()
+    GradAllReducer(net2)
+    assert all(ops.is_sink(p) for p in net2.parameters())
+    ops.set_accumulate_param_grads(False)
+    assert not ops.is_sink(net2.a)
+    ops.set_accumulate_param_grads(True)

@@ -148,3 +148,18 @@ def test_pretrained_weight_arrays_reproduce_reference_outputs():
         for i in range(2):
             h, pred = O.plain_forward(params, frames[:, i:i + 2].transpose(1, 2), h, pred, i == 0)
             assert rel(pred, z["pred%d" % i]) < 2e-6
+
+
+# ------------------------------------------------------------------ round 3: the inference loop (SEQN = 3, both metrics)
+def test_inference_loop_seqn3_golden():
+    """infer_seqn3.npz = the reference's model class driven by the body of infer_BMCNet.py:44-86 (make_golden_r3.py)."""
+    z = np.load(os.path.join(GOLDEN, "infer_seqn3.npz"))
+    scale, n_c, n_b, B, H, W, seqn, nwin, gh, gw = (int(v) for v in z["meta"])
+    params = {k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("sd/")}
+    res = O.infer_windows(params, torch.tensor(z["frames"]), torch.tensor(z["gts"]), n_c, scale, seqn)
+    assert len(res) == nwin
+    for i, (pred, esr, base) in enumerate(res):
+        ref = torch.tensor(z["pred%d" % i])
+        assert float((pred - ref).norm() / ref.norm()) < 2e-6
+        assert abs(float(esr) - float(z["esr_mse%d" % i])) < 2e-6 * float(z["esr_mse%d" % i])
+        assert abs(float(base) - float(z["bicubic_mse%d" % i])) < 2e-6 * float(z["bicubic_mse%d" % i])
