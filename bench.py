@@ -11,6 +11,13 @@ one backward through all windows, gradient all-reduce (N > 1), Adam(amsgrad) ste
 BASELINE.json configs[1] per GPU (BMCNet x4, 180x240 -> 720x960, bs=4/GPU, fp32, SEQL=9, SEQN=2) -> weak scaling;
 configs[2] (bs=32 over 8 GPUs) is exactly the N=8 point.  Inputs (events) are resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line.
+
+At N = 1 the same line also carries `extra` blocks measured after the headline run (`--also config3,config4,infer`,
+the default; `--also none` skips them): BASELINE configs[3] (EventZoom 31x56, its own bf16 arithmetic, and fp32 beside it),
+the reference's literal NFS LR shape (45x80, bs 2: config/train_nfs.yml:71), configs[4]'s per-GPU shape (RGB 180x190, T = 16
+windows, 8 sequences, per-window recompute) and the streaming-inference latency per window (infer_BMCNet.py:44-68)
+with and without HIP-graph replay.  They are short (a few steps each), labelled with their own workload strings, and
+never enter `value`.
 """
 import argparse
 import json
@@ -28,22 +35,57 @@ import torch.distributed as dist
 
 # algorithmic work (measured on the reference with torch.utils.flop_counter, 2 FLOP/MAC)
 FLOP_PER_LRPX_FWD_BWD = 118_121_472      # BMCNet(4,128,5) one window forward+backward
+FLOP_PER_LRPX_FWD = 41_574_912           # ... forward only (inference)
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.6           # 16 x the fp32 rate (v_mfma_f32_32x32x16_bf16, dense, 2.4 GHz)
 # peak of the dominant kernel per arithmetic mode, in algorithmic (fp32-equivalent) FLOP/s: the bf16x6 split spends six
 # bf16 MFMAs per algorithmic product
 KERNEL_PEAK = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16": PEAK_BF16_MFMA_TFLOPS}
 KERNEL_NAME = {"fp32": "conv_kernel<9,128>", "bf16x6": "conv_bf_kernel<9,128,8,3>", "bf16": "conv_bf_kernel<9,128,8,1>"}
+PMC_KERNEL = {"fp32": "conv_kernel<9,128,8>", "bf16x6": "conv_bf_kernel<9,128,8,3>", "bf16": "conv_bf_kernel<9,128,8,1>"}
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+DTYPE = {"fp32": "f32", "bf16x6": "f32 (3xbf16 split, 6 products)", "bf16": "bf16"}
+ARITH = {"fp32": "fp32 (native fp32 MFMA)", "bf16x6": "fp32-equivalent (3 bf16 planes, 6 products, fp32 accumulate)",
+         "bf16": "bf16 operands, fp32 accumulate and storage"}
+SHAPES = {(180, 240): "NFS-shaped 180x240 (BASELINE configs[1] / [2])", (31, 56): "EventZoom 31x56 (BASELINE configs[3] shape)",
+          (180, 190): "RGB 180x190 (BASELINE configs[4] per-GPU shape)", (45, 80): "NFS 45x80 (the reference's own LR size, config/train_nfs.yml)"}
 
 
-def cpu_baseline(budget_hw=(180, 240), threads=16):
-    """CPU oracle (the PyTorch-CPU restatement of the reference path, oracle/bmc_oracle.py) timed on this host:
-    one BMCNet window forward+backward, B=1, on a bounded sample (one 180x240 LR frame), in frames per second.
-    16 threads is the measured optimum of torch-CPU on the GPU box's 256-thread host for this network (8: 1.08 s,
-    16: 0.67 s, 32: 1.08 s, 64: 2.3 s, 128: 8.6 s per quarter frame).  Reported only; never the thing optimised."""
+def shape_name(H, W):
+    return SHAPES.get((H, W), "synthetic %dx%d" % (H, W))
+
+
+def host_info():
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        txt = open("/proc/cpuinfo").read()
+        models = [l.split(":", 1)[1].strip() for l in txt.splitlines() if l.startswith("model name")]
+        cores = {(a, b) for a, b in zip([l.split(":")[1].strip() for l in txt.splitlines() if l.startswith("physical id")],
+                                         [l.split(":")[1].strip() for l in txt.splitlines() if l.startswith("core id")])}
+        info["cpu_model"] = models[0] if models else None
+        info["physical_cores"] = len(cores) or None
+    except OSError:
+        pass
+    return info
+
+
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def cpu_baseline(dev=None, budget_hw=(180, 240), threads=16):
+    """CPU oracle (the PyTorch-CPU restatement of the reference path, oracle/bmc_oracle.py) timed on this host, the protocol
+    of SURVEY 8(d) / BASELINE.md 4: 2 warm-up + 3 timed iterations, median, thread and core counts stated.
+      (ii) one BMCNet window forward+backward, B=1, one 180x240 LR frame -> the headline `value` in frames per second;
+      (i)  events_to_channels on one 180x240 LR frame (24 576 events) and one 720x960 HR frame (393 216 events), numpy
+           restatement, one thread -- with the GPU scatter kernel's time for the same frames beside it.
+    16 threads is the measured optimum of torch-CPU on the GPU box's host for this network (8: 1.08 s, 16: 0.67 s, 32: 1.08 s,
+    64: 2.3 s, 128: 8.6 s per quarter frame).  Reported only; never the thing optimised."""
+    import numpy as np
+    import torch.nn.functional as F
     from models.BMCNet import BMCNet
     from oracle import bmc_oracle as O
-    import torch.nn.functional as F
     torch.manual_seed(3407)
     torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
     scale, n_c, n_b = 4, 128, 5
@@ -56,7 +98,7 @@ def cpu_baseline(budget_hw=(180, 240), threads=16):
     gt = torch.poisson(torch.full((1, 2, scale * H, scale * W), 0.284))
     z = lambda c: torch.zeros(1, c, H, W)
     times = []
-    for it in range(3):
+    for it in range(5):
         t0 = time.perf_counter()
         _, _, _, pred = O.bmcnet_forward(params, x, z(n_c), z(n_c), z(n_c), z(32), True, scale)
         loss = F.mse_loss(pred, gt)
@@ -64,15 +106,43 @@ def cpu_baseline(budget_hw=(180, 240), threads=16):
         times.append(time.perf_counter() - t0)
         for p in seen.values():
             p.grad = None
-    t = min(times[1:])
+    t = _median(times[2:])
     frames = (H * W) / (180.0 * 240.0)
+    # (i) the event -> count scatter
+    rng = np.random.default_rng(3407)
+    ev = {}
+    for tag, (h, w, n) in {"180x240": (180, 240, 24576), "720x960": (720, 960, 393216)}.items():
+        xs, ys = rng.integers(0, w, n).astype(np.float32), rng.integers(0, h, n).astype(np.float32)
+        ps = rng.choice([-1.0, 1.0], n).astype(np.float32)
+        ts = []
+        for it in range(5):
+            t0 = time.perf_counter()
+            O.events_to_channels_np(xs, ys, ps, (h, w))
+            ts.append(time.perf_counter() - t0)
+        ev[tag] = {"events": n, "cpu_ms": round(_median(ts[2:]) * 1e3, 3)}
+        if dev is not None:
+            from bmc_hip import ops
+            d = [torch.tensor(a, device=dev) for a in (xs, ys, ps)]
+            off = torch.tensor([0, n], dtype=torch.int64, device=dev)
+            for _ in range(3):
+                ops.events_to_channels_batched(*d, off, h, w, mutate=False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.events_to_channels_batched(*d, off, h, w, mutate=False)
+            e1.record()
+            torch.cuda.synchronize()
+            ev[tag]["gpu_ms_one_frame_launch"] = round(e0.elapsed_time(e1) / 20, 4)
     return {"value": round(frames / t, 5), "unit": "LR-voxel-frames/s", "cores": torch.get_num_threads(),
-            "kind": "port",
+            "kind": "port", "host": host_info(),
             "sample": "oracle/bmc_oracle.py BMCNet(4,128,5) 1 window fwd+bwd, B=1, LR %dx%d (%.2f of a 180x240 frame), "
-                      "1 warm-up + 2 timed (best), %.2fs each, scaled by pixel count" % (H, W, frames, t)}
+                      "2 warm-up + 3 timed (median %.2fs; all five: %s), %d torch threads" %
+                      (H, W, frames, t, " ".join("%.2f" % v for v in times), torch.get_num_threads()),
+            "events_to_channels": dict(ev, note="numpy restatement (oracle.events_to_channels_np), 1 thread, 2 warm-up + 3 timed "
+                                                "(median); gpu = bmc_events_to_channels, ONE frame per launch (the step batches 36 frames per launch)")}
 
 
-def dominant_kernel_roofline(step_fn, iso, math="fp32"):
+def dominant_kernel_roofline(step_fn, iso, math, shape_key):
     """roofline block for the dominant kernel, conv_kernel<9,128> (3x3 implicit GEMM: forward + data gradients,
     ~59 % of the step's algorithmic FLOPs).  One extra, untimed step runs with an event pair around every launch of
     that kernel on its launch stream (torch's current stream); achieved = sum of the launches' algorithmic FLOPs /
@@ -88,26 +158,27 @@ def dominant_kernel_roofline(step_fn, iso, math="fp32"):
         a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1)
     n, fl, ms = agg["conv_kernel<9,128>"]
     ach = fl / (ms * 1e-3) / 1e12
-    # HBM bytes per launch: from the committed rocprofv3 PMC passes over one bench step (profiles/r02_pmc_summary.json:
-    # the AVERAGE in-step launch of this kernel, FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes;
-    # tools/pmc_summary.py) -- never computed here
+    # HBM bytes per launch: from the committed rocprofv3 PMC passes over one bench step (the AVERAGE in-step launch of this
+    # kernel, FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py) -- never computed
+    # here, and attached ONLY when the summary was collected on this very workload (its `_workload` record): the bytes of an
+    # average launch depend on the frame size and the batch
     traffic, pmc = None, None
-    tj = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-    if os.path.exists(tj):
-        entry = json.load(open(tj)).get(math, {}).get({"fp32": "conv_kernel<9,128,8>", "bf16x6": "conv_bf_kernel<9,128,8,3>",
-                                                         "bf16": "conv_bf_kernel<9,128,8,1>"}[math])
-        if entry:
-            traffic = entry.get("hbm_bytes_per_launch")
-            pmc = {k: entry[k] for k in ("mfma_busy_frac", "in_kernel_clock_GHz", "hbm_GBps") if k in entry}
+    if os.path.exists(PMC_FILE):
+        summ = json.load(open(PMC_FILE))
+        if summ.get("_workload") == shape_key:
+            entry = summ.get(math, {}).get(PMC_KERNEL[math])
+            if entry:
+                traffic = entry.get("hbm_bytes_per_launch")
+                pmc = {k: entry[k] for k in ("mfma_busy_frac", "in_kernel_clock_GHz", "hbm_GBps", "lds_bank_conflict_frac") if k in entry}
+                pmc["source"] = "profiles/" + os.path.basename(PMC_FILE)
     peak = KERNEL_PEAK[math]
-    out = {"bound": "mfma", "kernel": "%s (3x3 implicit GEMM fwd + dgrad, all %d launches of one step)" % (KERNEL_NAME[math], n),
-           "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-           "frac": round(ach / peak, 4), "traffic": traffic,
-           "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n, "launches_per_step": n,
-           "isolated_2B_128to128": iso, "pmc": pmc,
-           "other_kernels": {k: {"launches": v[0], "achieved_tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2),
-                                 "avg_launch_ms": round(v[2] / v[0], 4)} for k, v in agg.items() if k != "conv_kernel<9,128>"}}
-    return out
+    return {"bound": "mfma", "kernel": "%s (3x3 implicit GEMM fwd + dgrad, all %d launches of one step)" % (KERNEL_NAME[math], n),
+            "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": traffic,
+            "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n, "launches_per_step": n,
+            "isolated_2B_128to128": iso, "pmc": pmc,
+            "other_kernels": {k: {"launches": v[0], "achieved_tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2),
+                                  "avg_launch_ms": round(v[2] / v[0], 4)} for k, v in agg.items() if k != "conv_kernel<9,128>"}}
 
 
 def isolated_conv(dev, B, H, W, n_c, iters=30):
@@ -133,6 +204,137 @@ def isolated_conv(dev, B, H, W, n_c, iters=30):
     return {"avg_launch_ms": round(ms, 4), "achieved_tflops": round(flops / (ms * 1e-3) / 1e12, 2)}
 
 
+def workload_string(n_c, n_b, H, W, B, L, math, scale=4, dist_on=False, recompute=False, graph=False):
+    return ("BMCNet(scale=%d, n_c=%d, n_b=%d) x%d SR train step, %s -> %dx%d, bs=%d/GPU, arithmetic %s, SEQL=%d SEQN=2 (%d windows "
+            "BPTT), event scatter + fwd + MSE + bwd + Adam(amsgrad)%s%s%s" %
+            (scale, n_c, n_b, scale, shape_name(H, W), scale * H, scale * W, B, ARITH[math], L, L - 1,
+             " + RCCL grad all-reduce" if dist_on else "", " [per-window recompute]" if recompute else "",
+             " [HIP graph replay]" if graph else ""))
+
+
+class Workload:
+    """One training-step workload on this rank's GPU: model, optimizer, resident synthetic events, the step closure."""
+
+    def __init__(self, dev, B, H, W, L, n_c, n_b, math, recompute=False, graph=False, use_dist=False, rank=0, scale=4):
+        from models.BMCNet import BMCNet
+        from bmc_hip import ops
+        from bmc_hip.parallel import GradAllReducer
+        from train_step import bptt_step, encode_sequence, synthetic_events
+        self.dev, self.B, self.H, self.W, self.L, self.n_c, self.n_b, self.math = dev, B, H, W, L, n_c, n_b, math
+        self.scale, self.recompute, self.graph_mode = scale, recompute, graph
+        ops.set_math(math)
+        torch.manual_seed(3407)                                   # same init on every rank (reference default seed)
+        self.model = BMCNet(scale, n_c, n_b).to(dev)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-4, weight_decay=1e-5, amsgrad=True,    # config/train_nfs.yml:28-34
+                                    capturable=graph)
+        self.reducer = GradAllReducer(self.model, self.opt) if use_dist else None
+        # event density of the reference NFS config (0.569 ev/px/frame), EventZoom / RGB windows likewise rounded to 1024
+        n_lr = int(round(0.5689 * H * W / 1024)) * 1024 if (H, W) != (180, 240) else 24576
+        self.ev = synthetic_events(B, L, H, W, scale, max(n_lr, 1024), dev, seed=3407 + rank)
+
+        def step():
+            inp, gt = encode_sequence(self.ev, B, L, H, W, scale)
+            return bptt_step(self.model, self.opt, inp, gt, n_c, scale, recompute=recompute)
+
+        self.eager_step = self.step = step
+        if graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):            # PyTorch's capture protocol: warm up on a side stream first
+                for _ in range(2):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.opt.zero_grad(set_to_none=True)
+            torch.cuda.empty_cache()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._g_out = self.eager_step()
+
+            def replay():
+                self._graph.replay()
+                return self._g_out
+
+            self.step = replay
+
+    def step_flops(self):
+        if (self.n_c, self.n_b, self.scale) != (128, 5, 4):
+            return None
+        return FLOP_PER_LRPX_FWD_BWD * self.H * self.W * self.B * (self.L - 1)
+
+    def shape_key(self):
+        return {"H": self.H, "W": self.W, "B": self.B, "L": self.L, "n_c": self.n_c, "n_b": self.n_b}
+
+
+def timed(fn, warmup, steps, use_dist, dev):
+    """W untimed + exactly K timed steps between barrier + synchronize pairs; max over ranks."""
+    loss = None
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = fn()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    return dt, loss
+
+
+def extra_train(dev, tag, B, H, W, L, math, steps, warmup, recompute=False, graph=False):
+    """A short side measurement of another BASELINE configuration on this GPU: same step code, its own shape and arithmetic."""
+    from bmc_hip import ops
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    wl = Workload(dev, B, H, W, L, 128, 5, math, recompute=recompute, graph=graph)
+    dt, loss = timed(wl.step, warmup, steps, False, dev)
+    out = {"workload": workload_string(128, 5, H, W, B, L, math, recompute=recompute, graph=graph), "dtype": DTYPE[math],
+           "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
+           "value": round(B * (L - 1) * steps / dt, 2), "unit": "LR-voxel-frames/s",
+           "step_achieved_tflops": round(wl.step_flops() * steps / dt / 1e12, 2),
+           "step_frac_of_peak": round(wl.step_flops() * steps / dt / 1e12 / KERNEL_PEAK[math], 4),
+           "peak_of": "%.1f TFLOP/s (%s MFMA, dense)" % (KERNEL_PEAK[math], "bf16" if math == "bf16" else "fp32" if math == "fp32" else "bf16 / 6"),
+           "peak_mem_GiB": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1), "final_loss": round(float(loss), 6)}
+    del wl
+    ops.set_math("fp32")
+    torch.cuda.empty_cache()
+    return out
+
+
+def extra_infer(dev, windows=24):
+    """Streaming inference (infer_BMCNet.py:44-68): per-window latency of BMCNet(4,128,5), batch 1, fp32, events on the launch
+    stream around the model call exactly where the reference puts its starter / ender pair; eager and HIP-graph replay."""
+    from infer import StreamingSR
+    from models.BMCNet import BMCNet
+    torch.manual_seed(0)
+    m = BMCNet(4, 128, 5).to(dev)
+    out = {"workload": "BMCNet(4,128,5) streaming x4 SR inference, batch 1, fp32, SEQN=3 inputs (infer_BMCNet.py:147), per recurrent "
+                       "window; mean over %d windows after 6 warm-up windows" % (windows - 6), "unit": "ms/window"}
+    for H, W in ((45, 80), (180, 240)):
+        frames = torch.poisson(torch.full((1, windows + 2, 2, H, W), 0.284)).to(dev)
+        rec = {}
+        for graph in (False, True):
+            sr = StreamingSR(m, 128, 4, graph=graph)
+            for i in range(windows):
+                sr.step(frames[:, i:i + 3].transpose(1, 2))
+            ms = sr.latency_ms(skip=6)
+            rec["graph_replay" if graph else "eager"] = round(ms, 3)
+        rec["frac_of_fp32_mfma_peak_graph"] = round(FLOP_PER_LRPX_FWD * H * W / (rec["graph_replay"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+        out["%dx%d->%dx%d" % (H, W, 4 * H, 4 * W)] = rec
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +352,8 @@ def main():
     ap.add_argument("--math", default=os.environ.get("BMC_MATH", "fp32"), choices=["fp32", "bf16x6", "bf16"],
                     help="arithmetic of the MFMA kernels for the headline measurement (default fp32 = native fp32 MFMA)")
     ap.add_argument("--no-bf16x6", action="store_true", help="skip the additional bf16x6-mode measurement")
+    ap.add_argument("--also", default="config3,config4,infer",
+                    help="comma list of extra blocks appended to the JSON line at --gpus 1 (config3, config4, infer; 'none' = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -184,102 +388,45 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus or os.environ.get("BMC_FORCE_DIST")
+    if args.graph and use_dist:
+        raise SystemExit("--graph is single-GPU only")
 
-    from models.BMCNet import BMCNet
     from bmc_hip import ops
-    from bmc_hip.parallel import GradAllReducer
-    from train_step import bptt_step, encode_sequence, synthetic_events
-    ops.set_math(args.math)
-
-    scale, n_c, n_b = 4, args.n_c, args.n_b
+    n_c, n_b = args.n_c, args.n_b
     B, H, W, L = args.batch, args.height, args.width, args.seql
-    torch.manual_seed(3407)                                   # same init on every rank (reference default seed)
-    model = BMCNet(scale, n_c, n_b).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5, amsgrad=True,    # config/train_nfs.yml:28-34
-                           capturable=args.graph)
-    reducer = GradAllReducer(model, opt) if use_dist else None
-    n_lr = int(round(0.5689 * H * W / 1024)) * 1024 if (H, W) != (180, 240) else 24576
-    ev = synthetic_events(B, L, H, W, scale, n_lr, dev, seed=3407 + rank)
+    wl = Workload(dev, B, H, W, L, n_c, n_b, args.math, recompute=args.recompute, graph=args.graph, use_dist=use_dist, rank=rank)
 
-    def step():
-        inp, gt = encode_sequence(ev, B, L, H, W, scale)
-        return bptt_step(model, opt, inp, gt, n_c, scale, recompute=args.recompute)
-
-    eager_step = step
-    if args.graph:
-        if use_dist:
-            raise SystemExit("--graph is single-GPU only")
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):            # PyTorch's capture protocol: warm up on a side stream first
-            for _ in range(2):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        opt.zero_grad(set_to_none=True)
-        torch.cuda.empty_cache()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            g_loss, g_mse = eager_step()
-
-        def step():
-            graph.replay()
-            return g_loss, g_mse
-    def timed(fn, warmup, steps):
-        """W untimed + exactly K timed steps between barrier + synchronize pairs; max over ranks."""
-        loss = None
-        for _ in range(warmup):
-            fn()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss, _ = fn()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = t.item()
-        return dt, loss
-
-    dt, loss = timed(step, args.warmup, args.steps)
+    dt, loss = timed(wl.step, args.warmup, args.steps, use_dist, dev)
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2**30
 
     # the instrumented extra step contains the gradient all-reduce: every rank has to take part in it
     iso = isolated_conv(dev, B, H, W, n_c) if rank == 0 else None
-    roof = dominant_kernel_roofline(eager_step, iso, args.math)
+    roof = dominant_kernel_roofline(wl.eager_step, iso, args.math, wl.shape_key())
     # second arithmetic mode of the same step (every rank takes part): the fp32-equivalent bf16x6 split -- reported
     # beside the headline number, never as it
     split = None
     if args.math == "fp32" and not args.no_bf16x6 and not args.graph:
         ops.set_math("bf16x6")
-        dt6, loss6 = timed(eager_step, 1, args.steps)
-        roof6 = dominant_kernel_roofline(eager_step, None, "bf16x6")
+        dt6, loss6 = timed(wl.eager_step, 1, args.steps, use_dist, dev)
+        roof6 = dominant_kernel_roofline(wl.eager_step, None, "bf16x6", wl.shape_key())
         ops.set_math("fp32")
         split = (dt6, float(loss6), roof6)
+    step_flops = wl.step_flops()
+    del wl
+    torch.cuda.empty_cache()
     if rank == 0:
         windows = L - 1
         frames_per_step = world * B * windows
         value = frames_per_step * args.steps / dt
-        step_flops = FLOP_PER_LRPX_FWD_BWD * H * W * B * windows if (n_c, n_b) == (128, 5) else None
         if step_flops:
             roof["step_achieved_tflops_per_gpu"] = round(step_flops * args.steps / dt / 1e12, 2)
             roof["step_frac_of_peak"] = round(step_flops * args.steps / dt / 1e12 / KERNEL_PEAK[args.math], 4)
         out = {
-            "metric": "LR-voxel-frames/sec x4 SR train step, %s %dx%d" % ("NFS" if (H, W) == (180, 240) else "synthetic", H, W),
+            "metric": "LR-voxel-frames/sec x4 SR train step, %s, %s" % (shape_name(H, W), DTYPE[args.math]),
             "value": round(value, 3), "unit": "LR-voxel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x6": "f32 (3xbf16 split, 6 products)", "bf16": "bf16"}[args.math], "data": "synthetic",
-            "config": {"workload": "BMCNet(scale=4, n_c=%d, n_b=%d) x4 NFS %dx%d->%dx%d, bs=%d/GPU fp32, SEQL=%d SEQN=2 (%d windows BPTT), "
-                                   "event scatter + fwd + MSE + bwd + Adam(amsgrad)%s%s" %
-                                   (n_c, n_b, H, W, scale * H, scale * W, B, L, windows, " + RCCL grad all-reduce" if use_dist else "",
-                                    " [per-window recompute]" if args.recompute else "") + (" [HIP graph replay]" if args.graph else ""),
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.math], "data": "synthetic",
+            "config": {"workload": workload_string(n_c, n_b, H, W, B, L, args.math, dist_on=use_dist, recompute=args.recompute, graph=args.graph),
                        "global_batch": world * B, "frames_per_step": frames_per_step,
                        "parallelism": "dp%d" % world, "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "peak_mem_GiB": round(peak_mem, 1),
@@ -300,8 +447,21 @@ def main():
                               "workload, same step, `--math bf16x6` makes it the headline run"}
             if step_flops:
                 out["bf16x6_mode"]["step_fp32_equivalent_tflops_per_gpu"] = round(step_flops * args.steps / dt6 / 1e12, 2)
+        also = [] if args.also in ("", "none") or world != 1 or use_dist else [a.strip() for a in args.also.split(",") if a.strip()]
+        if also and (H, W, B, L, n_c, n_b) == (180, 240, 4, 9, 128, 5) and not args.graph:
+            extra = {}
+            if "config3" in also:
+                extra["configs[3] EventZoom 31x56 bs4, bf16 (the config's arithmetic)"] = extra_train(dev, "c3", 4, 31, 56, 9, "bf16", 10, 4)
+                extra["configs[3] shape in fp32"] = extra_train(dev, "c3f", 4, 31, 56, 9, "fp32", 10, 4)
+                extra["reference NFS LR shape 45x80 bs2 (config/train_nfs.yml:71), fp32"] = extra_train(dev, "nfs", 2, 45, 80, 9, "fp32", 10, 4)
+            if "config4" in also:
+                extra["configs[4] per-GPU shape RGB 180x190 T=16 bs8, fp32, per-window recompute"] = \
+                    extra_train(dev, "c4", 8, 180, 190, 17, "fp32", 2, 1, recompute=True)
+            if "infer" in also:
+                extra["streaming inference latency"] = extra_infer(dev)
+            out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(dev)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -76,6 +76,9 @@ _stack_pol = _sig("bmc_events_to_stack_polarity", [_p, _p, _p, _p, _ll, _p, _p, 
 _mask = _sig("bmc_events_to_mask", [_p, _p, _p, _ll, _i, _i, _p, _p, _i, _p])
 _stack = _sig("bmc_events_to_stack", [_p, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p, _p, _i, _p])
 _enc_raw = _sig("bmc_encode_raw_events", [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p])
+_events_ws = _sig("bmc_events_binned_ws_bytes", [_ll, _i, _i, _i], C.c_longlong)
+_events_binned = _sig("bmc_events_to_channels_binned", [_p, _p, _p, _p, _ll, _i, _i, _i, _p, _i, _p, _ll, _p])
+_enc_raw_binned = _sig("bmc_encode_raw_events_binned", [_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p, _p, _ll, _p])
 _pack_w = _sig("bmc_pack_weight", [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p])
 _pack_wt = _sig("bmc_pack_weight_t", [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p])
 _split_w = _sig("bmc_split_weight", [_p, _p, _ll, _i, _i, _p])
@@ -108,7 +111,8 @@ EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_event
            "bmc_unshuffle_to_nhwc", "bmc_shuffle_to_hr", "bmc_bicubic_resize_fwd", "bmc_bicubic_resize_bwd",
            "bmc_chain_fwd", "bmc_chain_bwd", "bmc_chain_affine_grads", "bmc_group_sum",
            "bmc_head_mse_fwd", "bmc_head_mse_bwd", "bmc_events_to_stack_polarity", "bmc_events_to_mask",
-           "bmc_pgemm_reduce_weight_groups"]
+           "bmc_pgemm_reduce_weight_groups", "bmc_events_binned_ws_bytes", "bmc_events_to_channels_binned",
+           "bmc_encode_raw_events_binned"]
 
 
 def check(rc, what):

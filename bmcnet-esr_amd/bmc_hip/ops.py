@@ -1129,9 +1129,29 @@ def events_to_channels_batched(xs, ys, ps, offsets, H, W, mutate=True):
     _need_gpu(xs)
     nframes = offsets.numel() - 1
     out = torch.empty((nframes, 2, H, W), device=xs.device, dtype=torch.float32)
+    ws = _binned_ws(xs.numel(), nframes, H, W, xs.device)
+    if ws is not None:       # large frames: LDS-privatised count images, no scattered global float atomics (csrc/scatter.hip)
+        lib.call(lib._events_binned, "bmc_events_to_channels_binned", xs.data_ptr(), ys.data_ptr(), ps.data_ptr(),
+                 offsets.data_ptr(), xs.numel(), nframes, H, W, out.data_ptr(), int(mutate), ws.data_ptr(), ws.numel() * 8,
+                 _stream())
+        return out
     lib.call(lib._events, "bmc_events_to_channels", xs.data_ptr(), ys.data_ptr(), ps.data_ptr(), offsets.data_ptr(),
              nframes, H, W, out.data_ptr(), int(mutate), _stream())
     return out
+
+
+BINNED_MIN_PIXELS = int(os.environ.get("BMC_BINNED_MIN_PIXELS", 1 << 17))
+
+
+def _binned_ws(nevents, nframes, H, W, device):
+    """Workspace of the binned event encoders, or None where the plain atomic kernel is the better fit (small frames: a
+    count image that fits a few LDS bands anyway; the HR ground-truth frames of the step, 720x960, take the binned path)."""
+    if H * W < BINNED_MIN_PIXELS or nevents == 0 or nframes == 0 or W > 16384:
+        return None
+    nbytes = lib._events_ws(nevents, nframes, H, W)
+    if nbytes < 0:
+        return None
+    return torch.empty((nbytes + 7) // 8, device=device, dtype=torch.int64)
 
 
 def encode_raw_events(xs_i16, ys_i16, ps_f64, offsets, flips, H, W):
@@ -1147,6 +1167,11 @@ def encode_raw_events(xs_i16, ys_i16, ps_f64, offsets, flips, H, W):
         if flips.dtype != torch.uint8 or not flips.is_cuda or flips.numel() != nframes:
             raise RuntimeError("encode_raw_events: flips must be a uint8 GPU vector with one entry per frame")
         fp = flips.data_ptr()
+    ws = _binned_ws(xs_i16.numel(), nframes, H, W, xs_i16.device)
+    if ws is not None:
+        lib.call(lib._enc_raw_binned, "bmc_encode_raw_events_binned", xs_i16.data_ptr(), ys_i16.data_ptr(), ps_f64.data_ptr(),
+                 offsets.data_ptr(), fp, xs_i16.numel(), nframes, H, W, out.data_ptr(), ws.data_ptr(), ws.numel() * 8, _stream())
+        return out
     lib.call(lib._enc_raw, "bmc_encode_raw_events", xs_i16.data_ptr(), ys_i16.data_ptr(), ps_f64.data_ptr(),
              offsets.data_ptr(), fp, nframes, H, W, out.data_ptr(), _stream())
     return out

@@ -59,6 +59,173 @@ __global__ void encode_raw_kernel(const short* __restrict__ xs, const short* __r
     }
 }
 
+// ---- the same two encoders without scattered global float atomics (large frames) --------------------------------------
+// A 720x960 ground-truth frame holds ~0.4 M events on random pixels: every lane of a global_atomic_add_f32 hits its own
+// 64-byte segment, and MI355X executes float atomics at the memory side at ~0.08 TB/s in that shape
+// (MI355X_MICROARCH.md, Global float atomics): 0.68 ms for the 36 HR frames of a C2 step, 10x the time their bytes need.
+// Here the count image of a (frame, row band) is built in LDS by ONE workgroup (LDS float adds) and written out once with
+// coalesced stores (which is also the zero fill: no memset); events reach their band's workgroup through a counting
+// sort on the band index:
+//   count : a workgroup walks 4 096-event chunks of a frame, histograms their bands in LDS and adds the histogram to the
+//           frame's band counts (integer atomics, <= nbands per workgroup);
+//   scan  : exclusive prefix sum over the (frame, band) count table -> segment starts;
+//   place : the same walk again: per chunk a workgroup reserves its slots per band with one integer atomic each and drops
+//           8-byte records (plane pixel, weight) there; zero-weight events are dropped, out-of-range coordinates are
+//           reset in the caller's arrays if asked to;
+//   gather: one workgroup per (frame, band) adds its records into the LDS image and stores it.
+// Sums are order independent for the integer-valued weights p*p of +-1 polarities (exact below 2^24), as before.
+constexpr int BIN_LDS = 32768;          // floats of LDS image per workgroup (128 KB): 2 channels x R rows x W
+constexpr int BIN_CHUNK = 4096;         // events per chunk (256 threads x 16)
+constexpr int BIN_MAXBANDS = 1024;
+
+struct F32Events {       // events as event_formatting() leaves them (dataloader/base_dataset.py:24-31)
+    float* xs; float* ys; const float* ps; int mutate;
+    __device__ __forceinline__ void load(long long e, int, int, int, float& x, float& y, float& p) const { x = xs[e]; y = ys[e]; p = ps[e]; }
+    __device__ __forceinline__ void reset(long long e) const { if (mutate) { xs[e] = 0.f; ys[e] = 0.f; } }
+};
+struct RawEvents {       // raw dataset columns + flip flags (see encode_raw_kernel)
+    const short* xs; const short* ys; const double* ps; const unsigned char* flips;
+    __device__ __forceinline__ void load(long long e, int f, int H, int W, float& x, float& y, float& p) const {
+        const int fl = flips ? flips[f] : 0;
+        double xd = (double)xs[e], yd = (double)ys[e], pd = ps[e];
+        if (fl & 1) xd = (double)(W - 1) - xd;
+        if (fl & 2) yd = (double)(H - 1) - yd;
+        if (fl & 4) pd = pd * -1.0;
+        x = (float)xd; y = (float)yd; p = (float)pd;
+    }
+    __device__ __forceinline__ void reset(long long) const {}
+};
+// -> plane pixel (channel * H*W + row * W + column) and weight of the event's one contribution, or weight 0 (none):
+// positive events count in channel 0 unless out of range; negative ones in channel 1, out-of-range ones at [H-1, 0]
+__device__ __forceinline__ void event_record(float x, float y, float p, int H, int W, bool& oob, int& pix, float& wgt) {
+    oob = (x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f);
+    if (oob) { x = 0.f; y = 0.f; }
+    const int xi = (int)x, yi = H - (int)y - 1;
+    const bool neg = p < 0.f;
+    wgt = (neg || (!oob && p > 0.f)) ? p * p : 0.f;
+    pix = (neg ? H * W : 0) + yi * W + xi;
+}
+// PLACE = false: count pass (table += histogram).  PLACE = true: table holds the segment starts; records are written.
+template <typename EV, bool PLACE>
+__global__ __launch_bounds__(256) void bin_events_kernel(const EV ev, const long long* __restrict__ offsets, int H, int W, int R,
+                                                          int nbands, int* __restrict__ table, int* __restrict__ cursors,
+                                                          unsigned long long* __restrict__ records) {
+    __shared__ int hist[BIN_MAXBANDS];
+    __shared__ int base[BIN_MAXBANDS];
+    const int f = blockIdx.y;
+    const long long e0 = offsets[f], e1 = offsets[f + 1];
+    for (int i = threadIdx.x; i < nbands; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int HW = H * W;
+    for (long long c0 = e0 + (long long)blockIdx.x * BIN_CHUNK; c0 < e1; c0 += (long long)gridDim.x * BIN_CHUNK) {
+        int band[BIN_CHUNK / 256], rank[BIN_CHUNK / 256], pix[BIN_CHUNK / 256];
+        float wgt[BIN_CHUNK / 256];
+#pragma unroll
+        for (int k = 0; k < BIN_CHUNK / 256; ++k) {
+            const long long e = c0 + k * 256 + threadIdx.x;
+            band[k] = -1;
+            if (e < e1) {
+                float x, y, p;
+                ev.load(e, f, H, W, x, y, p);
+                bool oob;
+                event_record(x, y, p, H, W, oob, pix[k], wgt[k]);
+                if (PLACE && oob) ev.reset(e);
+                if (wgt[k] != 0.f) {
+                    const int q = pix[k] >= HW ? pix[k] - HW : pix[k];
+                    band[k] = (q / W) / R;
+                    rank[k] = atomicAdd(&hist[band[k]], 1);
+                }
+            }
+        }
+        if (!PLACE) continue;         // the count pass keeps adding to one histogram
+        __syncthreads();
+        for (int i = threadIdx.x; i < nbands; i += 256) {
+            const int h = hist[i];
+            base[i] = h ? atomicAdd(cursors + (long long)f * nbands + i, h) : 0;
+            hist[i] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BIN_CHUNK / 256; ++k)
+            if (band[k] >= 0) {
+                const long long slot = (long long)table[(long long)f * nbands + band[k]] + base[band[k]] + rank[k];
+                records[slot] = ((unsigned long long)__float_as_uint(wgt[k]) << 32) | (unsigned)pix[k];
+            }
+        // (the next chunk's LDS adds come after the barrier above; its reservation after the one at the loop's first barrier)
+    }
+    if (!PLACE) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nbands; i += 256)
+            if (hist[i]) atomicAdd(table + (long long)f * nbands + i, hist[i]);
+    }
+}
+// exclusive prefix sum of table[0 .. n) in place, table[n] = total; one workgroup (n is a few thousand at most)
+__global__ __launch_bounds__(1024) void bin_scan_kernel(int* __restrict__ table, int n) {
+    __shared__ int part[1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per < n ? threadIdx.x * per : n, hi = lo + per < n ? lo + per : n;
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += table[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        table[n] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { const int v = table[i]; table[i] = run; run += v; }
+}
+__global__ __launch_bounds__(1024) void bin_gather_kernel(const unsigned long long* __restrict__ records, const int* __restrict__ starts,
+                                                          int H, int W, int R, int nbands, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float img[BIN_LDS];
+    const int f = blockIdx.y, b = blockIdx.x;
+    const int r0 = b * R, rows = r0 + R <= H ? R : H - r0;
+    const int n1 = rows * W;                       // floats per channel in this band
+    for (int i = threadIdx.x; i < 2 * n1; i += 1024) img[i] = 0.f;
+    __syncthreads();
+    const int s0 = starts[(long long)f * nbands + b], s1 = starts[(long long)f * nbands + b + 1];   // (entry ntab = the total)
+    const int HW = H * W;
+    for (int i = s0 + threadIdx.x; i < s1; i += 1024) {
+        const unsigned long long rec = records[i];
+        const int pix = (int)(unsigned)rec;
+        const int ch = pix >= HW, q = pix - ch * HW - r0 * W;
+        atomicAdd(&img[ch * n1 + q], __uint_as_float((unsigned)(rec >> 32)));
+    }
+    __syncthreads();
+    float* const o = out + (long long)f * 2 * HW + (long long)r0 * W;
+    for (int ch = 0; ch < 2; ++ch)
+        for (int i = threadIdx.x; i < n1; i += 1024) o[(long long)ch * HW + i] = img[ch * n1 + i];
+}
+template <typename EV>
+int launch_binned(const EV& ev, const long long* offsets, long long nevents, int nframes, int H, int W, float* out, void* ws,
+                  long long ws_bytes, hipStream_t st, const char* name) {
+    const int R = BIN_LDS / 2 / W < H ? BIN_LDS / 2 / W : H, nbands = R > 0 ? (H + R - 1) / R : 0;
+    BMC_CHECK_ARG(R >= 1 && nbands <= BIN_MAXBANDS, "%s: frame %dx%d does not fit the LDS band scheme", name, H, W);
+    BMC_CHECK_ARG(nevents >= 0 && nevents < (1ll << 31) && (long long)H * W < (1ll << 30), "%s: too many events / pixels", name);
+    const long long ntab = (long long)nframes * nbands;
+    BMC_CHECK_ARG(ntab <= 1024 * 1024, "%s: too many (frame, band) pairs", name);
+    const long long head = ((2 * ntab + 1) * 4 + 7) / 8 * 8;
+    BMC_CHECK_ARG(ws && ws_bytes >= head + nevents * 8 && ((uintptr_t)ws & 7) == 0,
+                  "%s: workspace of %lld bytes needed (8-byte aligned)", name, head + nevents * 8);
+    int* const table = static_cast<int*>(ws);                       // [ntab + 1]: counts, then segment starts (+ total)
+    int* const cursors = table + ntab + 1;                          // [ntab]
+    unsigned long long* const records = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + head);
+    hipError_t e = hipMemsetAsync(table, 0, (size_t)(2 * ntab + 1) * 4, st);
+    if (e != hipSuccess) { bmc_set_error("%s: memset failed: %s", name, hipGetErrorString(e)); return -2; }
+    // workgroups per frame: enough chunks in flight for the longest frame the total allows, at most 128
+    long long per = (nevents + BIN_CHUNK - 1) / BIN_CHUNK;
+    if (per > 128) per = 128;
+    if (per < 1) per = 1;
+    const dim3 grid((unsigned)per, (unsigned)nframes);
+    hipLaunchKernelGGL((bin_events_kernel<EV, false>), grid, dim3(256), 0, st, ev, offsets, H, W, R, nbands, table, cursors, records);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, table, (int)ntab);
+    hipLaunchKernelGGL((bin_events_kernel<EV, true>), grid, dim3(256), 0, st, ev, offsets, H, W, R, nbands, table, cursors, records);
+    hipLaunchKernelGGL(bin_gather_kernel, dim3((unsigned)nbands, (unsigned)nframes), dim3(1024), 0, st, records, table, H, W, R, nbands, out);
+    return 0;
+}
+
 // Temporal-bilinear voxel grid (dataloader/encodings.py:272-287): bin b receives p * max(0, 1 - |t*(bins-1) - b|)
 // through events_to_image(), i.e. with the vertical flip and with the same side effect as above: the FIRST bin's call
 // zeroes out-of-range events and resets their coordinates in place, so in every later bin they are no longer masked
@@ -116,6 +283,49 @@ __global__ void voxel_fill_kernel(const float* __restrict__ xs, const float* __r
         bool oob;
         const int q = voxel_pixel(xs[e], ys[e], H, W, oob);
         idx[e0 + atomicAdd(u + q, 1)] = (int)(e - e0);
+    }
+}
+// Long segments (hot pixels, and pixel (H-1)*W, where EVERY out-of-range event of a frame lands) are put in event order
+// here, by the whole workgroup, before the per-pixel pass below: its single-thread insertion sort is O(k^2) moves on an
+// unsorted segment (50 k events ~ 1e9 dependent global accesses) but O(k) on a sorted one.  One workgroup per frame
+// collects the segments longer than VOX_LONG (up to 1 024 of them; any beyond that keep the slow path, still correct)
+// and sorts each with a bitonic network written for arbitrary lengths: every compare-exchange moves the larger key to the
+// higher index, so virtual +infinity padding above the segment's end never moves (out-of-range partners are skipped).
+constexpr int VOX_LONG = 32;
+__global__ __launch_bounds__(1024) void voxel_sort_long_kernel(const long long* __restrict__ offsets, int HW,
+                                                               const int* __restrict__ seg, int* __restrict__ idx) {
+    __shared__ int longq[1024];
+    __shared__ int nlong;
+    const int f = blockIdx.x;
+    const int* const sg = seg + (long long)f * (HW + 1);
+    int* const id = idx + offsets[f];
+    if (threadIdx.x == 0) nlong = 0;
+    __syncthreads();
+    for (int q = threadIdx.x; q < HW; q += 1024)
+        if (sg[q + 1] - sg[q] > VOX_LONG) {
+            const int s = atomicAdd(&nlong, 1);
+            if (s < 1024) longq[s] = q;
+        }
+    __syncthreads();
+    const int n = nlong < 1024 ? nlong : 1024;
+    for (int s = 0; s < n; ++s) {
+        const int a = sg[longq[s]], k = sg[longq[s] + 1] - a;
+        int* const v = id + a;
+        for (int size = 2; (size >> 1) < k; size <<= 1) {
+            // first step of a merge: partner = mirror image inside the block of `size`; then halving strides
+            for (int stride = size >> 1, first = 1; stride > 0; stride >>= 1, first = 0) {
+                for (int t = threadIdx.x; t < (k + 1) / 2 + stride; t += 1024) {      // t enumerates the lower partners
+                    const int blk = t / stride, off = t - blk * stride;
+                    const int i = blk * 2 * stride + off;
+                    const int j = first ? blk * 2 * stride + (2 * stride - 1 - off) : i + stride;
+                    if (i < k && j < k) {
+                        const int x = v[i], y = v[j];
+                        if (x > y) { v[i] = y; v[j] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
     }
 }
 __global__ void voxel_reduce_kernel(float* __restrict__ xs, float* __restrict__ ys, const float* __restrict__ ts,
@@ -296,6 +506,7 @@ extern "C" int bmc_events_to_voxel(float* xs, float* ys, const float* ts, const 
     hipLaunchKernelGGL(voxel_count_kernel, dim3(64, nframes), dim3(256), 0, st, xs, ys, offsets, H, W, seg);
     hipLaunchKernelGGL(voxel_scan_kernel, dim3(nframes), dim3(1024), 0, st, seg, cur, H * W);
     hipLaunchKernelGGL(voxel_fill_kernel, dim3(64, nframes), dim3(256), 0, st, xs, ys, offsets, H, W, cur, idx);
+    hipLaunchKernelGGL(voxel_sort_long_kernel, dim3(nframes), dim3(1024), 0, st, offsets, H * W, seg, idx);
     hipLaunchKernelGGL(voxel_reduce_kernel, dim3((H * W + 255) / 256, nframes), dim3(256), 0, st, xs, ys, ts, ps, offsets, bins,
                        H, W, seg, idx, out, mutate);
     BMC_CHECK_LAUNCH("bmc_events_to_voxel");
@@ -311,6 +522,37 @@ extern "C" int bmc_encode_raw_events(const short* xs, const short* ys, const dou
     if (e != hipSuccess) { bmc_set_error("bmc_encode_raw_events: memset failed: %s", hipGetErrorString(e)); return -2; }
     hipLaunchKernelGGL(encode_raw_kernel, dim3(64, nframes), dim3(256), 0, st, xs, ys, ps, offsets, flips, H, W, out);
     BMC_CHECK_LAUNCH("bmc_encode_raw_events");
+    return 0;
+}
+
+extern "C" long long bmc_events_binned_ws_bytes(long long nevents, int nframes, int H, int W) {
+    const int R = BIN_LDS / 2 / W < H ? BIN_LDS / 2 / W : H;
+    if (R < 1 || nframes < 0 || nevents < 0) return -1;
+    const long long ntab = (long long)nframes * ((H + R - 1) / R);
+    return ((2 * ntab + 1) * 4 + 7) / 8 * 8 + nevents * 8;
+}
+
+extern "C" int bmc_events_to_channels_binned(float* xs, float* ys, const float* ps, const long long* offsets, long long nevents,
+                                             int nframes, int H, int W, float* out, int mutate, void* ws, long long ws_bytes,
+                                             bmc_stream_t s) {
+    BMC_CHECK_ARG(nframes >= 0 && H > 0 && W > 0 && out, "bmc_events_to_channels_binned: bad shape");
+    if (nframes == 0) return 0;
+    F32Events ev{xs, ys, ps, mutate};
+    const int rc = launch_binned(ev, offsets, nevents, nframes, H, W, out, ws, ws_bytes, (hipStream_t)s, "bmc_events_to_channels_binned");
+    if (rc) return rc;
+    BMC_CHECK_LAUNCH("bmc_events_to_channels_binned");
+    return 0;
+}
+
+extern "C" int bmc_encode_raw_events_binned(const short* xs, const short* ys, const double* ps, const long long* offsets,
+                                            const unsigned char* flips, long long nevents, int nframes, int H, int W, float* out,
+                                            void* ws, long long ws_bytes, bmc_stream_t s) {
+    BMC_CHECK_ARG(nframes >= 0 && H > 0 && W > 0 && out, "bmc_encode_raw_events_binned: bad shape");
+    if (nframes == 0) return 0;
+    RawEvents ev{xs, ys, ps, flips};
+    const int rc = launch_binned(ev, offsets, nevents, nframes, H, W, out, ws, ws_bytes, (hipStream_t)s, "bmc_encode_raw_events_binned");
+    if (rc) return rc;
+    BMC_CHECK_LAUNCH("bmc_encode_raw_events_binned");
     return 0;
 }
 

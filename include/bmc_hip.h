@@ -59,6 +59,20 @@ const char* bmc_last_error(void);
 int bmc_events_to_channels(float* xs, float* ys, const float* ps, const long long* offsets,
                            int nframes, int H, int W, float* out, int mutate, bmc_stream_t s);
 
+/* The same two encoders for LARGE frames (the 720x960 ground-truth frames of the training step) without scattered global
+ * float atomics: events are counting-sorted by row band (integer atomics on a small table), one workgroup per
+ * (frame, band) accumulates its band of the count image in LDS and stores it once (that store is also the zero fill).
+ * Same results bit for bit (integer-valued sums), same in-place side effect on xs / ys with mutate.  nevents =
+ * offsets[nframes]; ws: 8-byte aligned workspace of bmc_events_binned_ws_bytes(nevents, nframes, H, W) bytes
+ * ((frame, band) count table and cursors + 8 bytes per event).  W <= 16384. */
+long long bmc_events_binned_ws_bytes(long long nevents, int nframes, int H, int W);
+int bmc_events_to_channels_binned(float* xs, float* ys, const float* ps, const long long* offsets, long long nevents,
+                                  int nframes, int H, int W, float* out, int mutate, void* ws, long long ws_bytes,
+                                  bmc_stream_t s);
+int bmc_encode_raw_events_binned(const short* xs, const short* ys, const double* ps, const long long* offsets,
+                                 const unsigned char* flips, long long nevents, int nframes, int H, int W, float* out,
+                                 void* ws, long long ws_bytes, bmc_stream_t s);
+
 /* events_to_voxel(): temporal-bilinear voxel grid [nframes][bins][H][W] (dataloader/encodings.py:272-287; ts already
  * normalised to [0,1] by event_formatting).  Same coordinate conventions and first-call side effect as above.  The
  * weights are arbitrary floats, so the order of summation is part of the result: a pixel's events are added in EVENT

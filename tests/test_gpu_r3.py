@@ -172,3 +172,173 @@ def test_streaming_graph_follows_weight_updates_and_reset():
     first = sr.step(win(0))
     ref.reset()
     assert torch.equal(first, ref.step(win(0)))
+
+
+# ------------------------------------------------------------------ BASELINE configs[1] (C2) at its full size
+def test_c2_full_size_window_forward_backward_vs_oracle():
+    """One BMCNet(4,128,5) window at the C2 frame size (180x240 -> 720x960), B = 1, forward AND backward against the CPU
+    oracle's autograd (round 2 checked C2's backward at a quarter frame only): loss <= 1e-5, every parameter gradient
+    <= 1e-3 (measured ~1e-5).  Includes the conv_fs partial-column launches and the grouped conv_hp / conv_hn launch at
+    full size.  ~10 s of CPU."""
+    dev = _gpu()
+    from models.BMCNet import BMCNet
+    from oracle import bmc_oracle as O
+    scale, n_c, n_b, B, H, W = 4, 128, 5, 1, 180, 240
+    torch.manual_seed(71)
+    m = BMCNet(scale, n_c, n_b)
+    scaled_init(m, 2.0)
+    params = oracle_params(m)
+    g = torch.Generator().manual_seed(72)
+    frames = torch.poisson(torch.full((B, 3, 2, H, W), 0.284), generator=g)
+    gts = torch.poisson(torch.full((B, 3, 2, scale * H, scale * W), 0.284), generator=g)
+    xs = [frames[:, i:i + 2].transpose(1, 2) for i in range(2)]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    # two windows, so that the recurrent inputs (states, unshuffled previous prediction) carry gradient too
+    loss_ref, preds_ref, _ = O.bptt_loss(params, xs, [gts[:, 1], gts[:, 2]], n_c, scale)
+    loss_ref.backward()
+    m.to(dev)
+    z = lambda c: torch.zeros(B, c, H, W, device=dev)
+    st = (z(n_c), z(n_c), z(n_c), z(2 * scale * scale))
+    loss = 0
+    for i in range(2):
+        st = m(xs[i].to(dev), *st, i == 0)
+        assert rel_l2(st[-1], preds_ref[i]) < 1e-4
+        loss = loss + F.mse_loss(st[-1], gts[:, i + 1].to(dev))
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
+    errs = {n: rel_l2(p.grad, params[n].grad) for n, p in m.named_parameters() if params[n].grad is not None}
+    assert len(errs) >= 50
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    print("C2 full-size 2-window fwd+bwd: loss %.6f vs %.6f, worst gradients %s" % (loss.item(), loss_ref.item(), [(n, "%.1e" % e) for n, e in worst]))
+    assert worst[0][1] < 1e-3, worst
+
+
+def test_c2_full_step_batch4_8_windows_properties():
+    """The bench's own step at its full size (BASELINE configs[1]: bs 4, SEQL 9 -> 8 windows, 180x240, store-everything:
+    ~140 GiB) through size-independent properties: the step's gradient is the mean of its two half-batches' gradients and
+    its loss the mean of theirs (MSE is a batch mean, sequences are independent: what batch sharding relies on), and a
+    slice of it is bit-identical with per-window recompute."""
+    dev = _gpu()
+    from models.BMCNet import BMCNet
+    from train_step import bptt_step
+    scale, n_c, n_b, B, L, H, W = 4, 128, 5, 4, 9, 180, 240
+    torch.manual_seed(73)
+    m = BMCNet(scale, n_c, n_b).to(dev)
+    scaled_init(m, 2.0)
+    g = torch.Generator().manual_seed(74)
+    inp = torch.poisson(torch.full((B, L, 2, H, W), 0.284), generator=g).to(dev)
+    gt = torch.poisson(torch.full((B, L, 2, scale * H, scale * W), 0.284), generator=g).to(dev)
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+
+    def step(sl, recompute=False, nwin=L):
+        torch.cuda.reset_peak_memory_stats()
+        loss, _ = bptt_step(m, opt, inp[sl, :nwin], gt[sl, :nwin], n_c, scale, recompute=recompute)
+        grads = [p.grad.clone() for p in m.parameters()]
+        return loss.item(), grads, torch.cuda.max_memory_allocated() / 2 ** 30
+
+    l_all, g_all, mem = step(slice(0, 4))
+    print("C2 full step: loss %.6f peak %.1f GiB" % (l_all, mem))
+    assert np.isfinite(l_all) and mem < 220.0
+    l_a, g_a, _ = step(slice(0, 2))
+    l_b, g_b, _ = step(slice(2, 4))
+    assert abs(l_all - 0.5 * (l_a + l_b)) < 2e-6 * abs(l_all)
+    worst = max(rel_l2(ga, 0.5 * (a + b)) for ga, a, b in zip(g_all, g_a, g_b))
+    assert worst < 2e-4, worst
+    l_r, g_r, _ = step(slice(0, 2), True, 4)
+    l_s, g_s, _ = step(slice(0, 2), False, 4)
+    assert l_r == l_s and all(torch.equal(a, b) for a, b in zip(g_r, g_s))
+
+
+# ------------------------------------------------------------------ event encoders: LDS-binned path, long voxel segments
+def test_binned_event_scatter_bit_exact_vs_oracle_and_atomic_kernel():
+    """bmc_events_to_channels_binned (counting sort by row band + LDS count images, csrc/scatter.hip) on HR-sized frames
+    with ragged / empty frames, out-of-range events of both polarities, float coordinates and a hot pixel: identical bit
+    for bit to the numpy oracle and to the atomic kernel, including the in-place reset of out-of-range coordinates."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from oracle import bmc_oracle as O
+    H, W = 720, 960
+    rng = np.random.default_rng(5)
+    counts = [393216, 0, 1000, 200001, 7]
+    xs, ys, ps = [], [], []
+    for n in counts:
+        x = rng.uniform(-3.0, W + 3.0, n).astype(np.float32)
+        y = rng.uniform(-3.0, H + 3.0, n).astype(np.float32)
+        if n > 5000:
+            x[:3000], y[:3000] = 17.5, 700.25            # a hot pixel
+            x[3000:3400], y[3000:3400] = -1.0, 5.0       # out of range, both polarities
+        xs.append(x); ys.append(y); ps.append(rng.choice([-1.0, 1.0], n).astype(np.float32))
+    off = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int64, device=dev)
+    cat = lambda l: torch.tensor(np.concatenate(l), device=dev)
+    assert H * W >= ops.BINNED_MIN_PIXELS
+    x1, y1, p1 = cat(xs), cat(ys), cat(ps)
+    got = ops.events_to_channels_batched(x1, y1, p1, off, H, W, mutate=True)
+    old = ops.BINNED_MIN_PIXELS
+    try:
+        ops.BINNED_MIN_PIXELS = 1 << 40                      # force the atomic kernel
+        x2, y2, p2 = cat(xs), cat(ys), cat(ps)
+        ref_gpu = ops.events_to_channels_batched(x2, y2, p2, off, H, W, mutate=True)
+    finally:
+        ops.BINNED_MIN_PIXELS = old
+    assert torch.equal(got, ref_gpu) and torch.equal(x1, x2) and torch.equal(y1, y2)
+    for f, n in enumerate(counts):
+        img, xa, ya = O.events_to_channels_np(xs[f], ys[f], ps[f], (H, W))
+        assert np.array_equal(got[f].cpu().numpy(), img), f
+        a, b = int(off[f]), int(off[f + 1])
+        assert np.array_equal(x1[a:b].cpu().numpy(), xa) and np.array_equal(y1[a:b].cpu().numpy(), ya)
+    assert float(got.sum()) == float(sum(O.events_to_channels_np(xs[f], ys[f], ps[f], (H, W))[0].sum() for f in range(len(counts))))
+    # mutate=False leaves the caller's arrays alone
+    x3, y3 = cat(xs), cat(ys)
+    ops.events_to_channels_batched(x3, y3, cat(ps), off, H, W, mutate=False)
+    assert torch.equal(x3, cat(xs)) and torch.equal(y3, cat(ys))
+
+
+def test_binned_raw_column_encoder_bit_exact_at_hr_size():
+    dev = _gpu()
+    from bmc_hip import ops
+    from oracle import bmc_oracle as O
+    H, W = 720, 960
+    rng = np.random.default_rng(6)
+    counts = [150000, 393216, 3]
+    flags = [5, 2, 7]
+    xs = [rng.integers(-2, W + 2, n).astype(np.int16) for n in counts]
+    ys = [rng.integers(-2, H + 2, n).astype(np.int16) for n in counts]
+    ps = [rng.choice([-1.0, 1.0], n).astype(np.float64) for n in counts]
+    off = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int64, device=dev)
+    got = ops.encode_raw_events(torch.tensor(np.concatenate(xs), device=dev), torch.tensor(np.concatenate(ys), device=dev),
+                                torch.tensor(np.concatenate(ps), device=dev), off,
+                                torch.tensor(flags, dtype=torch.uint8, device=dev), H, W)
+    for f in range(len(counts)):
+        assert np.array_equal(got[f].cpu().numpy(), O.encode_raw_frame_np(xs[f], ys[f], ps[f], flags[f], (H, W))), f
+
+
+def test_voxel_long_segments_are_sorted_cooperatively():
+    """every out-of-range event of a frame lands in ONE pixel's segment, hot pixels give long segments too, and
+    the per-pixel pass sorted them with a single-thread insertion sort (O(k^2)).  50 000 + 20 000 such events now go
+    through the workgroup-wide sort first: bit-exact vs the numpy oracle (event-order summation), in well under a second."""
+    import time
+    dev = _gpu()
+    from bmc_hip import ops
+    from oracle import bmc_oracle as O
+    H, W, bins, n = 45, 80, 5, 90000
+    rng = np.random.default_rng(8)
+    xs = rng.uniform(0, W, n).astype(np.float32)
+    ys = rng.uniform(0, H, n).astype(np.float32)
+    sel = rng.permutation(n)
+    xs[sel[:50000]], ys[sel[:50000]] = -2.0, 3.0          # out of range -> pixel (H-1, 0) from the second bin on
+    xs[sel[50000:70000]], ys[sel[50000:70000]] = 40.5, 20.5
+    ts = np.sort(rng.uniform(0, 1, n)).astype(np.float32)
+    ps = rng.choice([-1.0, 1.0], n).astype(np.float32)
+    ref, xa, ya = O.events_to_voxel_np(xs, ys, ts, ps, bins, (H, W))
+    d = [torch.tensor(a, device=dev) for a in (xs, ys, ts, ps)]
+    off = torch.tensor([0, n], dtype=torch.int64, device=dev)
+    ops.events_to_voxel_batched(d[0].clone(), d[1].clone(), d[2], d[3], off, bins, H, W)      # warm-up (module load)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = ops.events_to_voxel_batched(d[0], d[1], d[2], d[3], off, bins, H, W)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("voxel with 50k + 20k event segments: %.1f ms" % (dt * 1e3))
+    assert np.array_equal(got[0].cpu().numpy(), ref)
+    assert np.array_equal(d[0].cpu().numpy(), xa) and np.array_equal(d[1].cpu().numpy(), ya)
+    assert dt < 0.5
