@@ -127,10 +127,11 @@ def _conv(srcs, w4, spec, owner, bias, out, B, relu=False, residual=None, mask=N
     """Forward-style launch: out[out_b0 : out_b0+B] = epi(conv(cat(srcs)) + bias)."""
     G, Cout, Cin, taps = w4.shape
     _, H, W, Co = out.shape
-    wp = _packed_weight(w4, spec, owner)
+    wn = ops.wino_ok(B, H, W, Cout, taps)
+    wp = _packed_weight(w4, spec, owner, wino=wn)
     conv_raw(srcs, wp, spec.kpad * taps * coutpad(Cout), bias, Cout if bias is not None else 0,
              out.data_ptr() + 4 * out_b0 * H * W * Co, H * W * Co, Co, B, H, W, Cout, taps, relu=relu, residual=residual,
-             bpg=bpg, accumulate=accumulate, mask=mask, flops=2.0 * B * H * W * Cout * taps * spec.kreal)
+             bpg=bpg, accumulate=accumulate, mask=mask, flops=2.0 * B * H * W * Cout * taps * spec.kreal, wino=wn)
 
 
 def _dgrad(g_src, w4, spec, src_index, owner, out, B, residual=None, mask=None, bpg=None, accumulate=False, out_b0=0):
@@ -138,10 +139,11 @@ def _dgrad(g_src, w4, spec, src_index, owner, out, B, residual=None, mask=None, 
     G, Cout, Cin, taps = w4.shape
     _, H, W, Co = out.shape
     nch = spec.nch[src_index]
-    wt = _packed_weight_t(w4, spec, src_index, owner)
+    wn = ops.wino_ok(B, H, W, nch, taps)
+    wt = _packed_weight_t(w4, spec, src_index, owner, wino=wn)
     conv_raw([g_src], wt, round_up(Cout, CK) * taps * coutpad(nch), None, 0, out.data_ptr() + 4 * out_b0 * H * W * Co,
              H * W * Co, Co, B, H, W, nch, taps, residual=residual, mask=mask, bpg=bpg, accumulate=accumulate,
-             flops=2.0 * B * H * W * spec.real_nch[src_index] * taps * Cout)
+             flops=2.0 * B * H * W * spec.real_nch[src_index] * taps * Cout, wino=wn)
 
 
 def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, w_param, b_param, G=1, w_shape=None):

@@ -81,6 +81,7 @@ _events_binned = _sig("bmc_events_to_channels_binned", [_p, _p, _p, _p, _ll, _i,
 _enc_raw_binned = _sig("bmc_encode_raw_events_binned", [_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p, _p, _ll, _p])
 _pack_w = _sig("bmc_pack_weight", [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p])
 _pack_wt = _sig("bmc_pack_weight_t", [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p])
+_pack_wino = _sig("bmc_pack_weight_wino", [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p])
 _split_w = _sig("bmc_split_weight", [_p, _p, _ll, _i, _i, _p])
 _conv = _sig("bmc_conv", [C.POINTER(ConvArgs), _p])
 _pgemm = _sig("bmc_pgemm", [C.POINTER(PgemmArgs), _p])
@@ -112,7 +113,7 @@ EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_event
            "bmc_chain_fwd", "bmc_chain_bwd", "bmc_chain_affine_grads", "bmc_group_sum",
            "bmc_head_mse_fwd", "bmc_head_mse_bwd", "bmc_events_to_stack_polarity", "bmc_events_to_mask",
            "bmc_pgemm_reduce_weight_groups", "bmc_events_binned_ws_bytes", "bmc_events_to_channels_binned",
-           "bmc_encode_raw_events_binned"]
+           "bmc_encode_raw_events_binned", "bmc_pack_weight_wino"]
 
 
 def check(rc, what):

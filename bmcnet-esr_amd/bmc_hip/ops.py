@@ -132,6 +132,7 @@ class ConvSpec:
 # Optional in-situ kernel timing (bench.py): when PROFILE is a list, every conv / pgemm launch appends
 # (kernel kind, algorithmic FLOPs, start event, end event) recorded on the launch stream.
 PROFILE = None
+PROFILE_WINO = [0, 0]       # while PROFILE is a list: conv launches that took the Winograd kernel / the direct kernels
 
 
 def _prof_begin():
@@ -229,10 +230,36 @@ def stacked(owners, build, tag=""):
     return t
 
 
-def _packed_weight(w4: torch.Tensor, spec: ConvSpec, owner):
-    """[G,Cout,Cin,taps] -> MFMA staging layout (bmc_pack_weight).  owner: the parameter tensor w4 was derived
-    from (cache key), or None for no caching."""
+# 3x3 convolutions with 128-granular output channels and enough tiles to fill the chip run through the Winograd transform
+# F(2x2, 3x3) (csrc/wino.hip: 16 instead of 36 multiplies per 2x2 output tile and channel pair, fp32 throughout; one
+# 256-accumulator workgroup per CU, so small problems stay on the direct kernel).  BMC_WINO=0 switches it off.
+WINO = os.environ.get("BMC_WINO", "1") != "0"
+WINO_MIN_TILES = int(os.environ.get("BMC_WINO_MIN_TILES", 512))
+
+
+def wino_ok(B, H, W, Cout, taps):
+    """Does a launch of this geometry take the Winograd kernel?  (Decided ONCE per launch by the caller and handed to the
+    weight pack and to conv_raw alike: the two packed layouts are not interchangeable.)"""
+    if not WINO or MATH != 0 or taps != 9:
+        return False
+    cp = coutpad(Cout)
+    return cp % 128 == 0 and B * ((H + 7) // 8) * ((W + 15) // 16) * (cp // 128) >= WINO_MIN_TILES
+
+
+def _packed_weight(w4: torch.Tensor, spec: ConvSpec, owner, wino=False):
+    """[G,Cout,Cin,taps] -> MFMA staging layout (bmc_pack_weight; wino: the transformed weights of bmc_pack_weight_wino).
+    owner: the parameter tensor w4 was derived from (cache key), or None for no caching."""
     G, Cout, Cin, taps = w4.shape
+    if wino:
+        hit = _cache_get(spec, ("fw",), owner)
+        if hit is not None:
+            return hit
+        cp = coutpad(Cout)
+        out = torch.empty(G * spec.kpad * 16 * cp, device=w4.device, dtype=torch.float32)
+        lib.call(lib._pack_wino, "bmc_pack_weight_wino", w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin,
+                 spec.kpad, cp, 0, 0, 0, out.data_ptr(), _stream())
+        _cache_put(spec, ("fw",), owner, out)
+        return out
     hit = _cache_get(spec, ("f", MATH), owner)
     if hit is not None:
         return hit
@@ -246,15 +273,24 @@ def _packed_weight(w4: torch.Tensor, spec: ConvSpec, owner):
     return out
 
 
-def _packed_weight_t(w4: torch.Tensor, spec: ConvSpec, src_index: int, owner):
+def _packed_weight_t(w4: torch.Tensor, spec: ConvSpec, src_index: int, owner, wino=False):
     G, Cout, Cin, taps = w4.shape
-    hit = _cache_get(spec, ("t", src_index, MATH), owner)
-    if hit is not None:
-        return hit
     k0 = sum(spec.nch[:src_index])
     nk = spec.nch[src_index]
     nkpad = coutpad(nk)
     c16 = round_up(Cout, CK)
+    if wino:
+        hit = _cache_get(spec, ("tw", src_index), owner)
+        if hit is not None:
+            return hit
+        out = torch.empty(G * c16 * 16 * nkpad, device=w4.device, dtype=torch.float32)
+        lib.call(lib._pack_wino, "bmc_pack_weight_wino", w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin,
+                 c16, nkpad, 1, k0, nk, out.data_ptr(), _stream())
+        _cache_put(spec, ("tw", src_index), owner, out)
+        return out
+    hit = _cache_get(spec, ("t", src_index, MATH), owner)
+    if hit is not None:
+        return hit
     out = torch.empty(G * c16 * taps * nkpad, device=w4.device, dtype=torch.float32)
     lib.call(lib._pack_wt, "bmc_pack_weight_t", w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin, taps,
              k0, nk, nkpad, c16, out.data_ptr(), _stream())
@@ -270,7 +306,9 @@ def _packed_weight_t(w4: torch.Tensor, spec: ConvSpec, src_index: int, owner):
 # --------------------------------------------------------------------------
 def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stride, out_ptr, out_batch_stride,
              out_pix_stride, B, H, W, Cout, taps, relu=False, residual: Optional[lib.Src] = None, bpg=None,
-             accumulate=False, flops=0.0, mask: Optional[lib.Src] = None):
+             accumulate=False, flops=0.0, mask: Optional[lib.Src] = None, wino=False):
+    """wino: wpacked is the Winograd pack (the caller decided with wino_ok() and packed accordingly); w_group_stride is
+    still given for the direct layout ([K/16][9 taps][Coutpad][16]) and converted here (16 positions instead of 9 taps)."""
     a = lib.ConvArgs()
     a.nsrc = len(srcs)
     for i, s in enumerate(srcs):
@@ -279,6 +317,10 @@ def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stri
     a.bias = bias.data_ptr() if bias is not None else None
     a.w_group_stride = w_group_stride * MATH // 2 if MATH else w_group_stride   # floats, or dwords of bf16 planes
     a.math = MATH
+    if wino:
+        assert MATH == 0 and taps == 9
+        a.w_group_stride = w_group_stride // 9 * 16
+        a.math = 4          # BMC_MATH_FP32_WINO
     a.bias_group_stride = bias_group_stride
     a.batch_per_group = bpg if bpg else B
     a.out = out_ptr
@@ -294,6 +336,8 @@ def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stri
     e0 = _prof_begin()
     lib.call(lib._conv, "bmc_conv", C.byref(a), _stream())
     _prof_end(e0, "conv_kernel<%d,%d>" % (taps, 32 if a.Coutpad == 32 else 128), flops)
+    if PROFILE is not None and e0 is not None:
+        PROFILE_WINO[0 if wino else 1] += 1
 
 
 _ZEROS = {}
@@ -501,7 +545,8 @@ class ConvFn(torch.autograd.Function):
         w4 = weight.detach().reshape(G, -1, meta.spec.cin, taps)
         Cout = w4.shape[1]
         ck = weight if meta.cache else None
-        wp = _packed_weight(w4.contiguous(), meta.spec, ck)
+        wn = wino_ok(B, H, W, Cout, taps)
+        wp = _packed_weight(w4.contiguous(), meta.spec, ck, wino=wn)
         if meta.out is not None:       # write into a batch range of a preallocated buffer (see OutSlot)
             out = meta.out.t[meta.out.b0:meta.out.b0 + B]
             assert out.shape == (B, H, W, Cout) and out.is_contiguous()
@@ -514,7 +559,7 @@ class ConvFn(torch.autograd.Function):
         cp = coutpad(Cout)
         conv_raw(srcs, wp, meta.spec.kpad * taps * cp, bias.detach() if bias is not None else None, Cout,
                  out.data_ptr(), H * W * Cout, Cout, B, H, W, Cout, taps, relu=meta.relu, residual=res,
-                 bpg=B // G, flops=2.0 * B * H * W * Cout * taps * meta.spec.kreal)
+                 bpg=B // G, flops=2.0 * B * H * W * Cout * taps * meta.spec.kreal, wino=wn)
         ctx.meta = meta
         ctx.params = (weight, bias)  # the objects the caller passed (leaf parameters take their gradients directly)
         if meta.ngp:
@@ -597,15 +642,15 @@ class ConvFn(torch.autograd.Function):
                 c0, nch, shift, mod, b0 = v
                 Bt, _, _, Ct = t.shape
                 dxs_ = grp[1]
-                wt = _packed_weight_t(w4, spec, i, ck)
+                wn = wino_ok(B, H, W, nch, taps)
+                wt = _packed_weight_t(w4, spec, i, ck, wino=wn)
                 conv_raw([_src(g, 0, Cout, 0, None, 0, B)], wt, round_up(Cout, CK) * taps * coutpad(nch), None, 0,
                          dxs_.data_ptr() + 4 * (b0 * H * W * Ct + c0), H * W * Ct, Ct, B, H, W, nch, taps, bpg=B,
-                         flops=2.0 * B * H * W * spec.real_nch[i] * taps * Cout)
+                         flops=2.0 * B * H * W * spec.real_nch[i] * taps * Cout, wino=wn)
                 dsrcs.append(dxs_ if i == grp[0][0] else None)
                 continue
             c0, nch, shift, mod, b0 = v
             Bt, _, _, Ct = t.shape
-            wt = _packed_weight_t(w4, spec, i, ck)
             c16 = round_up(Cout, CK)
             nkpad = coutpad(nch)
             gs, nb, gshift, gmod = g, B, 0, None
@@ -613,8 +658,10 @@ class ConvFn(torch.autograd.Function):
             if G > 1 and ((mod is not None and mod < B) or shift):
                 # grouped weights + remapped operand: launch over the full batch, fold the batch map afterwards
                 tmp = torch.empty((B, H, W, nch), device=dev, dtype=torch.float32)
+                wn = wino_ok(B, H, W, nch, taps)
+                wt = _packed_weight_t(w4, spec, i, ck, wino=wn)
                 conv_raw([_src(g, 0, Cout, 0, None, 0, B)], wt, c16 * taps * nkpad, None, 0, tmp.data_ptr(), H * W * nch,
-                         nch, B, H, W, nch, taps, bpg=B // G, flops=2.0 * B * H * W * spec.real_nch[i] * taps * Cout)
+                         nch, B, H, W, nch, taps, bpg=B // G, flops=2.0 * B * H * W * spec.real_nch[i] * taps * Cout, wino=wn)
                 if mod is not None and mod < B:
                     tmp = tmp.view(B // mod, mod, H, W, nch).sum(0)
                     if shift:
@@ -640,8 +687,10 @@ class ConvFn(torch.autograd.Function):
             gsrc = _src(gs, 0, Cout, gshift, gmod, 0, nb)
             if Cout % CK:
                 raise RuntimeError("bmc_hip: conv output channels must be a multiple of 16 for the data gradient")
+            wn = wino_ok(nb, H, W, nch, taps)
+            wt = _packed_weight_t(w4, spec, i, ck, wino=wn)
             conv_raw([gsrc], wt, c16 * taps * nkpad, None, 0, dx.data_ptr() + 4 * (b0 * H * W * Ct + c0), H * W * Ct, Ct,
-                     nb, H, W, nch, taps, bpg=nb // G, flops=2.0 * nb * H * W * spec.real_nch[i] * taps * Cout)
+                     nb, H, W, nch, taps, bpg=nb // G, flops=2.0 * nb * H * W * spec.real_nch[i] * taps * Cout, wino=wn)
             dsrcs.append(dx)
         if ngp:      # gradients of the stacked weights' owners: None when they went straight into .grad, else the stack's slices
             wps, bps = ctx.params
@@ -749,15 +798,16 @@ class ResBlockFn(torch.autograd.Function):
         taps = w1.shape[-1] * w1.shape[-2]
         cp = coutpad(Cn)
         xs = _src(x.detach(), 0, Cn, 0, None, 0, B)
-        wp1 = _packed_weight(w1.detach().reshape(1, Cn, Cn, taps), spec, w1)
-        wp2 = _packed_weight(w2.detach().reshape(1, Cn, Cn, taps), spec, w2)
+        wn = wino_ok(B, H, W, Cn, taps)
+        wp1 = _packed_weight(w1.detach().reshape(1, Cn, Cn, taps), spec, w1, wino=wn)
+        wp2 = _packed_weight(w2.detach().reshape(1, Cn, Cn, taps), spec, w2, wino=wn)
         fl = 2.0 * B * H * W * Cn * taps * Cn
         t = torch.empty_like(x)
         conv_raw([xs], wp1, spec.kpad * taps * cp, b1.detach(), Cn, t.data_ptr(), H * W * Cn, Cn, B, H, W, Cn, taps, relu=True,
-                 flops=fl)
+                 flops=fl, wino=wn)
         y = torch.empty_like(x) if out is None else out.t[out.b0:out.b0 + B]
         conv_raw([_src(t, 0, Cn, 0, None, 0, B)], wp2, spec.kpad * taps * cp, b2.detach(), Cn, y.data_ptr(), H * W * Cn, Cn, B, H,
-                 W, Cn, taps, residual=xs, flops=fl)
+                 W, Cn, taps, residual=xs, flops=fl, wino=wn)
         ctx.save_for_backward(x, t, w1, w2)
         ctx.spec, ctx.taps = spec, taps
         ctx.owners = (w1, w2)
@@ -779,17 +829,18 @@ class ResBlockFn(torch.autograd.Function):
         p_w1, p_b1, p_w2, p_b2 = ctx.params
         dw2, db2 = _wgrad_plain(g, t, spec, p_w2, p_b2, taps) if (need[3] or need[4]) else (None, None)
         # d(pre-activation of conv1) = ReLU'(t) * conv2^T(g): mask epilogue
-        w2t = _packed_weight_t(w2.detach().reshape(1, Cn, Cn, taps), spec, 0, ctx.owners[1])
+        wn = wino_ok(B, H, W, Cn, taps)
+        w2t = _packed_weight_t(w2.detach().reshape(1, Cn, Cn, taps), spec, 0, ctx.owners[1], wino=wn)
         dt = torch.empty_like(g)
         conv_raw([gs], w2t, c16 * taps * nkpad, None, 0, dt.data_ptr(), H * W * Cn, Cn, B, H, W, Cn, taps,
-                 mask=_src(t, 0, Cn, 0, None, 0, B), flops=fl)
+                 mask=_src(t, 0, Cn, 0, None, 0, B), flops=fl, wino=wn)
         dw1, db1 = _wgrad_plain(dt, x, spec, p_w1, p_b1, taps) if (need[1] or need[2]) else (None, None)
         dx = None
         if need[0]:   # dx = conv1^T(dt) + g (skip path): residual epilogue
-            w1t = _packed_weight_t(w1.detach().reshape(1, Cn, Cn, taps), spec, 0, ctx.owners[0])
+            w1t = _packed_weight_t(w1.detach().reshape(1, Cn, Cn, taps), spec, 0, ctx.owners[0], wino=wn)
             dx = grad_slot(ctx.gslot, g)
             conv_raw([_src(dt, 0, Cn, 0, None, 0, B)], w1t, c16 * taps * nkpad, None, 0, dx.data_ptr(), H * W * Cn, Cn, B, H, W,
-                     Cn, taps, residual=gs, flops=fl)
+                     Cn, taps, residual=gs, flops=fl, wino=wn)
         return dx, dw1, db1, dw2, db2, None, None
 
 

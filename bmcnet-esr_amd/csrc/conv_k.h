@@ -28,3 +28,7 @@ int bmc_conv_bf_launch(const ConvK& k, int taps, int BN, int TH, int planes, int
 // conv1.hip: 1x1 convolution on the 16x16x4 fp32 MFMA with LDS-DMA operand rings (large problems).  Returns 1 if it
 // launched the problem, 0 if it is left to conv.hip's kernel.
 int bmc_conv1_launch(ConvK k, int cus, hipStream_t st);
+
+// wino.hip: 3x3 convolution through the Winograd transform F(2x2, 3x3) on the fp32 MFMA (math = BMC_MATH_FP32_WINO; weights from
+// bmc_pack_weight_wino).  Returns 0, or < 0 with the error text set.
+int bmc_conv_wino_launch(ConvK k, int cus, hipStream_t st);

@@ -1,0 +1,451 @@
+// 3x3 convolution on the fp32 matrix cores through the Winograd transform F(2x2, 3x3):
+//
+//     Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray; B^T, G, A^T below)
+//
+// 16 multiplies per 2x2 output tile and (ci, co) pair instead of 36: the step's dominant kernel (the 3x3 128 -> 128
+// convolutions of the residual blocks, forward and data gradient: ~59 % of its FLOPs) is fp32-MFMA-bound at 0.83 of the
+// matrix peak, so the only way to make it substantially faster in exact-fp32 arithmetic is to execute fewer multiplies.
+// Numerics: B^T and A^T hold only 0 / +-1 (the input and output transforms are sums), G holds 1/2 (exact scalings); measured
+// against float64, one convolution is 1.2-1.6x the direct fp32 kernel's error (3.5e-7 vs 2.2e-7), the whole recurrent network
+// within 20 % of it (tools / DESIGN.md) -- far inside the 1e-4 budget.  Same semantics as conv.hip (bmc_conv): multi-source
+// NHWC operands, per-group weights, fused bias / residual / ReLU / ReLU-mask / accumulate epilogue.
+//
+// Machine mapping (v_mfma_f32_32x32x2_f32, D rows = output channels, D columns = WINOGRAD TILES):
+//   * workgroup = 4 waves = 8 x 16 output pixels = 4 x 8 tiles of 2 x 2; wave w = all 32 tiles x output channels [32w, 32w + 32)
+//     x all 16 transform positions = 16 accumulator tiles = 256 registers per lane: one workgroup per CU, one wave per SIMD;
+//   * lane (tile t = lane & 31, k-half h = lane >> 5) builds ITS tile's transformed input B^T d B in registers, straight from
+//     the raw (8 + 2) x (16 + 2) halo tile in LDS (two patch rows per transform row xi: 8 ds_read_b128, 32 x 4 adds): the
+//     MFMA's pixel operand never goes back to LDS, and both transforms are in-lane sums -- no shuffles;
+//   * the transformed weights U = G g G^T (packed once per weight version by bmc_pack_weight_wino, [chunk][xi][nu][co][16 ci],
+//     quads pre-swizzled) stream from L2 through a 3-stage LDS ring by LDS-DMA, one (chunk, xi) stage = 4 positions x 128 x 16
+//     floats = 32 KB, two stages ahead; wave w copies position nu = w of a stage (8 instructions of 1 KB);
+//   * one barrier per stage = per 32 MFMAs (2 048 matrix-pipe cycles) of every wave;
+//   * the epilogue applies A^T . A in place (24 adds per accumulator register), then finishes as conv.hip does: all loads,
+//     then all stores, 16 bytes per lane (a lane owns 4 consecutive channels of each of its tile's 4 pixels).
+// The bias rides in the accumulators of position (1, 1): A^T m A passes that position into all four outputs with weight 1.
+#include "bmc_common.h"
+#include "conv_k.h"
+#include "dma_ring.h"
+
+#ifndef BMC_WINO_ABL
+#define BMC_WINO_ABL 0     // ablation bits for tools/ builds only: 1 no MFMAs, 2 no weight DMA, 4 no halo loads, 8 no epilogue stores
+#endif
+
+namespace {
+
+constexpr int CK = BMC_CK;
+constexpr int RS = 20;                  // floats per halo pixel in LDS (16 + 4 pad)
+constexpr int TH = 8, TW = 16;          // output pixels per workgroup tile
+constexpr int HHT = TH + 2, HWD = TW + 2;
+constexpr int XROW = (HWD * RS + 63) / 64 * 64;      // halo row stride (as conv.hip: rows start on a 256-byte boundary)
+constexpr int XBUF = HHT * XROW;
+constexpr int XBUFA = 4096;              // floats per X buffer as allocated: 16 DMA instructions x 64 lanes x 4 floats >= XBUF
+constexpr int BN = 128;                 // output channels per workgroup tile
+constexpr int WSTAGE = 4 * BN * CK;     // floats per weight stage: 4 positions (nu) x 128 rows x 16 channels
+constexpr int NWR = 3, DW = 2;          // weight ring: stages, stages ahead
+__device__ __attribute__((aligned(16))) const float g_zero4w[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ int wswz(int row) { return (row >> 2) & 3; }
+
+__global__ __launch_bounds__(256, 1) void wino_conv_kernel(const ConvK a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * XBUFA + NWR * WSTAGE + BMC_MAX_SRC * 8 + BN];
+    static_assert(XBUFA >= XBUF && HHT * 96 <= 16 * 64, "X buffer / DMA coverage");
+    float* const Xb = lds;
+    float* const Wb = lds + 2 * XBUFA;
+    SrcDev* const tab = reinterpret_cast<SrcDev*>(lds + 2 * XBUFA + NWR * WSTAGE);
+    float* const init_lds = lds + 2 * XBUFA + NWR * WSTAGE + BMC_MAX_SRC * 8;
+    const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Wb;
+    const bool bias_pre = a.bias != nullptr && a.batch_per_group >= a.B && a.ntn == 1;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < BMC_MAX_SRC; ++i)
+        if (tid == i) tab[i] = a.src[i];
+    if (tid < BN) init_lds[tid] = (bias_pre && tid < a.Cout) ? a.bias[tid] : 0.f;
+    __syncthreads();
+
+    // ---- persistent walk over tiles, XCD-contiguous ranges (as conv.hip)
+    const int ntiles = a.ntiles;
+    constexpr int NX_ = 8;
+    const bool xcd_map = (gridDim.x % NX_) == 0 && ntiles >= (int)gridDim.x;
+    const int xcd = blockIdx.x % NX_, xj = blockIdx.x / NX_, per_x = gridDim.x / NX_;
+    const int t_lo = xcd_map ? (int)((long long)ntiles * xcd / NX_) : 0;
+    const int t_hi = xcd_map ? (int)((long long)ntiles * (xcd + 1) / NX_) : ntiles;
+    const int t_first = xcd_map ? t_lo + xj : (int)blockIdx.x;
+    const int t_stride = xcd_map ? per_x : (int)gridDim.x;
+    const int my_tiles = t_first < t_hi ? (t_hi - t_first + t_stride - 1) / t_stride : 0;
+    if (my_tiles == 0) return;
+    const int nchunks = a.nchunks;
+    const int total_chunks = my_tiles * nchunks, total_stages = 4 * total_chunks;
+
+    struct TileIt { int nt, tx, ty, b; };
+    auto decode = [&](int t) {
+        TileIt it;
+        it.nt = t % a.ntn; t /= a.ntn;
+        it.tx = t % a.tiles_x; t /= a.tiles_x;
+        it.ty = t % a.tiles_y;
+        it.b = t / a.tiles_y;
+        return it;
+    };
+
+    // ---- X loader: the raw halo tile of one 16-channel chunk, straight into LDS by LDS-DMA with per-lane source addresses
+    // (no staging registers -- the 256 accumulators leave none to spare -- and no ds_write).  The LDS image is the padded
+    // layout the patch reads want ([halo row][18 pixels x 20 floats], rows 384 floats apart) seen as a linear stream of
+    // 16-byte quads: quad Q = halo row Q / 96, pixel (Q % 96) / 5, channel quad (Q % 96) % 5; lanes on a pad quad (fifth quad
+    // of a pixel, row tail) or on a pixel outside the image fetch 16 bytes of zeros.  16 instructions (1 KB each) cover a
+    // tile, 4 per wave.
+    constexpr int NXD = 4;
+    int xl_tile = t_first, xl_chunk = 0, s_idx = 0, c_in = 0, snch = 0;
+    TileIt xl_it = decode(t_first);
+    const float* sbase = nullptr;
+    unsigned xoff[NXD];               // byte offset from the source's batch pointer (+ channel chunk), valid lanes
+    unsigned xokm = 0;                // bit k: instruction k's lane reads the image
+    auto src_select = [&]() {         // (once per tile and source: the lane's halo coordinates are recomputed, not kept)
+        const SrcDev S = tab[s_idx];
+        sbase = src_batch_ptr(S, xl_it.b); snch = S.nch;
+        const int y0 = xl_it.ty * TH, x0 = xl_it.tx * TW;
+        xokm = 0;
+#pragma unroll
+        for (int k = 0; k < NXD; ++k) {
+            const int Q = (wave * NXD + k) * 64 + lane, hy = Q / 96, rq = Q - hy * 96, hx = rq / 5, q = rq - hx * 5;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = hy < HHT && hx < HWD && q < 4 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            xokm |= ok ? (1u << k) : 0u;
+            xoff[k] = ok ? (unsigned)(((y * a.W + x) * S.pix_stride + q * 4) * 4) : 0u;
+        }
+    };
+    auto xl_setup = [&]() {
+        s_idx = 0; c_in = 0; xl_chunk = 0;
+        src_select();
+    };
+    const unsigned xb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Xb;
+    auto load_x = [&](int buf) {      // the next chunk of the stream -> X buffer `buf`
+        const char* const base = reinterpret_cast<const char*>(sbase + c_in);
+#pragma unroll
+        for (int k = 0; k < NXD; ++k) {
+            const void* src = (xokm >> k) & 1 ? static_cast<const void*>(base + xoff[k]) : static_cast<const void*>(g_zero4w);
+            if (BMC_WINO_ABL & 4) src = g_zero4w;
+            dma16v(src, xb_lds + (unsigned)((buf * XBUFA + (wave * NXD + k) * 256) * 4));
+        }
+        c_in += CK;
+        if (++xl_chunk == nchunks) {
+            xl_tile += t_stride;
+            if (xl_tile < t_hi) { xl_it = decode(xl_tile); xl_setup(); }
+        } else if (c_in >= snch) {
+            c_in = 0; ++s_idx;
+            src_select();
+        }
+    };
+
+    // ---- W ring loader: stage (tile, chunk, xi) = 4 positions; wave w copies position nu = w (8 KB = 8 DMA instructions)
+    int wl_tile = t_first, wl_sub = 0, wl_cnt = 0;      // wl_sub: stage index inside the tile (4 * chunk + xi)
+    const float* wl_base = nullptr;
+    const long long wrow = (long long)a.Coutpad * CK;     // floats per position block of a stage in global memory
+    auto wl_setup = [&]() {
+        const TileIt it = decode(wl_tile);
+        const int grp = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
+        wl_base = static_cast<const float*>(a.w) + (long long)grp * a.w_group_stride + (long long)it.nt * BN * CK;
+        wl_sub = 0;
+    };
+    auto issue_w = [&]() {
+        const float* p = wl_base + ((long long)wl_sub * 4 + wave) * wrow;
+        const unsigned dst = wb_lds + (unsigned)(((wl_cnt % NWR) * WSTAGE + wave * BN * CK) * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (!(BMC_WINO_ABL & 2)) dma16(p, (unsigned)((i * 64 + lane) * 16), dst + i * 1024);
+        ++wl_cnt;
+        if (++wl_sub == 4 * nchunks) {
+            wl_tile += t_stride;
+            if (wl_tile < t_hi) wl_setup();
+        }
+    };
+
+    // ---- fragment addressing
+    const int tr = li >> 3, tc = li & 7;
+    const int poff = (2 * tr) * XROW + (2 * tc) * RS + 4 * lh;            // + r * XROW + c * RS + 8 * kg
+    const int wrow_l = 32 * wave + li;                                      // this lane's weight row inside a position block
+    int woff[2];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) woff[kg] = wrow_l * CK + (((lh + 2 * kg) ^ wswz(wrow_l)) * 4);
+
+    f32x16 acc[16];
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {        // bias (or zeros) into position (1, 1): it reaches every output with weight 1
+            const f32x4 v = *reinterpret_cast<const f32x4*>(init_lds + 32 * wave + 4 * lh + 8 * rq);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[5][4 * rq + k] = v[k];
+        }
+    };
+
+    auto pin_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) asm volatile("" : "+a"(acc[p]));
+    };
+    auto pin_acc4 = [&]() __attribute__((always_inline)) {      // after the output transform only tiles 0-3 are live
+#pragma unroll
+        for (int p = 0; p < 4; ++p) asm volatile("" : "+a"(acc[p]));
+    };
+
+    // One stage: transform row xi of this lane's tile for both k-groups, 32 MFMAs against the stage's 4 weight positions.
+    auto stage = [&](const float* xb, const float* wb, int xi) __attribute__((always_inline)) {
+        // rows of the 4x4 patch that B^T's row xi combines: (0, 2 : -) (1, 2 : +) (2, 1 : -) (1, 3 : -)
+        const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
+        const bool plus = xi == 1;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            f32x4 t[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 da = *reinterpret_cast<const f32x4*>(xb + poff + ra * XROW + c * RS + 8 * kg);
+                const f32x4 db = *reinterpret_cast<const f32x4*>(xb + poff + rb * XROW + c * RS + 8 * kg);
+                t[c] = plus ? da + db : da - db;
+            }
+            f32x4 v[4];
+            v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                const f32x4 bf = *reinterpret_cast<const f32x4*>(wb + nu * BN * CK + woff[kg]);
+                f32x16& d = acc[4 * xi + nu];
+                if (BMC_WINO_ABL & 1) { d[0] += bf[0] * v[nu][0] + bf[3] * v[nu][3]; continue; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j], v[nu][j], d, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- epilogue: Y = A^T M A in place, then bias / residual / ReLU / mask / accumulate and the stores
+    auto epilogue = [&](const TileIt& it) __attribute__((always_inline)) {
+        pin_acc();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float y[4];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {     // output row a = h2: t_a[nu]
+                float ta[4];
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu)
+                    ta[nu] = h2 == 0 ? (acc[nu][r] + acc[4 + nu][r]) + acc[8 + nu][r] : (acc[4 + nu][r] - acc[8 + nu][r]) - acc[12 + nu][r];
+                y[2 * h2] = (ta[0] + ta[1]) + ta[2];
+                y[2 * h2 + 1] = (ta[1] - ta[2]) - ta[3];
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[p][r] = y[p];
+            // one register column at a time: the 16 accumulator tiles are pinned to the accumulator half of the register file
+            // between columns (left alone, the compiler copies all 256 of them into the other half at once and spills)
+            pin_acc();
+        }
+        const int g = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
+        const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
+        float* const outb = a.out + (long long)it.b * a.out_batch_stride;
+        const float* const resb = a.residual.ptr ? src_batch_ptr(a.residual, it.b) : nullptr;
+        const float* const maskb = a.mask.ptr ? src_batch_ptr(a.mask, it.b) : nullptr;
+        const int co0 = it.nt * BN + 32 * wave + 4 * lh;         // + 8 rq
+        bool pok[4];
+        int pix[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int y = it.ty * TH + 2 * tr + (p >> 1), x = it.tx * TW + 2 * tc + (p & 1);
+            pok[p] = y < a.H && x < a.W;
+            pix[p] = y * a.W + x;
+        }
+        const bool simple = !resb && !maskb && !a.accumulate && (bias_pre || !biasg);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (simple) break;
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {        // two channel quads at a time: the register file is full of accumulators
+                f32x4 v[2];
+                bool ok[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int rq = 2 * hq + i;
+                    ok[i] = pok[p] && co0 + 8 * rq < a.Cout;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][k] = acc[p][4 * rq + k];
+                }
+                auto fetch = [&](const float* base, int off, f32x4 (&d)[2], float fill) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        d[i] = f32x4{fill, fill, fill, fill};
+                        if (ok[i]) d[i] = ldg16(base + off + co0 + 8 * (2 * hq + i));
+                    }
+                };
+                if (biasg && !bias_pre) {
+                    f32x4 d[2];
+                    fetch(biasg, 0, d, 0.f);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) v[i] += d[i];
+                }
+                if (resb) {
+                    f32x4 d[2];
+                    fetch(resb, pix[p] * a.residual.pix_stride, d, 0.f);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) v[i] += d[i];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[i][k] = fmaxf(v[i][k], 0.f);
+                }
+                if (maskb) {
+                    f32x4 d[2];
+                    fetch(maskb, pix[p] * a.mask.pix_stride, d, 1.f);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[i][k] = d[i][k] > 0.f ? v[i][k] : 0.f;
+                }
+                if (a.accumulate) {
+                    f32x4 d[2];
+                    fetch(outb, pix[p] * a.out_pix_stride, d, 0.f);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) v[i] += d[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[p][4 * (2 * hq + i) + k] = v[i][k];
+                pin_acc4();
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int co = co0 + 8 * rq;
+                if ((BMC_WINO_ABL & 8) && acc[p][4 * rq] != 12345.678f) continue;
+                if (pok[p] && co < a.Cout) {
+                    f32x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = acc[p][4 * rq + k];
+                    if (simple && a.relu) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(outb + pix[p] * a.out_pix_stride + co) = v;
+                }
+            }
+        init_acc();
+    };
+
+    // ---- prologue: first halo tile, first DW weight stages
+    xl_setup();
+    wl_setup();
+    load_x(0);
+    for (int k = 0; k < DW && wl_cnt < total_stages; ++k) issue_w();
+    dma_wait<0>();
+    __syncthreads();
+    init_acc();
+
+    int gs = 0, gc = 0;           // global stage / chunk counters of this workgroup
+    for (int tile = t_first; tile < t_hi; tile += t_stride) {
+        for (int c = 0; c < nchunks; ++c, ++gc) {
+            const float* const xb = Xb + (gc & 1) * XBUFA;
+            const bool more_x = gc + 1 < total_chunks;
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi, ++gs) {
+                // stage gs + DW -> the slot stage gs - 1 was read from (every wave is past the barrier that ended it)
+                const bool issued = wl_cnt < total_stages;
+                if (issued) issue_w();
+                // the next chunk's halo -> the X buffer chunk gc - 1 was read from: three more stages to land from HBM
+                if (xi == 0 && more_x) load_x((gc + 1) & 1);
+                stage(xb, Wb + (gs % NWR) * WSTAGE, xi);
+                // stage gs + 1 must have landed before the barrier publishes it: everything but what was issued after it
+                // (this stage's 8 DMA instructions, and at xi = 0 / 1 the 4 halo instructions issued behind stage gs + 1's
+                // DMA); at xi = 2 / 3 the halo is older than stage gs + 1 and lands with it, in time for the next chunk
+                if (!issued) dma_wait<0>();
+                else if (xi <= 1 && more_x) dma_wait<8 + NXD>();
+                else dma_wait<8>();
+                ring_publish();
+            }
+        }
+        epilogue(decode(tile));
+    }
+}
+
+// U = G g G^T for every (output channel, packed input channel) pair, in the kernel's streaming order.
+//   forward  (transposed == 0): rows = output channels co (< Coutpad), K = packed input channels k (kmap[k] -> ci, < 0 = zero);
+//   data gradient w.r.t. packed source channels [k0, k0 + nk) (transposed != 0): rows = n = k - k0 (< rows_pad), K = output
+//   channels co (padded to kpad), taps mirrored: g'[ky][kx] = w[co][kmap[k0 + n]][2 - ky][2 - kx].
+// out[g][K chunk][xi][nu][row][16], the 4 quads of a row XOR-swizzled with (row >> 2) & 3 (the kernel's LDS image).
+__global__ void pack_wino_kernel(const float* __restrict__ w, const int* __restrict__ kmap, int G, int Cout, int Cin, int kpad,
+                                 int rows_pad, int transposed, int k0, int nk, float* __restrict__ out) {
+    const long long total = (long long)G * (kpad / CK) * rows_pad * CK;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int kk = idx % CK;
+        long long r = idx / CK;
+        const int row = r % rows_pad; r /= rows_pad;
+        const int chunk = r % (kpad / CK);
+        const int g = r / (kpad / CK);
+        const int k = chunk * CK + kk;
+        float gt[3][3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) gt[i / 3][i % 3] = 0.f;
+        int co, ci;
+        if (!transposed) { co = row; ci = kmap ? kmap[k] : (k < Cin ? k : -1); }
+        else { co = k; ci = row < nk ? (kmap ? kmap[k0 + row] : k0 + row) : -1; }
+        if (co < Cout && ci >= 0) {
+            const float* p = w + (((long long)g * Cout + co) * Cin + ci) * 9;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) gt[i / 3][i % 3] = transposed ? p[8 - i] : p[i];
+        }
+        // rows of G: (1,0,0) (1/2,1/2,1/2) (1/2,-1/2,1/2) (0,0,1)
+        float gg[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            gg[0][b] = gt[0][b];
+            gg[1][b] = 0.5f * ((gt[0][b] + gt[1][b]) + gt[2][b]);
+            gg[2][b] = 0.5f * ((gt[0][b] - gt[1][b]) + gt[2][b]);
+            gg[3][b] = gt[2][b];
+        }
+        const int pos = row * CK + (((kk >> 2) ^ ((row >> 2) & 3)) << 2) + (kk & 3);
+        float* const o = out + (((long long)g * (kpad / CK) + chunk) * 16) * rows_pad * CK + pos;
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            const float u0 = gg[xi][0];
+            const float u1 = 0.5f * ((gg[xi][0] + gg[xi][1]) + gg[xi][2]);
+            const float u2 = 0.5f * ((gg[xi][0] - gg[xi][1]) + gg[xi][2]);
+            const float u3 = gg[xi][2];
+            o[(long long)(xi * 4 + 0) * rows_pad * CK] = u0;
+            o[(long long)(xi * 4 + 1) * rows_pad * CK] = u1;
+            o[(long long)(xi * 4 + 2) * rows_pad * CK] = u2;
+            o[(long long)(xi * 4 + 3) * rows_pad * CK] = u3;
+        }
+    }
+}
+
+}  // namespace
+
+// Called by bmc_conv (conv.hip) for math == BMC_MATH_FP32_WINO once the argument block is validated.
+int bmc_conv_wino_launch(ConvK k, int cus, hipStream_t st) {
+    k.tiles_x = (k.W + TW - 1) / TW;
+    k.tiles_y = (k.H + TH - 1) / TH;
+    k.ntn = k.Coutpad / BN;
+    const long long ntiles = (long long)k.B * k.tiles_x * k.tiles_y * k.ntn;
+    if (ntiles >= (1ll << 31)) { bmc_set_error("bmc_conv (winograd): too many tiles"); return -1; }
+    k.ntiles = (int)ntiles;
+    dim3 grid((unsigned)(ntiles < cus ? ntiles : cus)), block(256);      // one workgroup per CU (256 accumulator registers per lane)
+    hipLaunchKernelGGL(wino_conv_kernel, grid, block, 0, st, k);
+    return 0;
+}
+
+extern "C" int bmc_pack_weight_wino(const float* w, const int* kmap, int G, int Cout, int Cin, int Kpad, int Coutpad,
+                                    int transposed, int k0, int nk, float* out, bmc_stream_t s) {
+    BMC_CHECK_ARG(w && out && G >= 1 && Cout >= 1 && Cin >= 1, "bmc_pack_weight_wino: bad arguments");
+    BMC_CHECK_ARG(Kpad > 0 && Kpad % CK == 0 && Coutpad > 0 && Coutpad % 128 == 0,
+                  "bmc_pack_weight_wino: Kpad must be a multiple of 16 and the row count a multiple of 128");
+    BMC_CHECK_ARG(!transposed || (k0 >= 0 && nk >= 1 && nk <= Coutpad && Kpad >= Cout), "bmc_pack_weight_wino: bad transposed window");
+    const long long total = (long long)G * (Kpad / CK) * Coutpad * CK;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)s, w, kmap, G,
+                       Cout, Cin, Kpad, Coutpad, transposed, k0, nk, out);
+    BMC_CHECK_LAUNCH("bmc_pack_weight_wino");
+    return 0;
+}

@@ -132,7 +132,18 @@ int bmc_pack_weight_t(const float* w, const int* kmap, int G, int Cout, int Cin,
 #define BMC_MATH_FP32 0
 #define BMC_MATH_BF16 1
 #define BMC_MATH_BF16X6 3
+#define BMC_MATH_FP32_WINO 4 /* bmc_conv only: fp32 MFMA through the Winograd transform F(2x2, 3x3), below */
 int bmc_split_weight(const float* packed, void* out, long long nsteps, int Coutpad, int planes, bmc_stream_t s);
+
+/* Conv weights [G][Cout][Cin][3][3] -> the TRANSFORMED weights U = G g G^T of Winograd's F(2x2, 3x3) minimal filtering
+ * (16 values per (co, ci) pair instead of 9), in the streaming order of bmc_conv with math = BMC_MATH_FP32_WINO:
+ * [G][Kpad/16][4 (xi)][4 (nu)][Coutpad][16], quads of a 16-float row XOR-swizzled with (row >> 2) & 3.
+ *   transposed == 0: rows = output channels (Coutpad: multiple of 128), K = packed input channels through kmap (as
+ *                    bmc_pack_weight);  w_group_stride of the launch = Kpad * Coutpad * 16 floats;
+ *   transposed != 0: the data-gradient operator w.r.t. packed source channels [k0, k0 + nk): rows = those channels (padded
+ *                    to Coutpad), K = the Cout output channels (padded to Kpad), taps mirrored (as bmc_pack_weight_t). */
+int bmc_pack_weight_wino(const float* w, const int* kmap, int G, int Cout, int Cin, int Kpad, int Coutpad, int transposed,
+                         int k0, int nk, float* out, bmc_stream_t s);
 
 /* ---- implicit-GEMM convolution (fp32 MFMA) -------------------------------
  * Replaces F.conv2d at models/submodules.py:25-26,33-34,44-53,63-67,75 and
@@ -164,7 +175,10 @@ typedef struct bmc_conv_args {
     int math;                   /* BMC_MATH_FP32 (0): v_mfma_f32_32x32x2_f32 on the fp32 operands;
                                    BMC_MATH_BF16 (1): operands rounded to bf16, fp32 accumulate (v_mfma_f32_32x32x16_bf16);
                                    BMC_MATH_BF16X6 (3): each fp32 operand split exactly into three bf16 planes, six plane
-                                   products with fp32 accumulate -- fp32-equivalent (dropped terms ~ one fp32 rounding per product) */
+                                   products with fp32 accumulate -- fp32-equivalent (dropped terms ~ one fp32 rounding per product);
+                                   BMC_MATH_FP32_WINO (4): taps = 9, Coutpad % 128 == 0, wpacked from bmc_pack_weight_wino: fp32 MFMA
+                                   on Winograd-transformed operands, F(2x2, 3x3): 16 instead of 36 multiplies per 2x2 output
+                                   tile and channel pair, fp32 throughout (error vs float64 ~1.5x the direct fp32 kernel's) */
 } bmc_conv_args_t;
 int bmc_conv(const bmc_conv_args_t* host_args, bmc_stream_t s);
 

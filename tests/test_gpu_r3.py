@@ -342,3 +342,145 @@ def test_voxel_long_segments_are_sorted_cooperatively():
     assert np.array_equal(got[0].cpu().numpy(), ref)
     assert np.array_equal(d[0].cpu().numpy(), xa) and np.array_equal(d[1].cpu().numpy(), ya)
     assert dt < 0.5
+
+
+# ------------------------------------------------------------------ Winograd F(2x2, 3x3) convolution kernel (csrc/wino.hip)
+@pytest.fixture
+def force_wino():
+    """Send every eligible 3x3 launch through the Winograd kernel, whatever its size (default: only launches that fill the chip)."""
+    from bmc_hip import ops
+    old = ops.WINO_MIN_TILES
+    ops.WINO_MIN_TILES = 0
+    yield ops
+    ops.WINO_MIN_TILES = old
+
+
+@pytest.mark.parametrize("B,H,W,cins,cout,relu,res", [
+    (1, 8, 16, [128], 128, True, False),              # exactly one tile
+    (2, 9, 7, [128], 128, False, False),              # ragged in both directions, partial tiles only
+    (2, 19, 37, [128], 128, True, True),
+    (2, 13, 21, [16, 128, 16], 128, True, False),     # multi-source: narrow sources' data gradients stay on the direct kernel
+    (1, 11, 18, [16, 128, 16, 16, 32], 128, True, False),
+    (2, 5, 40, [256], 256, False, True),              # two channel tiles, 16 chunks
+    (3, 17, 33, [32], 128, False, False),
+])
+def test_winograd_conv_fwd_bwd_vs_float64(force_wino, B, H, W, cins, cout, relu, res):
+    dev = _gpu()
+    ops = force_wino
+    from bmc_hip.ops import ConvSpec, View
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(B, cout, H, W, generator=g) if res else None
+    go = torch.randn(B, cout, H, W, generator=g)
+    xs_c = [x.double().requires_grad_() for x in xs]
+    w_c, b_c = w.double().requires_grad_(), b.double().requires_grad_()
+    r_c = r.double().requires_grad_() if res else None
+    y = F.conv2d(torch.cat(xs_c, 1), w_c, b_c, padding=1)
+    if res:
+        y = y + r_c
+    if relu:
+        y = torch.relu(y)
+    y.backward(go.double())
+    assert ops.wino_ok(B, H, W, cout, 9)
+    xs_g = [nhwc(x).to(dev).requires_grad_() for x in xs]
+    w_g, b_g = w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    r_g = nhwc(r).to(dev).requires_grad_() if res else None
+    ops.PROFILE, ops.PROFILE_WINO[:] = [], [0, 0]
+    yg = ops.conv([View(x) for x in xs_g], w_g, b_g, ConvSpec.dense(*cins), relu=relu, residual=View(r_g) if res else None)
+    yg.backward(nhwc(go).to(dev))
+    ops.PROFILE = None
+    assert ops.PROFILE_WINO[0] >= 1 + sum(1 for c in cins if c % 128 == 0), ops.PROFILE_WINO      # the kernel under test really ran
+    assert rel_l2(yg.permute(0, 3, 1, 2), y) < 3e-6
+    for xg, xc in zip(xs_g, xs_c):
+        assert rel_l2(xg.grad.permute(0, 3, 1, 2), xc.grad) < 3e-6
+    assert rel_l2(w_g.grad, w_c.grad) < 2e-5
+    assert rel_l2(b_g.grad, b_c.grad) < 2e-5
+    if res:
+        assert rel_l2(r_g.grad.permute(0, 3, 1, 2), r_c.grad) < 2e-5
+
+
+def test_winograd_matches_direct_kernel_with_every_epilogue(force_wino):
+    """The same launches through the direct fp32 kernel and through the Winograd kernel: bias in / out of the accumulators
+    (per-group bias), residual with a batch rotation, ReLU, ReLU mask, accumulate, per-group weights, output written into a
+    channel window of a wider tensor -- each within fp32 rounding of the other."""
+    dev = _gpu()
+    ops = force_wino
+    from bmc_hip.ops import _packed_weight, _src, conv_raw, coutpad, ConvSpec
+    torch.manual_seed(12)
+    B, H, W, Cn = 4, 21, 35, 128
+    spec = ConvSpec.dense(Cn)
+    x = torch.randn(B, H, W, Cn, device=dev)
+    res = torch.randn(B, H, W, Cn, device=dev)
+    msk = torch.randn(B, H, W, Cn, device=dev)
+    w = torch.randn(2, Cn, Cn, 9, device=dev) * 0.03
+    bias = torch.randn(2, Cn, device=dev)
+    cp = coutpad(Cn)
+
+    def run(wino, G, relu, use_res, use_mask, accumulate, wide):
+        w4 = w[:G].contiguous()
+        wp = _packed_weight(w4, spec, None, wino=wino)
+        Co = 2 * Cn if wide else Cn
+        out = torch.full((B, H, W, Co), 0.25, device=dev)
+        conv_raw([_src(x, 0, Cn, 0, None, 0, B)], wp, spec.kpad * 9 * cp, bias[:G].contiguous(), Cn,
+                 out.data_ptr() + (4 * Cn if wide else 0), H * W * Co, Co, B, H, W, Cn, 9, relu=relu,
+                 residual=_src(res, 0, Cn, 2, B, 0, B) if use_res else None, bpg=B // G, accumulate=accumulate,
+                 mask=_src(msk, 0, Cn, 0, None, 0, B) if use_mask else None, wino=wino)
+        return out
+
+    for G, relu, use_res, use_mask, accumulate, wide in [(1, False, False, False, False, False), (1, True, True, False, False, False),
+                                                         (2, False, False, True, False, False), (2, True, True, False, True, True),
+                                                         (1, False, True, True, True, False)]:
+        a, b = run(True, G, relu, use_res, use_mask, accumulate, wide), run(False, G, relu, use_res, use_mask, accumulate, wide)
+        assert rel_l2(a, b) < 2e-6, (G, relu, use_res, use_mask, accumulate, wide)
+        if wide:
+            assert torch.equal(a[..., :Cn], torch.full_like(a[..., :Cn], 0.25))      # the other channel window is untouched
+
+
+@pytest.mark.parametrize("tag", ["bmcnet_nc16", "bmcnet_nc32"])
+def test_full_model_golden_unaffected_by_winograd_switch(force_wino, tag):
+    """n_c = 16 / 32 models have no 128-channel convolution: the switch must not change a thing (eligibility is by shape)."""
+    dev = _gpu()
+    ops = force_wino
+    assert not ops.wino_ok(4, 64, 64, 32, 9) and not ops.wino_ok(4, 64, 64, 16, 9)
+
+
+def test_winograd_residual_blocks_and_bie_at_nc128_vs_oracle(force_wino):
+    """BMCNet(4,128,1) on a small frame, two recurrent windows forward + backward with every 128-channel 3x3 launch (residual
+    blocks, input-fusion and head convolutions, their data gradients) on the Winograd kernel, against the CPU oracle."""
+    dev = _gpu()
+    ops = force_wino
+    from models.BMCNet import BMCNet
+    from oracle import bmc_oracle as O
+    scale, n_c, n_b, B, H, W = 4, 128, 1, 2, 20, 27
+    torch.manual_seed(81)
+    m = BMCNet(scale, n_c, n_b)
+    scaled_init(m, 2.5)
+    params = oracle_params(m)
+    g = torch.Generator().manual_seed(82)
+    frames = torch.poisson(torch.full((B, 3, 2, H, W), 0.4), generator=g)
+    gts = torch.poisson(torch.full((B, 3, 2, scale * H, scale * W), 0.4), generator=g)
+    xs = [frames[:, i:i + 2].transpose(1, 2) for i in range(2)]
+    loss_ref, preds_ref, _ = O.bptt_loss(params, xs, [gts[:, 1], gts[:, 2]], n_c, scale)
+    loss_ref.backward()
+    m.to(dev)
+    z = lambda c: torch.zeros(B, c, H, W, device=dev)
+    st = (z(n_c), z(n_c), z(n_c), z(2 * scale * scale))
+    loss = 0
+    ops.PROFILE, ops.PROFILE_WINO[:] = [], [0, 0]
+    for i in range(2):
+        st = m(xs[i].to(dev), *st, i == 0)
+        assert rel_l2(st[-1], preds_ref[i]) < 1e-4
+        loss = loss + F.mse_loss(st[-1], gts[:, i + 1].to(dev))
+    loss.backward()
+    ops.PROFILE = None
+    assert ops.PROFILE_WINO[0] > 40, ops.PROFILE_WINO
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
+    errs = {n: rel_l2(p.grad, params[n].grad) for n, p in m.named_parameters() if params[n].grad is not None}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    print("winograd BMCNet(4,128,1) 2 windows: %d winograd / %d direct conv launches, worst gradients %s" %
+          (ops.PROFILE_WINO[0], ops.PROFILE_WINO[1], [(n, "%.1e" % e) for n, e in worst]))
+    assert worst[0][1] < 1e-3, worst
