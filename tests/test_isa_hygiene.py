@@ -18,7 +18,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "bmcnet-esr_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
-FILES = ["conv", "conv_bf", "pgemm", "pgemm_bf", "chain", "conv1"]
+FILES = ["conv", "conv_bf", "pgemm", "pgemm_bf", "chain", "conv1", "wino"]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 
@@ -103,6 +103,8 @@ def test_m0_only_inside_handwritten_asm(isa):
     ("chain_kernelILi8ELb0E", 2), ("chain_kernelILi8ELb1E", 2),   # two workgroups per CU hide each other's LayerNorm phases
     ("conv1_kernelILi8E", 2),
     ("conv_bf_kernelILi9ELi128ELi8ELi3E", 2), ("pgemm_bf9x3_kernel", 3),
+    ("wino2_conv_kernel", 2),                   # 8 waves x (128 accumulators + <= 128 others): two waves per SIMD is the point of it
+    ("wino_conv_kernel", 1),                    # 4 waves x 256 accumulators
 ])
 def test_occupancy_budgets(isa, frag, min_occ):
     hits = [(n, k) for _, n, k in _all(isa) if frag in n]
