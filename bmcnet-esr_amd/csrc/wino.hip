@@ -545,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
 #pragma unroll
         for (int k = 0; k < NXD; ++k) {
             const void* src = (xokm >> k) & 1 ? static_cast<const void*>(base + xoff[k]) : static_cast<const void*>(g_zero4w);
-            dma16v(src, xb_lds + (unsigned)((buf * XBUFA + (wave * NXD + k) * 256) * 4));
+            if (!(BMC_WINO_ABL & 4)) dma16v(src, xb_lds + (unsigned)((buf * XBUFA + (wave * NXD + k) * 256) * 4));
         }
         c_in += CK;
         if (++xl_chunk == nchunks) {
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     auto issue_w = [&]() {
         const float* p = wl_base + ((long long)wl_sub * 4 + (wave >> 1)) * wrow + (wave & 1) * 1024;
         const unsigned dst = wb_lds + (unsigned)(((wl_cnt % NWR) * WSTAGE + (wave >> 1) * BN * CK + (wave & 1) * 1024) * 4);
-        dma4k(p, (unsigned)(lane * 16), dst);
+        if (!(BMC_WINO_ABL & 2)) dma4k(p, (unsigned)(lane * 16), dst);
         ++wl_cnt;
         if (++wl_sub == 4 * nchunks) {
             wl_tile += t_stride;
@@ -612,21 +612,33 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         d[2] = *reinterpret_cast<const f32x4*>(xb + poffb + ra * XROW);
         d[3] = *reinterpret_cast<const f32x4*>(xb + poffb + rb * XROW);
     };
+    // (VALU instructions are the scarce resource here -- beside fp32 MFMAs each costs ~16-20 cycles of matrix-pipe time
+    //  (ablation) -- so the wave-uniform sign of the column combination is a multiplier of an exact fma, not a
+    //  select between a sum and a difference: 12 instructions per thread and stage)
+    const float psgn = pnu == 1 ? 1.f : -1.f;
     auto produce_store = [&](float* vb, int xi, const f32x4 (&d)[4]) __attribute__((always_inline)) {
         const f32x4 ta = xi == 1 ? d[0] + d[1] : d[0] - d[1];      // (B^T d) at column ca
         const f32x4 tb = xi == 1 ? d[2] + d[3] : d[2] - d[3];      //          at column cb
-        *reinterpret_cast<f32x4*>(vb + vst) = pnu == 1 ? ta + tb : ta - tb;
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(tb[k], psgn, ta[k]);
+        *reinterpret_cast<f32x4*>(vb + vst) = v;
     };
 
     auto stage = [&](const float* vb, const float* wb, int xi, const float* xb_n, float* vb_n, int xi_n) __attribute__((always_inline)) {
         f32x4 uf[4], vf[4][2], d[4];
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
+            if (BMC_WINO_ABL & 32) {
+                uf[nu] = f32x4{1.f, 2.f, 3.f, 4.f}; vf[nu][0] = vf[nu][1] = f32x4{4.f, 3.f, 2.f, 1.f};
+                asm volatile("" : "+v"(uf[nu]), "+v"(vf[nu][0]), "+v"(vf[nu][1]));
+                continue;
+            }
             uf[nu] = *reinterpret_cast<const f32x4*>(wb + nu * BN * CK + woff);
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) vf[nu][tb] = *reinterpret_cast<const f32x4*>(vb + nu * 32 * CK + tb * 16 * CK + voff);
         }
-        if (xb_n) produce_load(xb_n, xi_n, d);
+        if (!(BMC_WINO_ABL & 16)) produce_load(xb_n, xi_n, d);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
@@ -634,8 +646,9 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int tb = 0; tb < 2; ++tb)
-                    acc[4 * xi + nu][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[nu][m], vf[nu][tb][m], acc[4 * xi + nu][tb], 0, 0, 0);
-            if (nu == 1 && xb_n) produce_store(vb_n, xi_n, d);
+                    if (BMC_WINO_ABL & 1) acc[4 * xi + nu][tb][m] += uf[nu][m] * vf[nu][tb][m];
+                    else acc[4 * xi + nu][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[nu][m], vf[nu][tb][m], acc[4 * xi + nu][tb], 0, 0, 0);
+            if (nu == 1 && !(BMC_WINO_ABL & 16)) produce_store(vb_n, xi_n, d);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -646,6 +659,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         for (int tb = 0; tb < 2; ++tb) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (BMC_WINO_ABL & 128) break;
                 float y[4];
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
@@ -728,7 +742,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p)
-                if (pok[p]) *reinterpret_cast<f32x4*>(outb + pix[p] * a.out_pix_stride + co) = v[p];
+                if (pok[p] && !((BMC_WINO_ABL & 8) && v[p][0] != 12345.678f)) *reinterpret_cast<f32x4*>(outb + pix[p] * a.out_pix_stride + co) = v[p];
         }
         init_acc();
     };
@@ -759,12 +773,13 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
                 if (issued) issue_w();
                 if (xi == 0 && more_x) load_x((gc + 1) & 1);
                 const bool has_next = gs + 1 < total_stages;
-                const float* const xb_n = !has_next ? nullptr : (xi == 3 ? Xb + ((gc + 1) & 1) * XBUFA : xb);
+                // (the very last stage produces a V nobody reads, from this chunk's halo: no branch around the production)
+                const float* const xb_n = (xi == 3 && has_next) ? Xb + ((gc + 1) & 1) * XBUFA : xb;
                 stage(Vb + (gs & 1) * VSTAGE, Wb + (gs % NWR) * WSTAGE, xi, xb_n, Vb + ((gs + 1) & 1) * VSTAGE, (xi + 1) & 3);
                 if (!issued) dma_wait<0>();
                 else if (xi <= 1 && more_x) dma_wait<4 + NXD>();
                 else dma_wait<4>();
-                ring_publish();
+                if (BMC_WINO_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else ring_publish();
             }
         }
         epilogue(decode(tile));
