@@ -146,15 +146,17 @@ def _dgrad(g_src, w4, spec, src_index, owner, out, B, residual=None, mask=None, 
              flops=2.0 * B * H * W * spec.real_nch[src_index] * taps * Cout, wino=wn)
 
 
-def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, w_param, b_param, G=1, w_shape=None):
+def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, w_param, b_param, G=1, w_shape=None, keep=()):
     # (w_param / b_param: a parameter, None, or for G > 1 a tuple of the G parameters of the weight groups)
     """Weight gradient + bias gradient (column sums of the same A operand, taken from the tiles the pixel-reduction
     GEMM stages anyway) -> (dW, db) for autograd; None where the sums went straight into the leaf parameters' .grad
     (ops.reduce_wgrad).  G > 1 (stacked per-group weights): w_param None, result [G, ...]."""
-    slabs, nsplit, _, bsl = pgemm_raw(a_src, x_srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
-                                      flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)
-    return ops.reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bsl, w_param, b_param,
-                            w_shape if w_shape is not None else w_param.shape)
+    # keep: the operand tensors behind a_src / x_srcs (ops.wgrad_side: small launches run on the side stream)
+    with ops.wgrad_side(B * H * W, ops._flat_params(w_param, b_param), keep):
+        slabs, nsplit, _, bsl = pgemm_raw(a_src, x_srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
+                                          flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)
+        return ops.reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bsl, w_param, b_param,
+                                w_shape if w_shape is not None else w_param.shape)
 
 
 class BIETwinFn(torch.autograd.Function):
@@ -251,10 +253,10 @@ class BIETwinFn(torch.autograd.Function):
         w_dc = torch.cat([da, w_ut], 2).view(B2, Cn, 2 * Cn, 1)
         _conv([X(v12), X(g_x, mod=n, B=B2)], w_dc, s2, None, None, dc12, B2, bpg=1)
         # ---- unclustering(cat[c1, c2]) + xs: weight gradient
-        dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu)
+        dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu, keep=(g_x, c12))
         # ---- value convs (two weight groups)
         dwv, dbv = _wgrad(X(dv12), [X(x12)], s1, B2, H, W, 1, Cn, dev, ctx.vparams[:2], ctx.vparams[2:], G=2,
-                          w_shape=(2, Cn, Cn, 1, 1))
+                          w_shape=(2, Cn, Cn, 1, 1), keep=(dv12, x12))
         if ctx.fused:
             # ---- clustering, LayerNorm, convf: ONE data-gradient launch (csrc/chain.hip); y12 holds yhat, stats rstd.
             # dx12 = conv_f^T (second half of its inputs), dxs = skip + conv_f^T (first half) summed over both halves.
@@ -274,13 +276,14 @@ class BIETwinFn(torch.autograd.Function):
             lib.call(lib._chain_affine, "bmc_chain_affine_grads", Gm.data_ptr(), dbc_t.data_ptr(), wc.detach().data_ptr(),
                      gamma.detach().data_ptr(), beta.detach().data_ptr(), Cn, o_w.data_ptr(),
                      o_b.data_ptr() if o_b is not None else None, o_g.data_ptr(), o_bt.data_ptr(), acc, _stream())
-            dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf)
+            dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf,
+                              keep=(dz12, xs, x12))
             _dgrad(X(dv12), w_v, s1, 0, w_v, dx12, B2, bpg=n, accumulate=True)                          # dx12 += value convs
         else:
             dx12 = ops.grad_slot(ctx.gslot, x12)
             _dgrad(X(dv12), w_v, s1, 0, w_v, dx12, B2, bpg=n)                                           # dx12  =
             # ---- clustering, LayerNorm, convf
-            dwc, dbc = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev, p_wc, p_bc)
+            dwc, dbc = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev, p_wc, p_bc, keep=(dc12, y12))
             dy12 = new(B2)
             _dgrad(X(dc12), w_c, s1, 0, o_wc, dy12, B2)
             dz12 = new(B2)
@@ -295,17 +298,18 @@ class BIETwinFn(torch.autograd.Function):
                 ln_acc = 0
             lib.call(lib._ln_bwd, "bmc_layernorm_bwd", dy12.data_ptr(), z12.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
                      B2 * H * W, Cn, dz12.data_ptr(), ws.data_ptr(), o_g.data_ptr(), o_bt.data_ptr(), ln_acc, _stream())
-            dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf)
+            dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf,
+                              keep=(dz12, xs, x12))
             dxs = new(n)
             _dgrad(X(dz12, b0=0, B=n), w_f, s2, 0, o_wf, dxs, n, residual=X(g_x))                        # dxs  = skip + half 0
             _dgrad(X(dz12, b0=n, B=n), w_f, s2, 0, o_wf, dxs, n, accumulate=True)                        # dxs += half 1
             _dgrad(X(dz12, shift=n, mod=B2), w_f, s2, 1, o_wf, dx12, B2, accumulate=True)                # dx12 += (rotated)
         # ---- residual block, upstream gradient = batch-rotated g_o
         g_r = X(g_o, shift=n, mod=B2)
-        dw2, db2 = _wgrad(g_r, [X(t12)], s1, B2, H, W, 9, Cn, dev, p_rw2, p_rb2)
+        dw2, db2 = _wgrad(g_r, [X(t12)], s1, B2, H, W, 9, Cn, dev, p_rw2, p_rb2, keep=(g_o, t12))
         dt = new(B2)
         _dgrad(g_r, w_r2, s1, 0, o_rw2, dt, B2, mask=X(t12))
-        dw1, db1 = _wgrad(X(dt), [X(x12)], s1, B2, H, W, 9, Cn, dev, p_rw1, p_rb1)
+        dw1, db1 = _wgrad(X(dt), [X(x12)], s1, B2, H, W, 9, Cn, dev, p_rw1, p_rb1, keep=(dt, x12))
         _dgrad(X(dt), w_r1, s1, 0, o_rw1, dx12, B2, residual=g_r, accumulate=True)                       # dx12 += conv1^T + skip
         v = lambda t, ref: None if t is None else t.view(ref.shape)
         gv = (None,) * 4 if dwv is None else (dwv[0].reshape(wv1.shape), dbv[0], dwv[1].reshape(wv2.shape), dbv[1])
@@ -382,8 +386,8 @@ class BIEFirstFn(torch.autograd.Function):
         w_ut = wu.detach().view(Cn, 2, Cn).permute(1, 2, 0).repeat_interleave(n, 0)           # [B2, C (c_i), C (co)]
         w_dc = torch.cat([torch.cat([da, torch.zeros_like(da)], 0), w_ut], 2).view(B2, Cn, 2 * Cn, 1)
         _conv([X(v1, mod=n, B=B2), X(g_x, mod=n, B=B2)], w_dc, s2, None, None, dc12, B2, bpg=1)
-        dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu)
-        dwv1, dbv1 = _wgrad(X(dv1), [X(x12, b0=0, B=n)], s1, n, H, W, 1, Cn, dev, p_wv1, p_bv1)
+        dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu, keep=(g_x, c12))
+        dwv1, dbv1 = _wgrad(X(dv1), [X(x12, b0=0, B=n)], s1, n, H, W, 1, Cn, dev, p_wv1, p_bv1, keep=(dv1, x12))
         # ---- clustering, LayerNorm, convf (csrc/chain.hip), as in BIETwinFn
         dz12, dx12, dxs = chain_bwd(X(dc12), yhat, rstd, gamma.detach(), wf, wc, X(g_x), n, H, W, Cn, dev)
         Gm, dbc_t = _wgrad(X(dc12), [X(yhat)], s1, B2, H, W, 1, Cn, dev, None, None, w_shape=(Cn, Cn))
@@ -399,13 +403,14 @@ class BIEFirstFn(torch.autograd.Function):
         lib.call(lib._chain_affine, "bmc_chain_affine_grads", Gm.data_ptr(), dbc_t.data_ptr(), wc.detach().data_ptr(),
                  gamma.detach().data_ptr(), beta.detach().data_ptr(), Cn, o_w.data_ptr(),
                  o_b.data_ptr() if o_b is not None else None, o_g.data_ptr(), o_bt.data_ptr(), acc, _stream())
-        dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf)
+        dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf,
+                          keep=(dz12, xs, x12))
         _dgrad(X(dv1), w_v1, s1, 0, o_wv1, dx12, n, accumulate=True)                                     # dx12[first] += value conv
         # ---- residual block (second half), upstream gradient = g_o
-        dw2, db2 = _wgrad(X(g_o), [X(t2)], s1, n, H, W, 9, Cn, dev, p_rw2, p_rb2)
+        dw2, db2 = _wgrad(X(g_o), [X(t2)], s1, n, H, W, 9, Cn, dev, p_rw2, p_rb2, keep=(g_o, t2))
         dt = new(n)
         _dgrad(X(g_o), w_r2, s1, 0, o_rw2, dt, n, mask=X(t2))
-        dw1, db1 = _wgrad(X(dt), [X(x12, b0=n, B=n)], s1, n, H, W, 9, Cn, dev, p_rw1, p_rb1)
+        dw1, db1 = _wgrad(X(dt), [X(x12, b0=n, B=n)], s1, n, H, W, 9, Cn, dev, p_rw1, p_rb1, keep=(dt, x12))
         _dgrad(X(dt), w_r1, s1, 0, o_rw1, dx12, n, residual=X(g_o), accumulate=True, out_b0=n)           # dx12[second] += conv1^T + skip
         v = lambda t, ref: None if t is None else t.view(ref.shape)
         return (dx12, dxs, dw1, db1, dw2, db2, dwf, dbf, dgamma, dbeta, v(dwc, wc), dbc, dwu, dbu, v(dwv1, wv1), dbv1, None, None)

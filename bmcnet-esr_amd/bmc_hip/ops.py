@@ -335,7 +335,7 @@ def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stri
     a.accumulate = int(accumulate)
     e0 = _prof_begin()
     lib.call(lib._conv, "bmc_conv", C.byref(a), _stream())
-    _prof_end(e0, "conv_kernel<%d,%d>" % (taps, 32 if a.Coutpad == 32 else 128), flops)
+    _prof_end(e0, "wino_conv<9,128>" if wino else "conv_kernel<%d,%d>" % (taps, 32 if a.Coutpad == 32 else 128), flops)
     if PROFILE is not None and e0 is not None:
         PROFILE_WINO[0 if wino else 1] += 1
 
@@ -482,6 +482,103 @@ def sink_group(params, full=True):
     return [p.grad for p in params], acc
 
 
+# --------------------------------------------------------------------------
+# weight gradients beside the data-gradient chain (small frames)
+# --------------------------------------------------------------------------
+# Nothing in backward waits for a weight gradient: it only has to be in .grad when the optimizer steps.  At the frame sizes
+# of BASELINE configs[3] (31x56) and of the reference's own NFS config (45x80) every launch is a single wave of small
+# tiles that cannot fill the chip, and the step is a chain of ~4 700 of them: there the pixel-reduction GEMMs and their
+# slab reductions (a third of the step) run on a SIDE stream beside the convolutions of the data-gradient chain instead
+# of between them.  (At 180x240 every kernel fills all 256 CUs by itself: measured neutral in round 2, and the operands
+# kept alive until the join would cost memory -- off there.)  Protocol: the side stream waits for the launch stream before
+# every weight-gradient launch (its operands were just produced there); operand tensors are kept referenced until the
+# join; the join -- launch stream waits for the side stream -- is an autograd-engine callback at the end of the backward
+# pass that armed it, i.e. before anything (optimizer, GradAllReducer.finish) reads a .grad.  Only for gradients that go
+# straight into leaf parameters' .grad (sink route): a gradient handed back to autograd stays on the launch stream.
+# Accumulation order into a .grad = issue order on the one side stream = backward's order: deterministic as before.
+WGRAD_SIDE = os.environ.get("BMC_WGRAD_STREAM", "auto")          # "0" never, "1" always, "auto" small problems only
+WGRAD_SIDE_MAX_PIXELS = int(os.environ.get("BMC_WGRAD_STREAM_MAX_PIXELS", 1 << 17))
+
+
+class _SideState:
+    __slots__ = ("stream", "keep", "armed", "side")
+
+    def __init__(self, dev):
+        self.stream, self.keep, self.armed, self.side = torch.cuda.Stream(device=dev), [], False, False
+
+    def join(self):
+        if self.side:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep.clear()
+        self.armed = False
+
+
+_SIDE = {}
+
+
+class _SideCtx:
+    __slots__ = ("st", "cm")
+
+    def __init__(self, st):
+        self.st = st
+
+    def __enter__(self):
+        self.st.stream.wait_stream(torch.cuda.current_stream())
+        self.cm = torch.cuda.stream(self.st.stream)
+        self.cm.__enter__()
+        return self.st
+
+    def __exit__(self, *exc):
+        return self.cm.__exit__(*exc)
+
+
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOCTX = _NoCtx()
+
+
+def wgrad_side(npx, params, keep=()):
+    """Context for one weight-gradient launch (+ its reduction): the side stream when the launch is small, all its
+    destinations are sink parameters and an autograd backward pass is running (the join hangs on its end), else nothing.
+    keep: the operand tensors of the launch (referenced until the join)."""
+    if WGRAD_SIDE == "0" or torch._C._current_graph_task_id() < 0:
+        return _NOCTX
+    dev = _cur_dev()
+    st = _SIDE.get(dev)
+    if st is None:
+        st = _SIDE[dev] = _SideState(dev)
+    if not st.armed:
+        # the FIRST weight-gradient launch of a backward pass decides for the whole pass: one parameter's gradient is
+        # accumulated by launches of different batch sizes (conv_fs: B and 3B), and its read-modify-writes must not be
+        # split over two streams
+        st.side = WGRAD_SIDE == "1" or npx <= WGRAD_SIDE_MAX_PIXELS
+        torch.autograd.Variable._execution_engine.queue_callback(st.join)
+        st.armed = True
+    if not st.side:
+        return _NOCTX
+    ps = [p for p in params if p is not None]
+    if not ps or not all(is_sink(p) for p in ps):
+        return _NOCTX
+    st.keep.extend(keep)
+    return _SideCtx(st)
+
+
+def _flat_params(*ps):
+    out = []
+    for p in ps:
+        if isinstance(p, (tuple, list)):
+            out.extend(p)
+        elif p is not None:
+            out.append(p)
+    return out
+
+
 def reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bias_slabs, w_param, b_param, w_shape):
     """Sum the pixel-reduction GEMM's slabs into the weight (+ bias) gradient.  -> (dw, db) for autograd; entries are
     None where the gradient went straight into a leaf parameter's .grad (see above).  w_param / b_param may be tuples of
@@ -595,12 +692,13 @@ class ConvFn(torch.autograd.Function):
             srcs = [_src(t, *v, B) for t, v in zip(src_ts, meta.views)]
             a_src = _src(g, 0, Cout, 0, None, 0, B)
             wb = ctx.has_bias and need[2]
-            r_pg = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
-                             flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=wb)
-            slabs, nsplit = r_pg[0], r_pg[1]
             wp_, bp_ = ctx.params
-            dw, db = reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, r_pg[3] if wb else None, wp_, bp_ if wb else None,
-                                  weight.shape)
+            with wgrad_side(B * H * W, _flat_params(wp_, bp_ if wb else None), (g, *src_ts)):
+                r_pg = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
+                                 flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=wb)
+                slabs, nsplit = r_pg[0], r_pg[1]
+                dw, db = reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, r_pg[3] if wb else None, wp_, bp_ if wb else None,
+                                      weight.shape)
             bias_done = wb
         if ctx.has_bias and need[2] and not bias_done:
             bpg = B // G
@@ -742,9 +840,10 @@ def _wgrad_plain(g, x, spec, w_param, b_param, taps):
     gradient (column sums of g) from one pgemm launch."""
     B, H, W, Cout = g.shape
     dev = g.device
-    slabs, nsplit, _, bsl = pgemm_raw(_src(g, 0, Cout, 0, None, 0, B), [_src(x, 0, x.shape[3], 0, None, 0, B)], B, H, W, taps,
-                                      B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)
-    return reduce_wgrad(slabs, nsplit, 1, taps, Cout, spec, dev, bsl, w_param, b_param, w_param.shape)
+    with wgrad_side(B * H * W, [w_param, b_param], (g, x)):
+        slabs, nsplit, _, bsl = pgemm_raw(_src(g, 0, Cout, 0, None, 0, B), [_src(x, 0, x.shape[3], 0, None, 0, B)], B, H, W, taps,
+                                          B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)
+        return reduce_wgrad(slabs, nsplit, 1, taps, Cout, spec, dev, bsl, w_param, b_param, w_param.shape)
 
 
 GRAD_PAIRS = os.environ.get("BMC_GRAD_PAIRS", "1") != "0"

@@ -484,3 +484,47 @@ def test_winograd_residual_blocks_and_bie_at_nc128_vs_oracle(force_wino):
     print("winograd BMCNet(4,128,1) 2 windows: %d winograd / %d direct conv launches, worst gradients %s" %
           (ops.PROFILE_WINO[0], ops.PROFILE_WINO[1], [(n, "%.1e" % e) for n, e in worst]))
     assert worst[0][1] < 1e-3, worst
+
+
+# ------------------------------------------------------------------ weight gradients on a side stream (small frames)
+@pytest.mark.parametrize("math", ["fp32", "bf16"])
+def test_side_stream_weight_gradients_are_bit_identical(math):
+    """Small problems run their weight-gradient GEMMs + slab reductions on a side stream beside the data-gradient chain
+    (bmc_hip.ops.wgrad_side).  Same kernels, same accumulation order per parameter: the whole step -- loss and every
+    parameter gradient, three steps of Adam -- must be bit-identical to the single-stream run, in repeated runs."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from models.BMCNet import BMCNet
+    from train_step import bptt_step
+    ops.set_math(math)
+    scale, n_c, n_b, B, L, H, W = 4, 128, 2, 2, 4, 31, 56
+    g = torch.Generator().manual_seed(91)
+    inp = torch.poisson(torch.full((B, L, 2, H, W), 0.5), generator=g).to(dev)
+    gt = torch.poisson(torch.full((B, L, 2, scale * H, scale * W), 0.5), generator=g).to(dev)
+
+    def run(mode):
+        old = ops.WGRAD_SIDE
+        ops.WGRAD_SIDE = mode
+        try:
+            torch.manual_seed(92)
+            m = BMCNet(scale, n_c, n_b).to(dev)
+            scaled_init(m, 2.0)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-5, amsgrad=True)
+            losses = []
+            for _ in range(3):
+                loss, _ = bptt_step(m, opt, inp, gt, n_c, scale)
+                losses.append(loss.item())
+            torch.cuda.synchronize()
+            return losses, [p.grad.clone() for p in m.parameters() if p.grad is not None], [p.detach().clone() for p in m.parameters()]
+        finally:
+            ops.WGRAD_SIDE = old
+
+    l0, g0, p0 = run("0")
+    for rep in range(2):
+        l1, g1, p1 = run("1")
+        assert l0 == l1
+        assert len(g0) == len(g1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+        assert all(torch.equal(a, b) for a, b in zip(p0, p1))
+    la, ga, pa = run("auto")         # 31x56: the automatic choice is the side stream
+    assert la == l0 and all(torch.equal(a, b) for a, b in zip(ga, g0))
+    assert ops._SIDE and not next(iter(ops._SIDE.values())).armed and not next(iter(ops._SIDE.values())).keep
