@@ -20,10 +20,25 @@ CK = 16
 _cur_dev = torch._C._cuda_getDevice      # torch.cuda.current_device() without its Python-level lazy-init wrapper
 
 
+_STREAM_OVERRIDE = None      # raw handle of the side stream while a weight-gradient launch is being issued there (wgrad_side)
+
+
 def _stream():
     # torch.cuda.current_stream().cuda_stream without the Python-level wrappers (9 us -> 0.3 us per launch: the step is
     # host-bound at small frame sizes)
+    if _STREAM_OVERRIDE is not None:
+        return _STREAM_OVERRIDE
     return torch._C._cuda_getCurrentRawStream(_cur_dev())
+
+
+def _on_side(*tensors):
+    """Workspaces torch allocated (on the launch stream's pool) for kernels that run on the side stream: the allocator must
+    not hand their memory out again before the side stream is done with it."""
+    if _STREAM_OVERRIDE is not None:
+        st = _SIDE[_cur_dev()].stream
+        for t in tensors:
+            if t is not None:
+                t.record_stream(st)
 
 
 def _need_gpu(t: torch.Tensor):
@@ -135,18 +150,26 @@ PROFILE = None
 PROFILE_WINO = [0, 0]       # while PROFILE is a list: conv launches that took the Winograd kernel / the direct kernels
 
 
+def _prof_record(e):
+    # on the stream the launch really goes to (torch's current stream, or the side stream of wgrad_side)
+    if _STREAM_OVERRIDE is not None:
+        e.record(_SIDE[_cur_dev()].stream)
+    else:
+        e.record()
+
+
 def _prof_begin():
     if PROFILE is None:
         return None
     e = torch.cuda.Event(enable_timing=True)
-    e.record()
+    _prof_record(e)
     return e
 
 
 def _prof_end(e0, kind, flops):
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
+        _prof_record(e1)
         PROFILE.append((kind, flops, e0, e1))
 
 
@@ -234,7 +257,7 @@ def stacked(owners, build, tag=""):
 # F(2x2, 3x3) (csrc/wino.hip: 16 instead of 36 multiplies per 2x2 output tile and channel pair, fp32 throughout; one
 # 256-accumulator workgroup per CU, so small problems stay on the direct kernel).  BMC_WINO=0 switches it off.
 WINO = os.environ.get("BMC_WINO", "1") != "0"
-WINO_MIN_TILES = int(os.environ.get("BMC_WINO_MIN_TILES", 512))
+WINO_MIN_TILES = int(os.environ.get("BMC_WINO_MIN_TILES", 200))   # >= ~1 tile per CU on most of the chip (31x56 at 4B: 256 tiles, +3.5 %)
 
 
 def wino_ok(B, H, W, Cout, taps):
@@ -396,6 +419,7 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
         p.bias_slabs = bslabs.data_ptr()
     else:
         p.bias_slabs = None
+    _on_side(slabs, bslabs)
     e0 = _prof_begin()
     lib.call(lib._pgemm, "bmc_pgemm", C.byref(p), _stream())
     _prof_end(e0, "pgemm_kernel<%d>" % taps, flops)
@@ -479,6 +503,8 @@ def sink_group(params, full=True):
             elif not p.grad.is_contiguous():
                 p.grad = p.grad.contiguous()
         acc = 1
+        if any(missing) and _STREAM_OVERRIDE is not None:
+            _SIDE[_cur_dev()].follow_main()         # the zero fill ran on the launch stream: the side stream's adds come after it
     return [p.grad for p in params], acc
 
 
@@ -496,15 +522,23 @@ def sink_group(params, full=True):
 # pass that armed it, i.e. before anything (optimizer, GradAllReducer.finish) reads a .grad.  Only for gradients that go
 # straight into leaf parameters' .grad (sink route): a gradient handed back to autograd stays on the launch stream.
 # Accumulation order into a .grad = issue order on the one side stream = backward's order: deterministic as before.
-WGRAD_SIDE = os.environ.get("BMC_WGRAD_STREAM", "auto")          # "0" never, "1" always, "auto" small problems only
+WGRAD_SIDE = os.environ.get("BMC_WGRAD_STREAM", "0")             # "0" never (default, see below), "1" always, "auto" small fp32 problems
 WGRAD_SIDE_MAX_PIXELS = int(os.environ.get("BMC_WGRAD_STREAM_MAX_PIXELS", 1 << 17))
 
 
 class _SideState:
-    __slots__ = ("stream", "keep", "armed", "side")
+    __slots__ = ("stream", "raw", "event", "keep", "armed", "side")
 
     def __init__(self, dev):
-        self.stream, self.keep, self.armed, self.side = torch.cuda.Stream(device=dev), [], False, False
+        self.stream = torch.cuda.Stream(device=dev)
+        self.raw = self.stream.cuda_stream
+        self.event = torch.cuda.Event()
+        self.keep, self.armed, self.side = [], False, False
+
+    def follow_main(self):
+        """Everything queued on the launch stream so far happens before what the side stream is given next."""
+        self.event.record()
+        self.stream.wait_event(self.event)
 
     def join(self):
         if self.side:
@@ -517,19 +551,24 @@ _SIDE = {}
 
 
 class _SideCtx:
-    __slots__ = ("st", "cm")
+    """Launches issued inside go to the side stream: NOT by switching torch's current stream (two Python context switches per
+    launch cost more host time than the overlap buys at these sizes) but by overriding the raw stream handle our launches
+    take; torch-side allocations stay on the launch stream's pool and are handed over with _on_side()."""
+    __slots__ = ("st",)
 
     def __init__(self, st):
         self.st = st
 
     def __enter__(self):
-        self.st.stream.wait_stream(torch.cuda.current_stream())
-        self.cm = torch.cuda.stream(self.st.stream)
-        self.cm.__enter__()
+        global _STREAM_OVERRIDE
+        self.st.follow_main()
+        _STREAM_OVERRIDE = self.st.raw
         return self.st
 
     def __exit__(self, *exc):
-        return self.cm.__exit__(*exc)
+        global _STREAM_OVERRIDE
+        _STREAM_OVERRIDE = None
+        return False
 
 
 class _NoCtx:
@@ -557,7 +596,7 @@ def wgrad_side(npx, params, keep=()):
         # the FIRST weight-gradient launch of a backward pass decides for the whole pass: one parameter's gradient is
         # accumulated by launches of different batch sizes (conv_fs: B and 3B), and its read-modify-writes must not be
         # split over two streams
-        st.side = WGRAD_SIDE == "1" or npx <= WGRAD_SIDE_MAX_PIXELS
+        st.side = WGRAD_SIDE == "1" or (npx <= WGRAD_SIDE_MAX_PIXELS and MATH == 0)
         torch.autograd.Variable._execution_engine.queue_callback(st.join)
         st.armed = True
     if not st.side:
