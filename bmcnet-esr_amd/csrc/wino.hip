@@ -515,25 +515,35 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         return it;
     };
 
-    // ---- X loader: 16 DMA instructions per halo tile, 2 per wave (layout and quad stream as in the kernel above)
+    // ---- X loader: 16 DMA instructions per halo tile, 2 per wave (layout and quad stream as in the kernel above), in the
+    // cheap form "uniform base (SGPR pair) + per-lane 32-bit offset": EVERY lane fetches a valid address -- pixels outside
+    // the image the clamped edge pixel, pad quads the image's first quad -- and the lanes of out-of-image pixels overwrite
+    // their LDS quad with zeros once the chunk has landed, before the barrier that publishes it (zero_x below; interior
+    // tiles: nobody).  No per-lane 64-bit addresses, no selects: this kernel has no registers to spare (128 + 128).
     constexpr int NXD = 2;
     int xl_tile = t_first, xl_chunk = 0, s_idx = 0, c_in = 0, snch = 0;
     TileIt xl_it = decode(t_first);
     const float* sbase = nullptr;
-    unsigned xoff[NXD];
-    unsigned xokm = 0;
+    unsigned xoff[NXD];               // byte offset from the source's batch pointer (+ channel chunk)
+    unsigned xzm = 0;                 // bit k: instruction k's quad belongs to a pixel outside the image (of the tile being LOADED)
+    unsigned xzm_landed = 0;          // the same for the chunk in flight (zero_x consumes it; a tile's chunks share it)
     auto src_select = [&]() {
         const SrcDev S = tab[s_idx];
         sbase = src_batch_ptr(S, xl_it.b); snch = S.nch;
         const int y0 = xl_it.ty * TH, x0 = xl_it.tx * TW;
-        xokm = 0;
+        xzm = 0;
 #pragma unroll
         for (int k = 0; k < NXD; ++k) {
-            const int Q = (wave * NXD + k) * 64 + lane, hy = Q / 96, rq = Q - hy * 96, hx = rq / 5, q = rq - hx * 5;
-            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const bool ok = hy < HHT && hx < HWD && q < 4 && y >= 0 && y < a.H && x >= 0 && x < a.W;
-            xokm |= ok ? (1u << k) : 0u;
-            xoff[k] = ok ? (unsigned)(((y * a.W + x) * S.pix_stride + q * 4) * 4) : 0u;
+            int Q = (wave * NXD + k) * 64 + lane;
+            asm volatile("" : "+v"(Q));       // (recomputed here, once per tile and source: not a loop-invariant to keep in a register)
+            const int hy = Q / 96, rq = Q - hy * 96, hx = rq / 5, q = rq - hx * 5;
+            const bool real = hy < HHT && hx < HWD && q < 4;            // a quad some patch read will touch
+            int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool inside = y >= 0 && y < a.H && x >= 0 && x < a.W;
+            xzm |= (real && !inside) ? (1u << k) : 0u;
+            y = y < 0 ? 0 : (y < a.H ? y : a.H - 1);
+            x = x < 0 ? 0 : (x < a.W ? x : a.W - 1);
+            xoff[k] = real ? (unsigned)(((y * a.W + x) * S.pix_stride + q * 4) * 4) : 0u;
         }
     };
     auto xl_setup = [&]() {
@@ -541,12 +551,11 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         src_select();
     };
     auto load_x = [&](int buf) {
-        const char* const base = reinterpret_cast<const char*>(sbase + c_in);
+        const float* const base = sbase + c_in;
+        xzm_landed = xzm;
 #pragma unroll
-        for (int k = 0; k < NXD; ++k) {
-            const void* src = (xokm >> k) & 1 ? static_cast<const void*>(base + xoff[k]) : static_cast<const void*>(g_zero4w);
-            if (!(BMC_WINO_ABL & 4)) dma16v(src, xb_lds + (unsigned)((buf * XBUFA + (wave * NXD + k) * 256) * 4));
-        }
+        for (int k = 0; k < NXD; ++k)
+            if (!(BMC_WINO_ABL & 4)) dma16(base, xoff[k], xb_lds + (unsigned)((buf * XBUFA + (wave * NXD + k) * 256) * 4));
         c_in += CK;
         if (++xl_chunk == nchunks) {
             xl_tile += t_stride;
@@ -555,6 +564,17 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
             c_in = 0; ++s_idx;
             src_select();
         }
+    };
+    auto zero_x = [&](int buf) {      // after the chunk's DMA has landed (this wave's own pieces), before its barrier
+        if (__builtin_amdgcn_ballot_w64(xzm_landed != 0) == 0) return;       // interior tile: wave-uniform skip
+#pragma unroll
+        for (int k = 0; k < NXD; ++k)
+            if ((xzm_landed >> k) & 1) {
+                f32x4 z;
+                asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0"
+                             : "=v"(z[0]), "=v"(z[1]), "=v"(z[2]), "=v"(z[3]));      // (made here: a zero quad kept live would be spilled)
+                *reinterpret_cast<f32x4*>(Xb + buf * XBUFA + ((wave * NXD + k) * 64 + lane) * 4) = z;
+            }
     };
 
     // ---- W ring loader: wave w copies half (w & 1) of position nu = w >> 1 of a stage (4 KB)
@@ -625,31 +645,65 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         *reinterpret_cast<f32x4*>(vb + vst) = v;
     };
 
-    auto stage = [&](const float* vb, const float* wb, int xi, const float* xb_n, float* vb_n, int xi_n) __attribute__((always_inline)) {
-        f32x4 uf[4], vf[4][2], d[4];
+    // One stage = 32 MFMAs, split in two halves AROUND the barrier that publishes the next stage (conv.hip's pattern): the
+    // fragments of positions nu = 0, 1 were read right after the previous barrier (under the previous stage's second half),
+    // those of nu = 2, 3 are read at the top (their data has been public since that barrier) and consumed after this
+    // stage's barrier -- so no MFMA ever waits for an LDS round trip that starts at a barrier, which is where all eight
+    // waves of the workgroup would otherwise stall together (two waves per SIMD only cover each other when they are not in
+    // lockstep).  The production of the next stage's V (4 reads, 12 adds, 1 store per thread) rides in the first half.
+    f32x4 ufA[2], vfA[2][2];
+    auto load_first = [&](const float* vb, const float* wb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
+        for (int nu = 0; nu < 2; ++nu) {
             if (BMC_WINO_ABL & 32) {
-                uf[nu] = f32x4{1.f, 2.f, 3.f, 4.f}; vf[nu][0] = vf[nu][1] = f32x4{4.f, 3.f, 2.f, 1.f};
-                asm volatile("" : "+v"(uf[nu]), "+v"(vf[nu][0]), "+v"(vf[nu][1]));
+                ufA[nu] = f32x4{1.f, 2.f, 3.f, 4.f}; vfA[nu][0] = vfA[nu][1] = f32x4{4.f, 3.f, 2.f, 1.f};
+                asm volatile("" : "+v"(ufA[nu]), "+v"(vfA[nu][0]), "+v"(vfA[nu][1]));
                 continue;
             }
-            uf[nu] = *reinterpret_cast<const f32x4*>(wb + nu * BN * CK + woff);
+            ufA[nu] = *reinterpret_cast<const f32x4*>(wb + nu * BN * CK + woff);
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) vf[nu][tb] = *reinterpret_cast<const f32x4*>(vb + nu * 32 * CK + tb * 16 * CK + voff);
+            for (int tb = 0; tb < 2; ++tb) vfA[nu][tb] = *reinterpret_cast<const f32x4*>(vb + nu * 32 * CK + tb * 16 * CK + voff);
         }
+    };
+    auto mfma8 = [&](f32x4 (&c)[2], const f32x4& u, const f32x4 (&v)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                if (BMC_WINO_ABL & 1) c[tb][m] += u[m] * v[tb][m];
+                else c[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[m], v[tb][m], c[tb], 0, 0, 0);
+            }
+    };
+    // first half: everything before this stage's barrier
+    auto stage_head = [&](const float* vb, const float* wb, int xi, const float* xb_n, float* vb_n, int xi_n, f32x4 (&ufB)[2],
+                          f32x4 (&vfB)[2][2]) __attribute__((always_inline)) {
+        f32x4 d[4];
         if (!(BMC_WINO_ABL & 16)) produce_load(xb_n, xi_n, d);
         __builtin_amdgcn_sched_barrier(0);
+        mfma8(acc[4 * xi + 0], ufA[0], vfA[0]);
+        mfma8(acc[4 * xi + 1], ufA[1], vfA[1]);
+        if (!(BMC_WINO_ABL & 16)) produce_store(vb_n, xi_n, d);
+        __builtin_amdgcn_sched_barrier(0);
+        // the second half's fragments: read now (the first half's registers are free), consumed behind the barrier
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
+        for (int nu = 0; nu < 2; ++nu) {
+            if (BMC_WINO_ABL & 32) {
+                ufB[nu] = f32x4{1.f, 2.f, 3.f, 4.f}; vfB[nu][0] = vfB[nu][1] = f32x4{4.f, 3.f, 2.f, 1.f};
+                asm volatile("" : "+v"(ufB[nu]), "+v"(vfB[nu][0]), "+v"(vfB[nu][1]));
+                continue;
+            }
+            ufB[nu] = *reinterpret_cast<const f32x4*>(wb + (2 + nu) * BN * CK + woff);
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb)
-                    if (BMC_WINO_ABL & 1) acc[4 * xi + nu][tb][m] += uf[nu][m] * vf[nu][tb][m];
-                    else acc[4 * xi + nu][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[nu][m], vf[nu][tb][m], acc[4 * xi + nu][tb], 0, 0, 0);
-            if (nu == 1 && !(BMC_WINO_ABL & 16)) produce_store(vb_n, xi_n, d);
+            for (int tb = 0; tb < 2; ++tb) vfB[nu][tb] = *reinterpret_cast<const f32x4*>(vb + (2 + nu) * 32 * CK + tb * 16 * CK + voff);
         }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // second half: after the barrier; vb_n / wb_n: the NEXT stage's (just published) operands, or nullptr
+    auto stage_tail = [&](int xi, const float* vb_n, const float* wb_n, const f32x4 (&ufB)[2], const f32x4 (&vfB)[2][2]) __attribute__((always_inline)) {
+        if (vb_n) load_first(vb_n, wb_n);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(acc[4 * xi + 2], ufB[0], vfB[0]);
+        mfma8(acc[4 * xi + 3], ufB[1], vfB[1]);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -753,6 +807,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     load_x(0);
     for (int k = 0; k < DW && wl_cnt < total_stages; ++k) issue_w();
     dma_wait<0>();
+    zero_x(0);
     __syncthreads();
     {
         f32x4 d[4];
@@ -761,6 +816,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     }
     __syncthreads();
     init_acc();
+    load_first(Vb, Wb);
 
     int gs = 0, gc = 0;
     for (int tile = t_first; tile < t_hi; tile += t_stride) {
@@ -775,11 +831,14 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
                 const bool has_next = gs + 1 < total_stages;
                 // (the very last stage produces a V nobody reads, from this chunk's halo: no branch around the production)
                 const float* const xb_n = (xi == 3 && has_next) ? Xb + ((gc + 1) & 1) * XBUFA : xb;
-                stage(Vb + (gs & 1) * VSTAGE, Wb + (gs % NWR) * WSTAGE, xi, xb_n, Vb + ((gs + 1) & 1) * VSTAGE, (xi + 1) & 3);
+                f32x4 ufB[2], vfB[2][2];
+                stage_head(Vb + (gs & 1) * VSTAGE, Wb + (gs % NWR) * WSTAGE, xi, xb_n, Vb + ((gs + 1) & 1) * VSTAGE, (xi + 1) & 3, ufB, vfB);
                 if (!issued) dma_wait<0>();
                 else if (xi <= 1 && more_x) dma_wait<4 + NXD>();
                 else dma_wait<4>();
+                if (xi == 2 && more_x) zero_x((gc + 1) & 1);       // the next chunk's halo has landed (it is older than stage gs + 1)
                 if (BMC_WINO_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else ring_publish();
+                stage_tail(xi, has_next ? Vb + ((gs + 1) & 1) * VSTAGE : nullptr, Wb + ((gs + 1) % NWR) * WSTAGE, ufB, vfB);
             }
         }
         epilogue(decode(tile));

