@@ -681,10 +681,10 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         if (!(BMC_WINO_ABL & 16)) produce_load(xb_n, xi_n, d);
         __builtin_amdgcn_sched_barrier(0);
         mfma8(acc[4 * xi + 0], ufA[0], vfA[0]);
-        mfma8(acc[4 * xi + 1], ufA[1], vfA[1]);
         if (!(BMC_WINO_ABL & 16)) produce_store(vb_n, xi_n, d);
         __builtin_amdgcn_sched_barrier(0);
-        // the second half's fragments: read now (the first half's registers are free), consumed behind the barrier
+        // the second half's fragments: read HERE -- 8 MFMAs (256 cycles) before the barrier's lgkmcnt(0) -- and consumed
+        // behind the barrier
 #pragma unroll
         for (int nu = 0; nu < 2; ++nu) {
             if (BMC_WINO_ABL & 32) {
@@ -696,6 +696,8 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) vfB[nu][tb] = *reinterpret_cast<const f32x4*>(vb + (2 + nu) * 32 * CK + tb * 16 * CK + voff);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(acc[4 * xi + 1], ufA[1], vfA[1]);
         __builtin_amdgcn_sched_barrier(0);
     };
     // second half: after the barrier; vb_n / wb_n: the NEXT stage's (just published) operands, or nullptr
