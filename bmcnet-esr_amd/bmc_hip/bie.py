@@ -152,6 +152,8 @@ def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, w_param, b_param, G=1,
     GEMM stages anyway) -> (dW, db) for autograd; None where the sums went straight into the leaf parameters' .grad
     (ops.reduce_wgrad).  G > 1 (stacked per-group weights): w_param None, result [G, ...]."""
     # keep: the operand tensors behind a_src / x_srcs (ops.wgrad_side: small launches run on the side stream)
+    if ops.wino_wgrad_ok(a_src, x_srcs, spec, taps, Cout, G) and w_param is not None:
+        return ops.wgrad_wino(a_src, x_srcs[0], B, H, W, spec, dev, w_param, b_param, w_shape if w_shape is not None else w_param.shape)
     with ops.wgrad_side(B * H * W, ops._flat_params(w_param, b_param), keep):
         slabs, nsplit, _, bsl = pgemm_raw(a_src, x_srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
                                           flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)

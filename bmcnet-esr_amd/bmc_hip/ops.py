@@ -428,6 +428,49 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
     return slabs, nsplit, G
 
 
+# Weight gradients of the dense 3x3 128 -> 128 convolutions (the residual blocks: 88 % of the 3x3 weight-gradient work) go
+# through the Winograd transform too (csrc/wino_wgrad.hip: 16 instead of 36 multiplies per 2x2 tile and channel pair; fp32,
+# deterministic).  BMC_WINO_WGRAD=0 (or BMC_WINO=0) leaves them to the pixel-reduction GEMM.
+WINO_WGRAD = os.environ.get("BMC_WINO_WGRAD", "1") != "0"
+
+
+def wino_wgrad_ok(a_src, x_srcs, spec, taps, Cout, G):
+    """Does this weight gradient take the Winograd kernel?  One dense 128-channel source (pix_stride 128) whose channels are a
+    contiguous column range [k0, k0 + 128) of the weight tensor, 128 output channels, one weight group, fp32 arithmetic."""
+    if not (WINO and WINO_WGRAD and MATH == 0 and taps == 9 and G == 1 and Cout == 128 and len(x_srcs) == 1 and spec.kpad == 128):
+        return False
+    xs = x_srcs[0]
+    if not (xs.nch == 128 and xs.pix_stride == 128 and a_src.nch == 128 and a_src.pix_stride == 128):
+        return False
+    k0 = spec.kmap_host[0]
+    return k0 >= 0 and spec.kmap_host == list(range(k0, k0 + 128))
+
+
+def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias=True):
+    """(dW, db) of a convolution wino_wgrad_ok() accepted, with reduce_wgrad's conventions: None where the sums went straight
+    into a leaf parameter's .grad."""
+    nsplit = lib._ww_nsplit(B, H, W)
+    part = torch.empty(nsplit * 16 * 128 * 128, device=dev, dtype=torch.float32)
+    bpart = torch.empty(nsplit * 4 * 128, device=dev, dtype=torch.float32) if want_bias else None
+    _on_side(part, bpart)
+    e0 = _prof_begin()
+    lib.call(lib._ww, "bmc_wgrad_wino", C.byref(a_src), C.byref(x_src), B, H, W, nsplit, part.data_ptr(),
+             bpart.data_ptr() if want_bias else None, _stream())
+    _prof_end(e0, "wgrad_wino<9>", 2.0 * B * H * W * 128 * 9 * 128)
+    k0, full = spec.kmap_host[0], spec.covers_all
+    sg = sink_group([w_param, b_param] if want_bias else [w_param], full) if w_param is not None else None
+    if sg is not None:
+        (gw, *rest), acc = sg
+        lib.call(lib._ww_red, "bmc_wgrad_wino_reduce", part.data_ptr(), nsplit, gw.data_ptr(), spec.cin, k0, acc,
+                 bpart.data_ptr() if want_bias else None, rest[0].data_ptr() if want_bias else None, _stream())
+        return None, None
+    dw = (torch.empty if full else torch.zeros)(128 * spec.cin * 9, device=dev, dtype=torch.float32)
+    db = torch.empty(128, device=dev, dtype=torch.float32) if want_bias else None
+    lib.call(lib._ww_red, "bmc_wgrad_wino_reduce", part.data_ptr(), nsplit, dw.data_ptr(), spec.cin, k0, 0,
+             bpart.data_ptr() if want_bias else None, db.data_ptr() if want_bias else None, _stream())
+    return dw.view(w_shape), db
+
+
 def relu_bwd(dy, y):
     g = torch.empty_like(dy)
     lib.call(lib._relu_bwd, "bmc_relu_bwd", dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), _stream())
@@ -732,12 +775,15 @@ class ConvFn(torch.autograd.Function):
             a_src = _src(g, 0, Cout, 0, None, 0, B)
             wb = ctx.has_bias and need[2]
             wp_, bp_ = ctx.params
-            with wgrad_side(B * H * W, _flat_params(wp_, bp_ if wb else None), (g, *src_ts)):
-                r_pg = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
-                                 flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=wb)
-                slabs, nsplit = r_pg[0], r_pg[1]
-                dw, db = reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, r_pg[3] if wb else None, wp_, bp_ if wb else None,
-                                      weight.shape)
+            if wino_wgrad_ok(a_src, srcs, spec, taps, Cout, G) and not isinstance(wp_, (tuple, list)):
+                dw, db = wgrad_wino(a_src, srcs[0], B, H, W, spec, dev, wp_, bp_ if wb else None, weight.shape, want_bias=wb)
+            else:
+                with wgrad_side(B * H * W, _flat_params(wp_, bp_ if wb else None), (g, *src_ts)):
+                    r_pg = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
+                                     flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=wb)
+                    slabs, nsplit = r_pg[0], r_pg[1]
+                    dw, db = reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, r_pg[3] if wb else None, wp_,
+                                          bp_ if wb else None, weight.shape)
             bias_done = wb
         if ctx.has_bias and need[2] and not bias_done:
             bpg = B // G
@@ -879,8 +925,11 @@ def _wgrad_plain(g, x, spec, w_param, b_param, taps):
     gradient (column sums of g) from one pgemm launch."""
     B, H, W, Cout = g.shape
     dev = g.device
+    a_src, x_src = _src(g, 0, Cout, 0, None, 0, B), _src(x, 0, x.shape[3], 0, None, 0, B)
+    if wino_wgrad_ok(a_src, [x_src], spec, taps, Cout, 1):
+        return wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_param.shape)
     with wgrad_side(B * H * W, [w_param, b_param], (g, x)):
-        slabs, nsplit, _, bsl = pgemm_raw(_src(g, 0, Cout, 0, None, 0, B), [_src(x, 0, x.shape[3], 0, None, 0, B)], B, H, W, taps,
+        slabs, nsplit, _, bsl = pgemm_raw(a_src, [x_src], B, H, W, taps,
                                           B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)
         return reduce_wgrad(slabs, nsplit, 1, taps, Cout, spec, dev, bsl, w_param, b_param, w_param.shape)
 

@@ -221,6 +221,24 @@ int bmc_pgemm_reduce_weight_groups(const float* slabs, int nsplit, int G, int ta
 int bmc_pgemm_reduce_plain(const float* slabs, int nsplit, int G, int M, int N, float scale,
                            float* out, bmc_stream_t s);
 
+/* ---- weight gradient of a dense 3x3, 128 -> 128 channel convolution through the Winograd transform F(2x2, 3x3) ----
+ * The same sum as bmc_pgemm (taps = 9) + bmc_pgemm_reduce_weight for this shape -- F.conv2d's weight / bias gradient at
+ * models/submodules.py:25-26,33-34 (the residual blocks: 88 % of the network's 3x3 weight-gradient work) -- with 16 instead
+ * of 36 multiplies per 2x2 output tile and channel pair on the fp32 MFMA:
+ *   dU[xi][nu] = sum over tiles (A dY A^T)[xi][nu]^T (B^T d B)[xi][nu],  dW = G^T dU G,  db = sum of dY;
+ * fp32 throughout, deterministic (partial sums per workgroup, added in a fixed order).
+ *   dy, x:   NHWC tensors [B,H,W,128] (nch == pix_stride == 128; batch stride / shift / modulus as everywhere);
+ *            dy = gradient of the convolution's output, x = its input
+ *   nsplit:  workgroups per position row, 1 .. bmc_wgrad_wino_nsplit(B, H, W) (which returns the count that fills the chip)
+ *   part:    workspace of nsplit * 16 * 128 * 128 floats;  bias_part: NULL or nsplit * 4 * 128 floats
+ * bmc_wgrad_wino_reduce:  dw[co][k0 + ci][3][3] (=|+=) the gradient, dw = a [128][ldw][3][3] weight tensor of which the launch's
+ * input channels are columns [k0, k0 + 128);  db[128] (=|+=) the bias gradient (bias_part and db go together). */
+int bmc_wgrad_wino_nsplit(int B, int H, int W);
+int bmc_wgrad_wino(const bmc_src_t* dy, const bmc_src_t* x, int B, int H, int W, int nsplit, float* part, float* bias_part,
+                   bmc_stream_t s);
+int bmc_wgrad_wino_reduce(const float* part, int nsplit, float* dw, int ldw, int k0, int accumulate, const float* bias_part,
+                          float* db, bmc_stream_t s);
+
 /* ---- streaming kernels ---------------------------------------------------*/
 /* out[i] = sum_{k < groups} in[k*n + i] (fixed order): gradient of an operand shared by several batch groups of a launch */
 int bmc_group_sum(const float* in, int groups, long long n, float* out, bmc_stream_t s);

@@ -528,3 +528,81 @@ def test_side_stream_weight_gradients_are_bit_identical(math):
     la, ga, pa = run("auto")         # 31x56: the automatic choice is the side stream
     assert la == l0 and all(torch.equal(a, b) for a, b in zip(ga, g0))
     assert ops._SIDE and not next(iter(ops._SIDE.values())).armed and not next(iter(ops._SIDE.values())).keep
+
+
+# ------------------------------------------------------------------ Winograd weight-gradient kernel (csrc/wino_wgrad.hip)
+def _wgrad_reference(x, g):
+    """float64 weight / bias gradient of a 3x3 'same' convolution: x, g NHWC fp32 tensors -> (dW [Co,Ci,3,3], db [Co])."""
+    import torch.nn.functional as F
+    x64 = x.detach().cpu().double().permute(0, 3, 1, 2)
+    g64 = g.detach().cpu().double().permute(0, 3, 1, 2)
+    w = torch.zeros(g.shape[3], x.shape[3], 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x64, w, padding=1) * g64).sum().backward()
+    return w.grad, g64.sum((0, 2, 3))
+
+
+@pytest.mark.parametrize("B,H,W", [
+    (1, 2, 2),            # one tile, every neighbour outside the image
+    (2, 7, 9),            # odd sizes: the last tile row / column are half outside
+    (3, 4, 16),           # exactly one stage per image
+    (2, 31, 56),          # configs[3] frame
+    (5, 45, 80),          # the reference's own NFS frame; more stages than one workgroup per position row takes
+    (1, 64, 100),
+])
+def test_winograd_weight_gradient_vs_float64(B, H, W):
+    from bmc_hip import ops
+    torch.manual_seed(B * 1000 + H * 10 + W)
+    dev = torch.device("cuda:0")
+    x = torch.randn(B, H, W, 128, device=dev)
+    g = torch.randn(B, H, W, 128, device=dev)
+    spec = ops.ConvSpec.dense(128)
+    w = torch.zeros(128, 128, 3, 3, device=dev)
+    b = torch.zeros(128, device=dev)
+    assert ops.wino_wgrad_ok(ops._src(g, 0, 128, 0, None, 0, B), [ops._src(x, 0, 128, 0, None, 0, B)], spec, 9, 128, 1)
+    dw, db = ops._wgrad_plain(g, x, spec, w, b, 9)
+    ref_w, ref_b = _wgrad_reference(x, g)
+    old = ops.WINO_WGRAD
+    ops.WINO_WGRAD = False
+    try:
+        dw_d, db_d = ops._wgrad_plain(g, x, spec, w, b, 9)      # the pixel-reduction GEMM on the same operands
+    finally:
+        ops.WINO_WGRAD = old
+    rel = lambda a, r: float((a.detach().cpu().double() - r).norm() / r.norm())
+    e_w, e_b, e_d = rel(dw, ref_w), rel(db, ref_b), rel(dw_d, ref_w)
+    print("B%d %dx%d: winograd dW %.2e db %.2e, direct dW %.2e" % (B, H, W, e_w, e_b, e_d))
+    assert e_w < 2e-6 and e_b < 2e-6
+    assert e_w < 4 * e_d + 1e-7          # fp32 Winograd: a small factor over the direct fp32 kernel's own rounding error
+    # deterministic: a second launch gives the same bits
+    dw2, db2 = ops._wgrad_plain(g, x, spec, w, b, 9)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+def test_winograd_weight_gradient_views_accumulation_and_partial_columns():
+    """The launch forms the model uses: operands that are batch windows of larger tensors, gradients accumulated straight into
+    a leaf parameter's .grad (sink route, twice), and a launch that owns columns [256, 384) of a wider weight (conv_fs)."""
+    from bmc_hip import ops
+    torch.manual_seed(5)
+    dev = torch.device("cuda:0")
+    B, H, W = 2, 11, 18
+    xbig = torch.randn(3 * B, H, W, 128, device=dev)
+    g = torch.randn(B, H, W, 128, device=dev)
+    x = xbig[B:2 * B]
+    ref_w, ref_b = _wgrad_reference(x, g)
+    spec = ops.ConvSpec.dense(128)
+    w = torch.nn.Parameter(torch.zeros(128, 128, 3, 3, device=dev))
+    b = torch.nn.Parameter(torch.zeros(128, device=dev))
+    ops.set_accumulate_param_grads(True)
+    for _ in range(2):
+        dw, db = ops._wgrad_plain(g, x, spec, w, b, 9)
+        assert dw is None and db is None
+    rel = lambda a, r: float((a.detach().cpu().double() - r).norm() / r.norm())
+    assert rel(w.grad, 2 * ref_w) < 2e-6 and rel(b.grad, 2 * ref_b) < 2e-6
+    # partial columns of a 288-input-channel weight through the generic convolution node
+    wide = torch.nn.Parameter(torch.randn(128, 288, 3, 3, device=dev) * 0.05)
+    sp = ops.ConvSpec([list(range(144, 272))], cin=288)
+    xin = x.clone().requires_grad_(True)
+    y = ops.conv([ops.View(xin)], wide, None, sp)
+    (y * g).sum().backward()
+    got = wide.grad.detach().cpu().double()
+    assert rel(got[:, 144:272], ref_w) < 2e-6
+    assert float(got[:, :144].abs().max()) == 0 and float(got[:, 272:].abs().max()) == 0
