@@ -25,6 +25,9 @@
 #include "dma_ring.h"
 #include "wgrad_k.h"
 
+#ifndef BMC_WW_PIPE
+#define BMC_WW_PIPE 1     // 1: rows of stage s + 2 requested in the middle of stage s; 0: rows of stage s + 1 at its top
+#endif
 #ifndef BMC_WW_ABL
 #define BMC_WW_ABL 0      // ablation builds (tools/): 1 no MFMA, 2 no global loads, 4 no transform / LDS stores, 8 no fragment reads
 #endif
@@ -56,7 +59,9 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
     const int tr = tg >> 1, xq = tg & 1;
     // row xi of B^T = sa * row ra + sb * row rb of the patch: (1,0,-1,0) (0,1,1,0) (0,-1,1,0) (0,1,0,-1)
     constexpr int ra = xi == 0 ? 0 : 1, rb = xi == 3 ? 3 : 2;
-    // row xi of A: (1,0) (1,1) (1,-1) (0,-1) of dY's two rows
+    // row xi of A: (1,0) (1,1) (1,-1) (0,-1) of dY's two rows.  The two -1 entries standing alone (row 3 here, column 3 in
+    // produce()) are NOT applied: the partial sums of positions with xi = 3 or nu = 3 carry the opposite sign, which
+    // wino_wgrad_reduce_kernel folds into its coefficients (12 VALU instructions less per thread and stage)
     const int pst = c * ROWF + ((tg ^ swz(c)) << 2);                 // + position * POSF (+ HALF for V)
     // ---- consumer role
     const int nu = wave >> 1, ch = wave & 1;
@@ -149,6 +154,7 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
     auto produce = [&](float* buf, const unsigned zm) __attribute__((always_inline)) {
         if (BMC_WW_ABL & 4) return;
         if (zm) {
+            asm volatile("; image border" ::: "memory");      // (keeps this a branch: if-converted it costs 28 selects in EVERY stage)
 #pragma unroll
             for (int q = 0; q < 10; ++q) {
                 if (zm & (1u << q | 1u << 10)) xa[q] = 0.f;
@@ -178,14 +184,14 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
         *reinterpret_cast<f32x4*>(vp + 3 * POSF) = v3;
         float s[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s[q] = xi == 0 ? y0[q] : (xi == 3 ? -y0[q] : (xi == 1 ? y0[q] + y1[q] : y0[q] - y1[q]));
+        for (int q = 0; q < 8; ++q) s[q] = (xi == 0 || xi == 3) ? y0[q] : (xi == 1 ? y0[q] + y1[q] : y0[q] - y1[q]);
         f32x4 m0, m1, m2, m3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             m0[j] = s[2 * j];
             m1[j] = s[2 * j] + s[2 * j + 1];
             m2[j] = s[2 * j] - s[2 * j + 1];
-            m3[j] = -s[2 * j + 1];
+            m3[j] = s[2 * j + 1];
         }
         float* const mp = buf + pst;
         *reinterpret_cast<f32x4*>(mp) = m0;
@@ -195,27 +201,28 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
         if (xi == 1) bsum += (m1[0] + m1[1]) + (m1[2] + m1[3]);
     };
 
+    // Software pipeline: the rows of stage s + 1 are loaded during stage s - 1 (issued right after the registers were
+    // consumed), transformed and stored in the middle of stage s: a full stage (~5 us) of latency cover with one register set.
+    unsigned zmn = 0;
     if (st0 < st1) {
         const unsigned zm = load();
         produce(lds, zm);
     }
-    __syncthreads();
+    if (BMC_WW_PIPE && st0 + 1 < st1) zmn = load();
+    ring_publish();
     int it = 0;
     for (int st = st0; st < st1; ++st, ++it) {
         const float* const cur = lds + (it & 1) * BUFF;
         float* const nxt = lds + ((it & 1) ^ 1) * BUFF;
-        const bool more = st + 1 < st1;
-        unsigned zm = 0;
-        if (more) zm = load();
-        __builtin_amdgcn_sched_barrier(0);
         // 128 MFMAs in two halves of four ci-blocks each (12 fragment quads live at a time instead of all 12 + the loaded rows)
+        // (the dM fragments are read again for the second half: nothing of the first half stays live across produce())
         f32x4 af[4], bf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (BMC_WW_ABL & 8) { af[i] = f32x4{1.f, 2.f, 3.f, 4.f}; asm volatile("" : "+v"(af[i])); continue; }
-            af[i] = *reinterpret_cast<const f32x4*>(cur + aoff + i * 16 * ROWF);
-        }
         auto read_b = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (BMC_WW_ABL & 8) { af[i] = f32x4{1.f, 2.f, 3.f, 4.f}; asm volatile("" : "+v"(af[i])); continue; }
+                af[i] = *reinterpret_cast<const f32x4*>(cur + aoff + i * 16 * ROWF);
+            }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 if (BMC_WW_ABL & 8) { bf[n] = f32x4{4.f, 3.f, 2.f, 1.f}; asm volatile("" : "+v"(bf[n])); continue; }
@@ -233,15 +240,18 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
                         else acc[i][4 * h + n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][ks], bf[n][ks], acc[i][4 * h + n], 0, 0, 0);
                     }
         };
+        if (!BMC_WW_PIPE && st + 1 < st1) zmn = load();
         read_b(0);
         mfma64(0);
+        pin_acc();
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < st1) produce(nxt, zmn);
+        if (BMC_WW_PIPE && st + 2 < st1) zmn = load();
         __builtin_amdgcn_sched_barrier(0);
         read_b(1);
-        if (more) produce(nxt, zm);
-        __builtin_amdgcn_sched_barrier(0);
         mfma64(1);
         pin_acc();
-        __syncthreads();
+        ring_publish();      // (raw barrier: the loads in flight are not drained)
     }
 
     // ---- partial sums: part[split][xi][nu][co][ci]
@@ -316,16 +326,17 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
     }
     __syncthreads();
     // rows of G: (1,0,0) (1/2,1/2,1/2) (1/2,-1/2,1/2) (0,0,1);  dW[i][j] = sum_xi,nu G[xi][i] G[nu][j] dU[xi][nu]
+    // (row 3 enters with -1: the main kernel leaves out the sign of A's rows / columns 3)
     for (int tap = p8; tap < 9; tap += 8) {
         const int i = tap / 3, jj = tap - 3 * i;
         float o = 0.f;
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            const float gx = x == 0 ? (i == 0 ? 1.f : 0.f) : x == 3 ? (i == 2 ? 1.f : 0.f) : (x == 2 && i == 1 ? -0.5f : 0.5f);
+            const float gx = x == 0 ? (i == 0 ? 1.f : 0.f) : x == 3 ? (i == 2 ? -1.f : 0.f) : (x == 2 && i == 1 ? -0.5f : 0.5f);
             float rowv = 0.f;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const float gn = n == 0 ? (jj == 0 ? 1.f : 0.f) : n == 3 ? (jj == 2 ? 1.f : 0.f) : (n == 2 && jj == 1 ? -0.5f : 0.5f);
+                const float gn = n == 0 ? (jj == 0 ? 1.f : 0.f) : n == 3 ? (jj == 2 ? -1.f : 0.f) : (n == 2 && jj == 1 ? -0.5f : 0.5f);
                 rowv += gn * tot[x * 4 + n][ol];
             }
             o += gx * rowv;
