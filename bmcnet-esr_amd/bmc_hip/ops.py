@@ -451,7 +451,7 @@ def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want
     into a leaf parameter's .grad."""
     nsplit = lib._ww_nsplit(B, H, W)
     part = torch.empty(nsplit * 16 * 128 * 128, device=dev, dtype=torch.float32)
-    bpart = torch.empty(nsplit * 4 * 128, device=dev, dtype=torch.float32) if want_bias else None
+    bpart = torch.empty(nsplit * 128, device=dev, dtype=torch.float32) if want_bias else None
     _on_side(part, bpart)
     e0 = _prof_begin()
     lib.call(lib._ww, "bmc_wgrad_wino", C.byref(a_src), C.byref(x_src), B, H, W, nsplit, part.data_ptr(),

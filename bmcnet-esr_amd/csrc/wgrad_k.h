@@ -9,5 +9,5 @@ struct WgradK {
     int SY, SX;          // stages per image: pairs of tile rows x groups of 8 tiles
     int nstages, nsplit;
     float* part;         // [nsplit][4 xi][4 nu][128 co][128 ci]
-    float* bias_part;    // optional [nsplit][4][128]
+    float* bias_part;    // optional [nsplit][128]
 };

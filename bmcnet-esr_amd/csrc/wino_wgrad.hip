@@ -13,14 +13,14 @@
 // The tile axis is the reduction axis: `nsplit` workgroups per xi share the tiles in contiguous ranges and write
 // partial sums, which wino_wgrad_reduce_kernel adds in a fixed order and transforms to the 3x3 taps (deterministic).
 //
-// Stage = 16 tiles (2 tile rows x 8 tiles) = 4 k-steps of the MFMA.  Thread (channel c = tid & 127, tile quad tg = tid >> 7)
-// loads its rows of X / dY as scalars straight from global memory (a wave = 64 consecutive channels of one pixel: 256-byte
-// coalesced; one scalar base per image row + a per-lane offset per column, both clamped into the image; values from outside
-// it are replaced by zero afterwards), transforms four consecutive tiles in registers and stores one 16-byte quad per position:
-// LDS image [position][channel][16 tiles], rows of 64 B, quads XOR-swizzled as in dma_ring.h -- the MFMA operand
-// fragments (lane -> channel l & 15, quad l >> 4, the quad's four floats = the four k-steps) are conflict-free
-// ds_read_b128 and the producer's ds_write_b128 likewise.  The loads of stage s + 1 are issued before the 128 MFMAs of
-// stage s and consumed in their middle; two LDS buffers, one barrier per stage.
+// Stage = 16 tiles (2 tile rows x 8 tiles) = 4 k-steps of the MFMA.  Thread (channel quad cq = tid & 31, tile t = tid >> 5)
+// loads its two patch rows x four columns and dY rows x two columns as 16-byte quads straight from global memory (a wave =
+// two adjacent tiles x all 128 channels: 512-byte coalesced; one scalar base per image row + a per-lane offset per column,
+// both clamped into the image; values from outside it are replaced by zero afterwards), transforms them in registers and
+// stores one 16-byte quad per position: LDS image [position][tile][channel], rows of 144 floats, so that the MFMA operand
+// fragments (lane -> channel l & 15 of a 16-block, tile l >> 4 of the k-step) are conflict-free ds_read_b32 (consecutive
+// rows lie 16 banks apart) and the producer's ds_write_b128 likewise.  The rows of stage s + 2 are requested in the middle
+// of stage s and consumed in the middle of stage s + 1; two LDS buffers, one barrier per stage.
 #include "bmc_common.h"
 #include "dma_ring.h"
 #include "wgrad_k.h"
@@ -34,17 +34,31 @@
 
 namespace {
 
-constexpr int ROWF = 16;               // floats per LDS row: one channel's 16 tiles of a stage
-constexpr int POSF = 128 * ROWF;       // one position's image [128 channels][16 tiles]
-constexpr int HALF = 4 * POSF;         // the dM (or V) images of the 4 positions of a stage: 32 KB
-constexpr int BUFF = 2 * HALF;         // one stage: 64 KB
+constexpr int TROW = 144;              // floats per LDS row: one tile's 128 channels + 16 (consecutive rows 16 banks apart)
+constexpr int POSF = 16 * TROW;        // one position's image [16 tiles][144]
+constexpr int HALF = 4 * POSF;         // the dM (or V) images of the 4 positions of a stage: 36 KB
+constexpr int BUFF = 2 * HALF;         // one stage: 72 KB
 
 // A wave-uniform pointer, made opaque (readfirstlane) so that "uniform base + this lane's 32-bit offset" survives as the
 // scalar-base form of global_load (the compiler otherwise reassociates base + lane + offset into per-lane 64-bit addresses).
-__device__ __forceinline__ const float* uni(const float* p) {
+__device__ __forceinline__ const char* uni(const void* p) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
+// a - b on packed pairs: the compiler packs an f32x4 addition into two v_pk_add_f32 but a subtraction into four v_sub_f32
+// (and folds b * -1 + a back into one), and VALU issue slots are what the transform costs beside the fp32 MFMAs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+    const f32x2 lo = pk_sub(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2 hi = pk_sub(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
 // xi is a template parameter: which rows are loaded and with which signs they are combined is decided at compile time (the
@@ -53,22 +67,21 @@ template <int xi>
 __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, const int split) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- producer role: channel c, tiles 4 tg .. 4 tg + 3 of the stage (tile row tg >> 1, tiles 4 (tg & 1) .. + 3 of its 8)
-    const int c = tid & 127;
-    const int tg = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const int tr = tg >> 1, xq = tg & 1;
-    // row xi of B^T = sa * row ra + sb * row rb of the patch: (1,0,-1,0) (0,1,1,0) (0,-1,1,0) (0,1,0,-1)
+    // ---- producer role: channels 4 cq .. 4 cq + 3 of tile t of the stage (tile row t >> 3 of the pair, tile t & 7 of the 8);
+    // a wave = two horizontally adjacent tiles (lanes 0-31 / 32-63) x all 32 channel quads: 512-byte coalesced 16-byte loads
+    const int cq = tid & 31, hl = (tid >> 5) & 1, t = tid >> 5;
+    const int tr = wave >> 2, tcw = 2 * (wave & 3);                  // tile row, first tile column of the wave (uniform)
+    // row xi of B^T = +- row ra +- row rb of the patch: (1,0,-1,0) (0,1,1,0) (0,-1,1,0) (0,1,0,-1)
     constexpr int ra = xi == 0 ? 0 : 1, rb = xi == 3 ? 3 : 2;
     // row xi of A: (1,0) (1,1) (1,-1) (0,-1) of dY's two rows.  The two -1 entries standing alone (row 3 here, column 3 in
     // produce()) are NOT applied: the partial sums of positions with xi = 3 or nu = 3 carry the opposite sign, which
-    // wino_wgrad_reduce_kernel folds into its coefficients (12 VALU instructions less per thread and stage)
-    const int pst = c * ROWF + ((tg ^ swz(c)) << 2);                 // + position * POSF (+ HALF for V)
-    // ---- consumer role
+    // wino_wgrad_reduce_kernel folds into its coefficients
+    const int pst = t * TROW + 4 * cq;                               // + position * POSF (+ HALF for V)
+    // ---- consumer role: wave = position nu, output-channel half ch; lane -> channel li of a 16-block, tile lk of a k-step
     const int nu = wave >> 1, ch = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
-    const int qsw = (lk ^ swz(li)) << 2;
-    const int aoff = nu * POSF + (ch * 64 + li) * ROWF + qsw;        // + cbk * 16 * ROWF
-    const int boff = HALF + nu * POSF + li * ROWF + qsw;             // + nb * 16 * ROWF
+    const int aoff = nu * POSF + lk * TROW + ch * 64 + li;           // + k-step * 4 * TROW + block * 16
+    const int boff = HALF + nu * POSF + lk * TROW + li;
 
     f32x4 acc[4][8];
 #pragma unroll
@@ -85,8 +98,8 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
 
     const int per_img = a.SY * a.SX;
     const int st0 = (int)((long long)a.nstages * split / a.nsplit), st1 = (int)((long long)a.nstages * (split + 1) / a.nsplit);
-    constexpr int PS = 128;                  // pixel stride of both operands (checked by the launcher): column steps are immediates
-    const long long rowf = (long long)a.W * PS;
+    constexpr int PS = 128;                  // pixel stride of both operands (checked by the launcher)
+    const long long rowb = (long long)a.W * PS * 4;     // bytes per image row
 
     // (image, tile-row pair, group of 8 tiles) of the next stage to load, advanced incrementally -- no divisions in the loop
     int nb = st0 / per_img, nsy, nsx;
@@ -95,49 +108,44 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
         nsy = r / a.SX; nsx = r - nsy * a.SX;
     }
     nb = __builtin_amdgcn_readfirstlane(nb); nsy = __builtin_amdgcn_readfirstlane(nsy); nsx = __builtin_amdgcn_readfirstlane(nsx);
-    const float* xbase = uni(src_batch_ptr(a.x, nb));
-    const float* abase = uni(src_batch_ptr(a.a, nb));
+    const char* xbase = uni(src_batch_ptr(a.x, nb));
+    const char* abase = uni(src_batch_ptr(a.a, nb));
 
-    float xa[10], xb[10], y0[8], y1[8];      // (y0: dY row 0, or row 1 for xi = 3; y1: row 1 for xi = 1, 2)
-    // -> 0 for an interior stage; at the image border the returned bits name what lies outside the image (bits 0-9: patch
-    // columns, 10 / 11: patch rows, 12-19: dY columns, 20 / 21: dY rows) -- applied in produce(), so that the loads of a
-    // stage stay one batch in flight
+    f32x4 xa[4], xb[4], y0[2], y1[2];        // the two patch rows; dY row 0 (row 1 for xi = 3); dY row 1 (xi = 1, 2)
+    // Requests the rows of the next stage.  Every address is clamped into the image (one scalar base per image row + one
+    // per-lane byte offset per patch column; dY's two columns are patch columns 1 and 2); the return value says what of it
+    // lies outside the image: bits 0 / 1 / 2 / 3 = patch row a, patch row b, dY row 0, dY row 1, bits 8.. = first patch column
+    // of the wave + 1, bit 31 = some column of the wave is outside.  Applied in produce() (the loads stay one batch in flight).
     auto load = [&]() __attribute__((always_inline)) -> unsigned {
         unsigned zm = 0;
         if (BMC_WW_ABL & 2) {
 #pragma unroll
-            for (int q = 0; q < 10; ++q) { xa[q] = 1.f; xb[q] = 2.f; }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { y0[q] = 1.f; y1[q] = 2.f; }
+            for (int q = 0; q < 4; ++q) xa[q] = xb[q] = f32x4{1.f, 2.f, 3.f, 4.f};
+            y0[0] = y0[1] = y1[0] = y1[1] = f32x4{1.f, 2.f, 3.f, 4.f};
         } else {
-            const int ty = 2 * nsy + tr, tx0 = 8 * nsx + 4 * xq;
-            const int ix0 = 2 * tx0 - 1;                                   // patch columns ix0 .. ix0 + 9, dY columns ix0 + 1 .. ix0 + 8
+            const int ty = 2 * nsy + tr;
+            const int ixw = 2 * (8 * nsx + tcw) - 1;                       // first patch column of the wave's first tile
             const int iya = 2 * ty - 1 + ra, iyb = 2 * ty - 1 + rb;        // the two patch rows of B^T's row xi
             const int oy0 = 2 * ty + (xi == 3 ? 1 : 0), oy1 = 2 * ty + 1;  // dY rows
-            // one scalar base per image row (clamped into the image) + one per-lane 32-bit offset per column (clamped likewise;
-            // dY's columns are patch columns 1 .. 8): every address is valid, what lies outside the image is named in zm
-            const float* const pa = uni(xbase + min(max(iya, 0), a.H - 1) * rowf);
-            const float* const pb = uni(xbase + min(iyb, a.H - 1) * rowf);
-            const float* const q0 = uni(abase + min(oy0, a.H - 1) * rowf);
-            const float* const q1 = uni(abase + min(oy1, a.H - 1) * rowf);
-            zm = (iya < 0 || iya >= a.H ? 1u << 10 : 0u) | (iyb >= a.H ? 1u << 11 : 0u) | (oy0 >= a.H ? 1u << 20 : 0u) |
-                 (oy1 >= a.H ? 1u << 21 : 0u);
-            unsigned vo[10];
+            const char* const pa = uni(xbase + min(max(iya, 0), a.H - 1) * rowb);
+            const char* const pb = uni(xbase + min(iyb, a.H - 1) * rowb);
+            const char* const q0 = uni(abase + min(oy0, a.H - 1) * rowb);
+            const char* const q1 = uni(abase + min(oy1, a.H - 1) * rowb);
+            zm = (iya < 0 || iya >= a.H ? 1u : 0u) | (iyb >= a.H ? 2u : 0u) | (oy0 >= a.H ? 4u : 0u) | (oy1 >= a.H ? 8u : 0u) |
+                 (ixw < 0 || ixw + 5 >= a.W ? 1u << 31 : 0u);
+            if (zm) zm |= (unsigned)(ixw + 1) << 8;
+            unsigned vo[4];
 #pragma unroll
-            for (int q = 0; q < 10; ++q) {
-                const int ix = ix0 + q;
-                if (ix < 0 || ix >= a.W) zm |= (1u << q) | (q >= 1 && q <= 8 ? 1u << (11 + q) : 0u);
-                vo[q] = ((unsigned)min(max(ix, 0), a.W - 1) * PS + (unsigned)c) * 4u;      // bytes
+            for (int q = 0; q < 4; ++q) vo[q] = (unsigned)min(max(ixw + 2 * hl + q, 0), a.W - 1) * (PS * 4) + (unsigned)cq * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xa[q] = ldg16(pa + vo[q]);
+                xb[q] = ldg16(pb + vo[q]);
             }
 #pragma unroll
-            for (int q = 0; q < 10; ++q) {
-                xa[q] = ldg4(reinterpret_cast<const char*>(pa) + vo[q]);
-                xb[q] = ldg4(reinterpret_cast<const char*>(pb) + vo[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                y0[q] = ldg4(reinterpret_cast<const char*>(q0) + vo[q + 1]);
-                if (xi == 1 || xi == 2) y1[q] = ldg4(reinterpret_cast<const char*>(q1) + vo[q + 1]);
+            for (int q = 0; q < 2; ++q) {
+                y0[q] = ldg16(q0 + vo[q + 1]);
+                if (xi == 1 || xi == 2) y1[q] = ldg16(q1 + vo[q + 1]);
             }
         }
         if (++nsx == a.SX) {
@@ -150,55 +158,43 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
         }
         return zm;
     };
-    float bsum = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     auto produce = [&](float* buf, const unsigned zm) __attribute__((always_inline)) {
         if (BMC_WW_ABL & 4) return;
         if (zm) {
-            asm volatile("; image border" ::: "memory");      // (keeps this a branch: if-converted it costs 28 selects in EVERY stage)
+            asm volatile("; image border" ::: "memory");      // (keeps this a branch: if-converted it costs selects in EVERY stage)
+            const int col0 = (int)((zm >> 8) & 0x3fffff) - 1 + 2 * hl;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 10; ++q) {
-                if (zm & (1u << q | 1u << 10)) xa[q] = 0.f;
-                if (zm & (1u << q | 1u << 11)) xb[q] = 0.f;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (zm & (1u << (12 + q) | 1u << 20)) y0[q] = 0.f;
-                if (zm & (1u << (12 + q) | 1u << 21)) y1[q] = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const bool out = col0 + q < 0 || col0 + q >= a.W;
+                if (out || (zm & 1u)) xa[q] = z;
+                if (out || (zm & 2u)) xb[q] = z;
+                if (q == 1 || q == 2) {
+                    if (out || (zm & 4u)) y0[q - 1] = z;
+                    if (out || (zm & 8u)) y1[q - 1] = z;
+                }
             }
         }
-        float t[10];
+        f32x4 tq[4];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) t[q] = xi == 1 ? xa[q] + xb[q] : (xi == 2 ? xb[q] - xa[q] : xa[q] - xb[q]);
-        f32x4 v0, v1, v2, v3;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v0[j] = t[2 * j] - t[2 * j + 2];
-            v1[j] = t[2 * j + 1] + t[2 * j + 2];
-            v2[j] = t[2 * j + 2] - t[2 * j + 1];
-            v3[j] = t[2 * j + 1] - t[2 * j + 3];
-        }
+        for (int q = 0; q < 4; ++q) tq[q] = xi == 1 ? xa[q] + xb[q] : (xi == 2 ? sub4(xb[q], xa[q]) : sub4(xa[q], xb[q]));
         float* const vp = buf + HALF + pst;
-        *reinterpret_cast<f32x4*>(vp) = v0;
-        *reinterpret_cast<f32x4*>(vp + POSF) = v1;
-        *reinterpret_cast<f32x4*>(vp + 2 * POSF) = v2;
-        *reinterpret_cast<f32x4*>(vp + 3 * POSF) = v3;
-        float s[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s[q] = (xi == 0 || xi == 3) ? y0[q] : (xi == 1 ? y0[q] + y1[q] : y0[q] - y1[q]);
-        f32x4 m0, m1, m2, m3;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            m0[j] = s[2 * j];
-            m1[j] = s[2 * j] + s[2 * j + 1];
-            m2[j] = s[2 * j] - s[2 * j + 1];
-            m3[j] = s[2 * j + 1];
-        }
+        *reinterpret_cast<f32x4*>(vp) = sub4(tq[0], tq[2]);
+        *reinterpret_cast<f32x4*>(vp + POSF) = tq[1] + tq[2];
+        *reinterpret_cast<f32x4*>(vp + 2 * POSF) = sub4(tq[2], tq[1]);
+        *reinterpret_cast<f32x4*>(vp + 3 * POSF) = sub4(tq[1], tq[3]);
+        f32x4 s0, s1;
+        if (xi == 0 || xi == 3) { s0 = y0[0]; s1 = y0[1]; }
+        else if (xi == 1) { s0 = y0[0] + y1[0]; s1 = y0[1] + y1[1]; }
+        else { s0 = sub4(y0[0], y1[0]); s1 = sub4(y0[1], y1[1]); }
+        const f32x4 m1 = s0 + s1;
         float* const mp = buf + pst;
-        *reinterpret_cast<f32x4*>(mp) = m0;
+        *reinterpret_cast<f32x4*>(mp) = s0;
         *reinterpret_cast<f32x4*>(mp + POSF) = m1;
-        *reinterpret_cast<f32x4*>(mp + 2 * POSF) = m2;
-        *reinterpret_cast<f32x4*>(mp + 3 * POSF) = m3;
-        if (xi == 1) bsum += (m1[0] + m1[1]) + (m1[2] + m1[3]);
+        *reinterpret_cast<f32x4*>(mp + 2 * POSF) = sub4(s0, s1);
+        *reinterpret_cast<f32x4*>(mp + 3 * POSF) = s1;
+        if (xi == 1) bsum += m1;
     };
 
     // Software pipeline: the rows of stage s + 1 are loaded during stage s - 1 (issued right after the registers were
@@ -214,20 +210,18 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
     for (int st = st0; st < st1; ++st, ++it) {
         const float* const cur = lds + (it & 1) * BUFF;
         float* const nxt = lds + ((it & 1) ^ 1) * BUFF;
-        // 128 MFMAs in two halves of four ci-blocks each (12 fragment quads live at a time instead of all 12 + the loaded rows)
+        // 128 MFMAs in two halves of four ci-blocks each; k-step ks of a fragment = tile 4 ks + lk of the stage
         // (the dM fragments are read again for the second half: nothing of the first half stays live across produce())
-        f32x4 af[4], bf[4];
-        auto read_b = [&](int h) __attribute__((always_inline)) {
+        float af[4][4], bf[4][4];
+        auto read_ab = [&](int h) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (BMC_WW_ABL & 8) { af[i] = f32x4{1.f, 2.f, 3.f, 4.f}; asm volatile("" : "+v"(af[i])); continue; }
-                af[i] = *reinterpret_cast<const f32x4*>(cur + aoff + i * 16 * ROWF);
-            }
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                if (BMC_WW_ABL & 8) { bf[n] = f32x4{4.f, 3.f, 2.f, 1.f}; asm volatile("" : "+v"(bf[n])); continue; }
-                bf[n] = *reinterpret_cast<const f32x4*>(cur + boff + (4 * h + n) * 16 * ROWF);
-            }
+                for (int i = 0; i < 4; ++i) {
+                    if (BMC_WW_ABL & 8) { af[i][ks] = 1.f + i; bf[i][ks] = 2.f + ks; asm volatile("" : "+v"(af[i][ks]), "+v"(bf[i][ks])); continue; }
+                    af[i][ks] = cur[aoff + ks * 4 * TROW + i * 16];
+                    bf[i][ks] = cur[boff + ks * 4 * TROW + (4 * h + i) * 16];
+                }
         };
         auto mfma64 = [&](int h) __attribute__((always_inline)) {
 #pragma unroll
@@ -241,14 +235,14 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
                     }
         };
         if (!BMC_WW_PIPE && st + 1 < st1) zmn = load();
-        read_b(0);
+        read_ab(0);
         mfma64(0);
         pin_acc();
         __builtin_amdgcn_sched_barrier(0);
         if (st + 1 < st1) produce(nxt, zmn);
         if (BMC_WW_PIPE && st + 2 < st1) zmn = load();
         __builtin_amdgcn_sched_barrier(0);
-        read_b(1);
+        read_ab(1);
         mfma64(1);
         pin_acc();
         ring_publish();      // (raw barrier: the loads in flight are not drained)
@@ -262,11 +256,20 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
         for (int n = 0; n < 8; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) P[(ch * 64 + i * 16 + 4 * lk + r) * 128 + n * 16 + li] = acc[i][n][r];
-    if (xi == 1 && a.bias_part) a.bias_part[((long long)split * 4 + tg) * 128 + c] = bsum;
+    if (xi == 1 && a.bias_part) {        // bias partial of the workgroup: the 16 tile slots added through LDS (the loop ended on a barrier)
+        *reinterpret_cast<f32x4*>(lds + t * 128 + 4 * cq) = bsum;
+        __syncthreads();
+        if (tid < 128) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += lds[k * 128 + tid];
+            a.bias_part[(long long)split * 128 + tid] = sum;
+        }
+    }
 }
 
 __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WgradK a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUFF];     // 128 KB: one workgroup per CU
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUFF];     // 144 KB: one workgroup per CU
     // workgroup -> (split, xi): the four xi of a split read the same pixels -- on the same XCD (same L2) when the split
     // count allows (consecutive workgroup ids go round the 8 XCDs)
     int xi, split;
@@ -290,12 +293,12 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
     __shared__ float red[8][16][32];
     __shared__ float tot[16][32];
     const int ol = threadIdx.x & 31, p8 = threadIdx.x >> 5;
-    if ((int)blockIdx.y == 128) {        // bias: one block, 128 channels x 2 halves of the (split, quad) rows
+    if ((int)blockIdx.y == 128) {        // bias: one block, 128 channels x 2 halves of the splits
         if (blockIdx.x != 0) return;
         __shared__ float bs[2][128];
         const int cc = threadIdx.x & 127, hf = threadIdx.x >> 7;
         float s = 0.f;
-        for (int i = hf; i < nsplit * 4; i += 2) s += bias_part[(long long)i * 128 + cc];
+        for (int i = hf; i < nsplit; i += 2) s += bias_part[(long long)i * 128 + cc];
         bs[hf][cc] = s;
         __syncthreads();
         if (hf == 0) {

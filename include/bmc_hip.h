@@ -230,7 +230,7 @@ int bmc_pgemm_reduce_plain(const float* slabs, int nsplit, int G, int M, int N, 
  *   dy, x:   NHWC tensors [B,H,W,128] (nch == pix_stride == 128; batch stride / shift / modulus as everywhere);
  *            dy = gradient of the convolution's output, x = its input
  *   nsplit:  workgroups per position row, 1 .. bmc_wgrad_wino_nsplit(B, H, W) (which returns the count that fills the chip)
- *   part:    workspace of nsplit * 16 * 128 * 128 floats;  bias_part: NULL or nsplit * 4 * 128 floats
+ *   part:    workspace of nsplit * 16 * 128 * 128 floats;  bias_part: NULL or nsplit * 128 floats
  * bmc_wgrad_wino_reduce:  dw[co][k0 + ci][3][3] (=|+=) the gradient, dw = a [128][ldw][3][3] weight tensor of which the launch's
  * input channels are columns [k0, k0 + 128);  db[128] (=|+=) the bias gradient (bias_part and db go together). */
 int bmc_wgrad_wino_nsplit(int B, int H, int W);
