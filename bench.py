@@ -183,6 +183,10 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key):
            "isolated_2B_128to128": iso, "pmc": pmc,
            "other_kernels": {k: {"launches": v[0], "achieved_tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2),
                                  "avg_launch_ms": round(v[2] / v[0], 4)} for k, v in agg.items() if k != dom}}
+    ww = out["other_kernels"].get("wgrad_wino<9>")
+    if ww:      # the Winograd weight-gradient kernel (csrc/wino_wgrad.hip): algorithmic rate, and what its MFMAs execute (16/36 of it)
+        ww["executed_mfma_tflops"] = round(ww["achieved_tflops"] * 16.0 / 36.0, 2)
+        ww["executed_frac_of_peak"] = round(ww["achieved_tflops"] * 16.0 / 36.0 / peak, 4)
     if dom.startswith("wino"):
         # `achieved` / `frac` are ALGORITHMIC (2 x 9 x Cin x Cout FLOP per pixel, what the metric is defined on): the kernel
         # executes 16 multiplies per 2x2 output tile and channel pair instead of 36, so the algorithmic rate may exceed the
