@@ -311,6 +311,12 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const ConvK a) {
 // fields that do not depend on the tile shape are filled in.  Returns 1 if the problem was launched here, 0 if it is
 // left to the 32x32x2 kernel (small problems, channel counts this kernel has no instantiation for).
 int bmc_conv1_launch(ConvK k, int cus, hipStream_t st) {
+    // K = 128 / 256 with 128-granular output channels and enough tiles: the kernel with register-resident weights (conv1p.hip)
+    {
+        static const long long min64 = getenv("BMC_CONV1P_MIN_TILES") ? atoll(getenv("BMC_CONV1P_MIN_TILES")) : -1;     // (tests)
+        const long long tiles64 = (long long)k.B * (((long long)k.H * k.W + 63) / 64) * (k.Coutpad / 128);
+        if (k.Coutpad % 128 == 0 && tiles64 >= (min64 >= 0 ? min64 : 2ll * cus) && bmc_conv1p_launch(k, cus, st)) return 1;
+    }
     int NT;
     if (k.Coutpad == 32) NT = 2;
     else if (k.Coutpad % 128 == 0) NT = 8;

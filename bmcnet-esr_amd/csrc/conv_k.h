@@ -29,6 +29,10 @@ int bmc_conv_bf_launch(const ConvK& k, int taps, int BN, int TH, int planes, int
 // launched the problem, 0 if it is left to conv.hip's kernel.
 int bmc_conv1_launch(ConvK k, int cus, hipStream_t st);
 
+// conv1p.hip: the same for Coutpad % 128 == 0 and K = 128 / 256 with the weights resident in registers (tried first by
+// bmc_conv1_launch).  Returns 1 if it launched the problem.
+int bmc_conv1p_launch(ConvK k, int cus, hipStream_t st);
+
 // wino.hip: 3x3 convolution through the Winograd transform F(2x2, 3x3) on the fp32 MFMA (math = BMC_MATH_FP32_WINO; weights from
 // bmc_pack_weight_wino).  Returns 0, or < 0 with the error text set.
 int bmc_conv_wino_launch(ConvK k, int cus, hipStream_t st);

@@ -606,3 +606,65 @@ def test_winograd_weight_gradient_views_accumulation_and_partial_columns():
     got = wide.grad.detach().cpu().double()
     assert rel(got[:, 144:272], ref_w) < 2e-6
     assert float(got[:, :144].abs().max()) == 0 and float(got[:, 272:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------ conv1p.hip: 1x1 convolution with register-resident weights
+def test_conv1p_kernel_all_epilogues_vs_float64_and_old_kernels():
+    """Child processes with BMC_CONV1P_MIN_TILES=0 (every eligible 1x1 problem takes conv1p.hip, whatever its size) and with
+    BMC_CONV1P=0 (conv1.hip / conv.hip as before): K = 128 / 256 from one to three sources, 128 / 256 output channels, batch
+    maps, per-sample weights, bias, residual with rotation, ReLU, mask, accumulate, ragged images (partial last tile)."""
+    import json, os, subprocess, sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, json
+import torch
+sys.path[:0] = [ROOT, os.path.join(ROOT, "bmcnet-esr_amd")]
+from bmc_hip import ops
+from bmc_hip.ops import ConvSpec, _src, conv_raw, _packed_weight, coutpad
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(11)
+out = []
+srcsets = [[128], [64, 64], [128, 128], [16, 112], [32, 96, 128], [256], [128], [128, 128]]
+for case in range(16):
+    B = int(torch.randint(1, 5, (1,), generator=g)); H = int(torch.randint(3, 40, (1,), generator=g)); W = int(torch.randint(3, 50, (1,), generator=g))
+    nchs = srcsets[case % 8]
+    Cout = [128, 128, 256, 100][case % 4]
+    G = [1, B, 1, 1][case % 4] if B > 1 else 1
+    relu, use_res, use_mask, acc, bias = case % 2 == 0, case % 3 == 0, case % 5 == 1, case % 4 == 2, case % 3 != 1
+    xs = [torch.randn(B, H, W, c, generator=g).to(dev) for c in nchs]
+    cin = sum(nchs)
+    w = (torch.randn(G, Cout, cin, 1, generator=g) / cin ** 0.5).to(dev)
+    b = (torch.randn(G, Cout, generator=g) * 0.3).to(dev) if bias else None
+    res = torch.randn(B, H, W, Cout, generator=g).to(dev) if use_res else None
+    mask = torch.randn(B, H, W, Cout, generator=g).to(dev) if use_mask else None
+    base = torch.randn(B, H, W, Cout, generator=g).to(dev)
+    spec = ConvSpec.dense(*nchs)
+    wp = _packed_weight(w.contiguous(), spec, None)
+    y = base.clone()
+    shift = 1 if (use_res and B > 1) else 0
+    conv_raw([_src(t, 0, c, 0, None, 0, B) for t, c in zip(xs, nchs)], wp, spec.kpad * coutpad(Cout), b, Cout if bias else 0,
+             y.data_ptr(), H * W * Cout, Cout, B, H, W, Cout, 1, relu=relu,
+             residual=_src(res, 0, Cout, shift, B, 0, B) if use_res else None, bpg=B // G, accumulate=acc,
+             mask=_src(mask, 0, Cout, 0, None, 0, B) if use_mask else None)
+    xd = torch.cat(xs, -1).double().cpu()
+    wd = w.double().cpu()
+    ref = torch.stack([xd[i] @ wd[(i // (B // G))][:, :, 0].T for i in range(B)])
+    if bias: ref = ref + b.double().cpu()[torch.arange(B) // (B // G)][:, None, None, :]
+    if use_res: ref = ref + torch.roll(res.double().cpu(), -shift, 0)
+    if relu: ref = ref.clamp_min(0)
+    if use_mask: ref = torch.where(mask.double().cpu() > 0, ref, torch.zeros_like(ref))
+    if acc: ref = ref + base.double().cpu()
+    err = ((y.double().cpu() - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+    out.append((err, float(y.double().sum())))
+print(json.dumps(out))
+'''.replace("ROOT", repr(root))
+    res = {}
+    for tag, env in (("conv1p", {"BMC_CONV1P_MIN_TILES": "0"}), ("old", {"BMC_CONV1P": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    for i, ((e1, s1), (e0, s0)) in enumerate(zip(res["conv1p"], res["old"])):
+        assert e1 < 3e-6 and e0 < 3e-6, (i, e1, e0)
+        assert abs(s1 - s0) <= 1e-3 * max(1.0, abs(s0)), (i, s1, s0)
