@@ -775,8 +775,23 @@ class ConvFn(torch.autograd.Function):
             a_src = _src(g, 0, Cout, 0, None, 0, B)
             wb = ctx.has_bias and need[2]
             wp_, bp_ = ctx.params
+            v0 = meta.views[0]
             if wino_wgrad_ok(a_src, srcs, spec, taps, Cout, G) and not isinstance(wp_, (tuple, list)):
                 dw, db = wgrad_wino(a_src, srcs[0], B, H, W, spec, dev, wp_, bp_ if wb else None, weight.shape, want_bias=wb)
+            elif (ngp and 1 < G <= 4 and len(wp_) == G and wino_wgrad_ok(a_src, srcs, spec, taps, Cout, 1) and v0[2] == 0
+                  and v0[3] is None):
+                # grouped launch over separate parameters (conv_hp / conv_hn): one Winograd weight gradient per group, on the
+                # group's batch window of both operands
+                bpg = B // G
+                outs = []
+                for gi in range(G):
+                    a_g = _src(g, 0, Cout, 0, None, gi * bpg, bpg)
+                    x_g = _src(src_ts[0], v0[0], v0[1], 0, None, v0[4] + gi * bpg, bpg)
+                    outs.append(wgrad_wino(a_g, x_g, bpg, H, W, spec, dev, wp_[gi], bp_[gi] if wb else None, wp_[gi].shape, want_bias=wb))
+                dw = None if all(o[0] is None for o in outs) else torch.stack([
+                    o[0] if o[0] is not None else torch.zeros_like(wp_[i]) for i, o in enumerate(outs)])
+                db = None if (not wb or all(o[1] is None for o in outs)) else torch.stack([
+                    o[1] if o[1] is not None else torch.zeros_like(bp_[i]) for i, o in enumerate(outs)])
             else:
                 with wgrad_side(B * H * W, _flat_params(wp_, bp_ if wb else None), (g, *src_ts)):
                     r_pg = pgemm_raw(a_src, srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
