@@ -514,6 +514,20 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         it.b = t / a.tiles_y;
         return it;
     };
+    // The three tile walkers (halo loader, weight loader, epilogue) visit t_first, t_first + t_stride, ...: they advance by the
+    // digits of t_stride with carries, and the operands' batch maps (a modulo each) are re-evaluated only when the image
+    // changes -- a runtime integer division is ~30 VALU instructions, and ~15 of them per tile and wave sat beside the MFMAs.
+    const TileIt stp = decode(t_stride);
+    auto advance = [&](TileIt it) {
+        it.nt += stp.nt;
+        if (it.nt >= a.ntn) { it.nt -= a.ntn; ++it.tx; }
+        it.tx += stp.tx;
+        if (it.tx >= a.tiles_x) { it.tx -= a.tiles_x; ++it.ty; }
+        it.ty += stp.ty;
+        if (it.ty >= a.tiles_y) { it.ty -= a.tiles_y; ++it.b; }
+        it.b += stp.b;
+        return it;
+    };
 
     // ---- X loader: 16 DMA instructions per halo tile, 2 per wave (layout and quad stream as in the kernel above), in the
     // cheap form "uniform base (SGPR pair) + per-lane 32-bit offset": EVERY lane fetches a valid address -- pixels outside
@@ -527,9 +541,11 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     unsigned xoff[NXD];               // byte offset from the source's batch pointer (+ channel chunk)
     unsigned xzm = 0;                 // bit k: instruction k's quad belongs to a pixel outside the image (of the tile being LOADED)
     unsigned xzm_landed = 0;          // the same for the chunk in flight (zero_x consumes it; a tile's chunks share it)
+    int sb_s = -1, sb_b = -1;         // (source, image) sbase belongs to
     auto src_select = [&]() {
         const SrcDev S = tab[s_idx];
-        sbase = src_batch_ptr(S, xl_it.b); snch = S.nch;
+        if (s_idx != sb_s || xl_it.b != sb_b) { sbase = src_batch_ptr(S, xl_it.b); sb_s = s_idx; sb_b = xl_it.b; }
+        snch = S.nch;
         const int y0 = xl_it.ty * TH, x0 = xl_it.tx * TW;
         xzm = 0;
 #pragma unroll
@@ -559,7 +575,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         c_in += CK;
         if (++xl_chunk == nchunks) {
             xl_tile += t_stride;
-            if (xl_tile < t_hi) { xl_it = decode(xl_tile); xl_setup(); }
+            if (xl_tile < t_hi) { xl_it = advance(xl_it); xl_setup(); }
         } else if (c_in >= snch) {
             c_in = 0; ++s_idx;
             src_select();
@@ -581,8 +597,9 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     int wl_tile = t_first, wl_sub = 0, wl_cnt = 0;
     const float* wl_base = nullptr;
     const long long wrow = (long long)a.Coutpad * CK;
+    TileIt wl_it = decode(t_first);
     auto wl_setup = [&]() {
-        const TileIt it = decode(wl_tile);
+        const TileIt it = wl_it;
         const int grp = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
         wl_base = static_cast<const float*>(a.w) + (long long)grp * a.w_group_stride + (long long)it.nt * BN * CK;
         wl_sub = 0;
@@ -594,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         ++wl_cnt;
         if (++wl_sub == 4 * nchunks) {
             wl_tile += t_stride;
-            if (wl_tile < t_hi) wl_setup();
+            if (wl_tile < t_hi) { wl_it = advance(wl_it); wl_setup(); }
         }
     };
 
@@ -612,7 +629,12 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
 
     f32x4 acc[16][2];
     auto init_acc = [&]() {
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(init_lds + 16 * wave + 4 * lk);
+        // (the lane's quad index is re-derived here, once per tile, from v_mbcnt: kept live across the stage loop the address was
+        //  the one value the register allocator spilled, and its reload -- a scratch load -- waited, in order, for every DMA
+        //  in flight at the top of every tile)
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(init_lds + 16 * wave + 4 * (ln >> 4));
 #pragma unroll
         for (int p = 0; p < 16; ++p)
 #pragma unroll
@@ -709,6 +731,9 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    int ep_b = -1;
+    const float* ep_res = nullptr;
+    const float* ep_mask = nullptr;
     auto epilogue = [&](const TileIt& it) __attribute__((always_inline)) {
         pin_acc();
 #pragma unroll
@@ -735,8 +760,13 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         const int g = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
         const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
         float* const outb = a.out + (long long)it.b * a.out_batch_stride;
-        const float* const resb = a.residual.ptr ? src_batch_ptr(a.residual, it.b) : nullptr;
-        const float* const maskb = a.mask.ptr ? src_batch_ptr(a.mask, it.b) : nullptr;
+        if (it.b != ep_b) {
+            ep_b = it.b;
+            ep_res = a.residual.ptr ? src_batch_ptr(a.residual, it.b) : nullptr;
+            ep_mask = a.mask.ptr ? src_batch_ptr(a.mask, it.b) : nullptr;
+        }
+        const float* const resb = ep_res;
+        const float* const maskb = ep_mask;
         const int co = it.nt * BN + 16 * wave + 4 * lk;
         const bool cok = co < a.Cout;
         const bool simple = !resb && !maskb && !a.accumulate && (bias_pre || !biasg);
@@ -821,6 +851,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     load_first(Vb, Wb);
 
     int gs = 0, gc = 0;
+    TileIt ep_it = decode(t_first);
     for (int tile = t_first; tile < t_hi; tile += t_stride) {
         for (int c = 0; c < nchunks; ++c, ++gc) {
             const float* const xb = Xb + (gc & 1) * XBUFA;
@@ -843,7 +874,8 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
                 stage_tail(xi, has_next ? Vb + ((gs + 1) & 1) * VSTAGE : nullptr, Wb + ((gs + 1) % NWR) * WSTAGE, ufB, vfB);
             }
         }
-        epilogue(decode(tile));
+        epilogue(ep_it);
+        ep_it = advance(ep_it);
     }
 }
 

@@ -18,23 +18,29 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "bmcnet-esr_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
-FILES = ["conv", "conv_bf", "pgemm", "pgemm_bf", "chain", "conv1", "wino"]
+FILES = ["conv", "conv_bf", "pgemm", "pgemm_bf", "chain", "conv1", "conv1p", "wino", "wino_wgrad"]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 
 
 def _kernels(path):
     """-> {mangled name: dict(vgprs, scratch, occupancy, flat, m0_outside_asm)}"""
-    out, cur, body, in_asm = {}, None, None, False
+    out, cur, body, in_asm, in_loop = {}, None, None, False, False
     for ln in open(path):
         m = re.match(r"^(_Z\w+):", ln)
         if m:
             cur = m.group(1)
-            body = out[cur] = {"flat": 0, "m0": 0}
-            in_asm = False
+            body = out[cur] = {"flat": 0, "m0": 0, "scratch_in_loop": 0}
+            in_asm = in_loop = False
             continue
         if body is None:
             continue
+        if re.match(r"^\.LBB\d+_\d+:", ln):            # the compiler annotates the blocks of a loop ("in Loop: Header=..." / "Loop Header")
+            in_loop = "Loop" in ln
+        elif ln.lstrip().startswith(";") and "Loop" in ln and ("Header" in ln):
+            in_loop = True
+        if in_loop and re.search(r"\bscratch_(load|store)", ln.split(";")[0]):
+            body["scratch_in_loop"] += 1
         if "#ASMSTART" in ln:
             in_asm = True
         elif "#ASMEND" in ln:
@@ -83,14 +89,20 @@ def test_no_flat_memory_instructions(isa):
 
 
 def test_no_scratch(isa):
-    # two SGPRs parked in a VGPR lane: no memory traffic in the loop; wino2: one prologue-only value (stored and reloaded before
-    # the first stage: the kernel's 128 + 128 registers are all in use)
-    allowed = {"conv_kernelILi9ELi128ELi8E": 8, "wino2_conv_kernel": 8}
+    # two SGPRs parked in a VGPR lane: no memory traffic in the loop
+    # wino_wgrad: values parked before / reloaded after the stage loop (its 128 + 128 registers are all in use inside it) -- what
+    # matters there is test_no_scratch_traffic_inside_loops: a reload inside the loop waits, in order, for every prefetched row
+    allowed = {"conv_kernelILi9ELi128ELi8E": 8, "wino_wgrad_kernel": 64}
     bad = []
     for f, n, k in _all(isa):
         lim = max([v for key, v in allowed.items() if key in n] + [0])
         if k["ScratchSize"] > lim:
             bad.append((f, n, k["ScratchSize"]))
+    assert not bad, bad
+
+
+def test_no_scratch_traffic_inside_loops(isa):
+    bad = [(f, n, k["scratch_in_loop"]) for f, n, k in _all(isa) if k["scratch_in_loop"]]
     assert not bad, bad
 
 
@@ -107,10 +119,13 @@ def test_m0_only_inside_handwritten_asm(isa):
     ("conv_bf_kernelILi9ELi128ELi8ELi3E", 2), ("pgemm_bf9x3_kernel", 3),
     ("wino2_conv_kernel", 2),                   # 8 waves x (128 accumulators + <= 128 others): two waves per SIMD is the point of it
     ("wino_conv_kernel", 1),                    # 4 waves x 256 accumulators
+    ("wino_wgrad_kernel", 2),                   # 8 waves x (128 accumulators + <= 128 others)
+    ("conv1p_kernelILi8ELi1E", 4),              # K = 128: two 8-wave workgroups per CU
+    ("conv1p_kernelILi16ELi1E", 2),             # K = 256: 64 weight registers, one workgroup per CU
 ])
 def test_occupancy_budgets(isa, frag, min_occ):
     hits = [(n, k) for _, n, k in _all(isa) if frag in n]
     assert hits, frag
     for n, k in hits:
         assert k["Occupancy"] >= min_occ, (n, k)
-        assert k["ScratchSize"] <= 8, (n, k)
+        assert k["ScratchSize"] <= 8 or "wino_wgrad" in n, (n, k)
