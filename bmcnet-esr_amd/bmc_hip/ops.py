@@ -269,6 +269,19 @@ def wino_ok(B, H, W, Cout, taps):
     return cp % 128 == 0 and B * ((H + 7) // 8) * ((W + 15) // 16) * (cp // 128) >= WINO_MIN_TILES
 
 
+PAIR_SMALL = os.environ.get("BMC_PAIR_SMALL", "1") != "0"
+
+
+def pair_small(B2, H, W):
+    """Small frames: should two weight-distinct, equally shaped, independent residual blocks (ParallelBlk.conv1 / conv1_st,
+    models/BMCNet.py:19-22) run as ONE two-group launch per convolution over the stacked inputs?  Yes when one block's launch
+    does not reach a workgroup per CU but the pair does (the pair's 3x3 launches then take the Winograd kernel in fp32): at
+    31x56, bs 4 the step's 3x3 convolutions were 128-tile launches at 86 TFLOP/s.  The price is one concatenation of the two
+    inputs -- negligible at these sizes, which is why large frames keep the separate launches."""
+    t = B2 * ((H + 7) // 8) * ((W + 15) // 16)
+    return PAIR_SMALL and WINO and MATH == 0 and t < WINO_MIN_TILES <= 2 * t      # (bf16 arithmetic, no Winograd: 72 -> 76 ms, not used)
+
+
 def _packed_weight(w4: torch.Tensor, spec: ConvSpec, owner, wino=False):
     """[G,Cout,Cin,taps] -> MFMA staging layout (bmc_pack_weight; wino: the transformed weights of bmc_pack_weight_wino).
     owner: the parameter tensor w4 was derived from (cache key), or None for no caching."""

@@ -37,19 +37,11 @@ class ParallelBlk(nn.Module):
         if need_st:
             # both residual blocks write into the halves of one buffer, so the two lBIE calls (and, inside them, the
             # weight-shared conv1/conv2 and convf1/convf2 pairs) run as ONE fused twin node over 4B samples
-            B2 = x12.shape[0]
-            slot = ops.OutSlot(torch.empty((2 * B2,) + tuple(x12.shape[1:]), device=x12.device, dtype=x12.dtype), 0)
-            a = self.conv1.forward_nhwc(x12, out=slot)
-            b = self.conv1_st.forward_nhwc(xst12, out=ops.OutSlot(slot.t, B2))
-            o, xsst12 = self.lBIE.forward_twin(bie.Stack2Fn.apply(a, b, slot), xsst12)
+            o, xsst12 = self.lBIE.forward_twin(self._res_pair(x12, xst12), xsst12)
             x12, xst12 = bie.Unstack2Fn.unstack(o)
         elif bie.FUSE_FIRST and bie.chain_supported(x12.shape[-1]):
             # the same with only the first output of the local BIE (one fused node again: BIE.forward_first)
-            B2 = x12.shape[0]
-            slot = ops.OutSlot(torch.empty((2 * B2,) + tuple(x12.shape[1:]), device=x12.device, dtype=x12.dtype), 0)
-            a = self.conv1.forward_nhwc(x12, out=slot)
-            b = self.conv1_st.forward_nhwc(xst12, out=ops.OutSlot(slot.t, B2))
-            x12, xsst12 = self.lBIE.forward_first(bie.Stack2Fn.apply(a, b, slot), xsst12)
+            x12, xsst12 = self.lBIE.forward_first(self._res_pair(x12, xst12), xsst12)
             xst12 = None
         else:
             x12 = self.conv1.forward_nhwc(x12)
@@ -57,6 +49,21 @@ class ParallelBlk(nn.Module):
             x12, xst12, xsst12 = self.lBIE.forward_pair(x12, xst12, xsst12, need_second=False)
         x12, xs = self.gBIE.forward_twin(x12, xs)
         return x12, xs, xst12, xsst12
+
+    def _res_pair(self, x12, xst12):
+        """[conv1(x12); conv1_st(xst12)] as one tensor [2 * B2, H, W, C] (the two residual blocks have their own weights)."""
+        B2, H, W, _ = x12.shape
+        if ops.pair_small(B2, H, W):
+            # small frames: each convolution of the two blocks as ONE two-group launch over the stacked inputs (ops.pair_small)
+            xx = torch.cat([x12, xst12], 0)
+            c1, c2 = self.conv1, self.conv1_st
+            t = ops.conv_groups([View(xx)], (c1.conv1.weight, c2.conv1.weight), (c1.conv1.bias, c2.conv1.bias), c1._spec, relu=True)
+            return ops.conv_groups([View(t)], (c1.conv2.weight, c2.conv2.weight), (c1.conv2.bias, c2.conv2.bias), c1._spec,
+                                   residual=View(xx))
+        slot = ops.OutSlot(torch.empty((2 * B2,) + tuple(x12.shape[1:]), device=x12.device, dtype=x12.dtype), 0)
+        a = self.conv1.forward_nhwc(x12, out=slot)
+        b = self.conv1_st.forward_nhwc(xst12, out=ops.OutSlot(slot.t, B2))
+        return bie.Stack2Fn.apply(a, b, slot)
 
     def forward(self, x_1, x_2, x_s, x_1_st, x_2_st, x_1_s_st, x_2_s_st):
         B = x_1.shape[0]
