@@ -777,7 +777,7 @@ def test_streaming_inference_graph_replay_matches_eager():
 
 
 # ------------------------------------------------------------------ no kernel reads past the end of an operand
-@pytest.mark.parametrize("math", ["fp32", "bf16x6", "bf16", "fp32-wino"])
+@pytest.mark.parametrize("math", ["fp32", "bf16x6", "bf16", "fp32-wino", "fp32-c1p"])
 def test_no_reads_past_operand_end(math):
     """The conv fuzz shapes (1-5 sources, 3..90 pixel sides, fwd + data + weight gradients) with every operand placed so
     that it ENDS at the end of its own 2 MiB-multiple hipMalloc (caching allocator off, tools/fuzz_repro.py): an interior
@@ -786,8 +786,10 @@ def test_no_reads_past_operand_end(math):
     _gpu()
     import subprocess
     env = dict(os.environ, PYTORCH_NO_HIP_MEMORY_CACHING="1", PYTORCH_NO_CUDA_MEMORY_CACHING="1", FZ_END="1", FZ_SEEDS="2")
-    if math == "fp32-wino":        # the Winograd kernel's LDS-DMA halo / weight streams under the same guard (round 3)
+    if math == "fp32-wino":        # the Winograd kernels' LDS-DMA halo / weight streams and row loads under the same guard (round 3)
         math, env["FZ_WINO"] = "fp32", "1"
+    if math == "fp32-c1p":         # conv1p.hip's pixel-tile DMA (partial last tiles re-read the image's last pixel)
+        math, env["FZ_C1P"], env["BMC_CONV1P_MIN_TILES"] = "fp32", "1", "0"
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "fuzz_repro.py"), math],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("done"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])

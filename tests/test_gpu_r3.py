@@ -668,3 +668,48 @@ print(json.dumps(out))
     for i, ((e1, s1), (e0, s0)) in enumerate(zip(res["conv1p"], res["old"])):
         assert e1 < 3e-6 and e0 < 3e-6, (i, e1, e0)
         assert abs(s1 - s0) <= 1e-3 * max(1.0, abs(s0)), (i, s1, s0)
+
+
+# ------------------------------------------------------------------ small frames: paired residual blocks (ops.pair_small)
+def test_paired_residual_blocks_match_separate_launches():
+    """BMCNet(4,128,2) at 31x56, bs 4 (configs[3]'s frame: one block's launch is 128 tiles, the pair 256): two recurrent windows
+    forward + backward with the two weight-distinct residual blocks of every ParallelBlk as two-group launches (the default
+    there) and as separate launches -- same losses and parameter gradients up to the Winograd / direct kernel difference."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from models.BMCNet import BMCNet
+    torch.manual_seed(3)
+    scale, n_c, n_b, B, H, W = 4, 128, 2, 4, 31, 56
+    m = BMCNet(scale, n_c, n_b).to(dev)
+    scaled_init(m, 2.0)
+    g = torch.Generator().manual_seed(8)
+    frames = torch.poisson(torch.full((B, 3, 2, H, W), 0.284), generator=g).to(dev)
+    gt = torch.rand(B, 2, scale * H, scale * W, generator=g).to(dev)
+    assert ops.pair_small(2 * B, H, W)
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        z = lambda c: torch.zeros(B, c, H, W, device=dev)
+        state = (z(n_c), z(n_c), z(n_c), z(2 * scale * scale))
+        loss = 0
+        for i in range(2):
+            out = m(frames[:, i:i + 2].transpose(1, 2), *state, i == 0)
+            state = tuple(out)
+            loss = loss + F.mse_loss(out[-1], gt)
+        loss.backward()
+        return float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    la, ga = run()
+    old = ops.PAIR_SMALL
+    ops.PAIR_SMALL = False
+    try:
+        assert not ops.pair_small(2 * B, H, W)
+        lb, gb = run()
+    finally:
+        ops.PAIR_SMALL = old
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    assert ga.keys() == gb.keys()
+    worst = max(rel_l2(ga[k], gb[k]) for k in ga)
+    print("paired vs separate: loss %.6f / %.6f, worst parameter-gradient difference %.2e" % (la, lb, worst))
+    assert worst < 2e-4
