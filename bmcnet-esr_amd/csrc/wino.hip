@@ -503,7 +503,6 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     const int my_tiles = t_first < t_hi ? (t_hi - t_first + t_stride - 1) / t_stride : 0;
     if (my_tiles == 0) return;
     const int nchunks = a.nchunks;
-    const int total_chunks = my_tiles * nchunks, total_stages = 4 * total_chunks;
 
     struct TileIt { int nt, tx, ty, b; };
     auto decode = [&](int t) {
@@ -575,7 +574,8 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         c_in += CK;
         if (++xl_chunk == nchunks) {
             xl_tile += t_stride;
-            if (xl_tile < t_hi) { xl_it = advance(xl_it); xl_setup(); }
+            if (xl_tile < t_hi) xl_it = advance(xl_it);      // (past the last tile: the same tile again -- see the stage loop)
+            xl_setup();
         } else if (c_in >= snch) {
             c_in = 0; ++s_idx;
             src_select();
@@ -593,25 +593,28 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
             }
     };
 
-    // ---- W ring loader: wave w copies half (w & 1) of position nu = w >> 1 of a stage (4 KB)
-    int wl_tile = t_first, wl_sub = 0, wl_cnt = 0;
-    const float* wl_base = nullptr;
+    // ---- W ring loader: wave w copies half (w & 1) of position nu = w >> 1 of a stage (4 KB).  Source pointer and ring slot
+    // advance incrementally (the per-stage scalar work sits in front of the stage's MFMAs in BOTH waves of a SIMD at once --
+    // they leave the barrier together -- so it is matrix-pipe idle time: ~120 scalar instructions per 32 MFMAs were 24 %)
+    int wl_tile = t_first, wl_sub = 0, wslot = 0;
+    const float* wp = nullptr;
     const long long wrow = (long long)a.Coutpad * CK;
     TileIt wl_it = decode(t_first);
     auto wl_setup = [&]() {
-        const TileIt it = wl_it;
-        const int grp = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
-        wl_base = static_cast<const float*>(a.w) + (long long)grp * a.w_group_stride + (long long)it.nt * BN * CK;
+        const int grp = a.batch_per_group >= a.B ? 0 : wl_it.b / a.batch_per_group;
+        wp = static_cast<const float*>(a.w) + (long long)grp * a.w_group_stride + (long long)wl_it.nt * BN * CK + (wave >> 1) * wrow +
+             (wave & 1) * 1024;
         wl_sub = 0;
     };
+    const unsigned wdst0 = wb_lds + (unsigned)(((wave >> 1) * BN * CK + (wave & 1) * 1024) * 4);
     auto issue_w = [&]() {
-        const float* p = wl_base + ((long long)wl_sub * 4 + (wave >> 1)) * wrow + (wave & 1) * 1024;
-        const unsigned dst = wb_lds + (unsigned)(((wl_cnt % NWR) * WSTAGE + (wave >> 1) * BN * CK + (wave & 1) * 1024) * 4);
-        if (!(BMC_WINO_ABL & 2)) dma4k(p, (unsigned)(lane * 16), dst);
-        ++wl_cnt;
+        if (!(BMC_WINO_ABL & 2)) dma4k(wp, (unsigned)(lane * 16), wdst0 + (unsigned)(wslot * WSTAGE * 4));
+        wslot = wslot == NWR - 1 ? 0 : wslot + 1;
+        wp += 4 * wrow;
         if (++wl_sub == 4 * nchunks) {
             wl_tile += t_stride;
-            if (wl_tile < t_hi) { wl_it = advance(wl_it); wl_setup(); }
+            if (wl_tile < t_hi) wl_it = advance(wl_it);      // (past the last tile: the same tile again)
+            wl_setup();
         }
     };
 
@@ -724,7 +727,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     };
     // second half: after the barrier; vb_n / wb_n: the NEXT stage's (just published) operands, or nullptr
     auto stage_tail = [&](int xi, const float* vb_n, const float* wb_n, const f32x4 (&ufB)[2], const f32x4 (&vfB)[2][2]) __attribute__((always_inline)) {
-        if (vb_n) load_first(vb_n, wb_n);
+        load_first(vb_n, wb_n);
         __builtin_amdgcn_sched_barrier(0);
         mfma8(acc[4 * xi + 2], ufB[0], vfB[0]);
         mfma8(acc[4 * xi + 3], ufB[1], vfB[1]);
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     xl_setup();
     wl_setup();
     load_x(0);
-    for (int k = 0; k < DW && wl_cnt < total_stages; ++k) issue_w();
+    for (int k = 0; k < DW; ++k) issue_w();
     dma_wait<0>();
     zero_x(0);
     __syncthreads();
@@ -850,33 +853,37 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     init_acc();
     load_first(Vb, Wb);
 
-    int gs = 0, gc = 0;
+    // The loaders never stop: past the workgroup's last tile they stream that tile's operands again (valid addresses, into
+    // ring slots / buffers nobody reads any more), so that no stage carries an "is there a next one" branch and every wait
+    // is a constant.  The DMA still in flight is drained before the workgroup ends.
+    int gs = 0, gc = 0, rslot = 0;
     TileIt ep_it = decode(t_first);
     for (int tile = t_first; tile < t_hi; tile += t_stride) {
         for (int c = 0; c < nchunks; ++c, ++gc) {
             const float* const xb = Xb + (gc & 1) * XBUFA;
-            const bool more_x = gc + 1 < total_chunks;
+            const float* const xbn = Xb + ((gc + 1) & 1) * XBUFA;
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi, ++gs) {
-                const bool issued = wl_cnt < total_stages;
-                if (issued) issue_w();
-                if (xi == 0 && more_x) load_x((gc + 1) & 1);
-                const bool has_next = gs + 1 < total_stages;
-                // (the very last stage produces a V nobody reads, from this chunk's halo: no branch around the production)
-                const float* const xb_n = (xi == 3 && has_next) ? Xb + ((gc + 1) & 1) * XBUFA : xb;
+                issue_w();
+                if (xi == 0) load_x((gc + 1) & 1);
+                const int nslot = rslot == NWR - 1 ? 0 : rslot + 1;
                 f32x4 ufB[2], vfB[2][2];
-                stage_head(Vb + (gs & 1) * VSTAGE, Wb + (gs % NWR) * WSTAGE, xi, xb_n, Vb + ((gs + 1) & 1) * VSTAGE, (xi + 1) & 3, ufB, vfB);
-                if (!issued) dma_wait<0>();
-                else if (xi <= 1 && more_x) dma_wait<4 + NXD>();
-                else dma_wait<4>();
-                if (xi == 2 && more_x) zero_x((gc + 1) & 1);       // the next chunk's halo has landed (it is older than stage gs + 1)
+                stage_head(Vb + (gs & 1) * VSTAGE, Wb + rslot * WSTAGE, xi, xi == 3 ? xbn : xb, Vb + ((gs + 1) & 1) * VSTAGE, (xi + 1) & 3,
+                           ufB, vfB);
+                // everything but the newest DMA is complete: stage gs + 1's weights (the DW = 2 ring runs one stage further ahead:
+                // this stage's 4 instructions, and at xi = 0 / 1 the NXD halo instructions issued behind stage gs + 1's); at
+                // xi = 2 / 3 the halo is older than stage gs + 1 and lands with it, in time for the next chunk
+                if (xi <= 1) dma_wait<4 + NXD>(); else dma_wait<4>();
+                if (xi == 2) zero_x((gc + 1) & 1);       // the next chunk's halo has landed (it is older than stage gs + 1)
                 if (BMC_WINO_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else ring_publish();
-                stage_tail(xi, has_next ? Vb + ((gs + 1) & 1) * VSTAGE : nullptr, Wb + ((gs + 1) % NWR) * WSTAGE, ufB, vfB);
+                stage_tail(xi, Vb + ((gs + 1) & 1) * VSTAGE, Wb + nslot * WSTAGE, ufB, vfB);
+                rslot = nslot;
             }
         }
         epilogue(ep_it);
         ep_it = advance(ep_it);
     }
+    dma_wait<0>();
 }
 
 // U = G g G^T for every (output channel, packed input channel) pair, in the kernel's streaming order.
