@@ -28,6 +28,9 @@
 #include "dma_ring.h"
 #include <stdlib.h>
 
+#ifndef BMC_WINO_DMA_TAIL
+#define BMC_WINO_DMA_TAIL 1      // 1: a stage's DMA requests sit between its last two MFMA groups; 0: in front of its first
+#endif
 #ifndef BMC_WINO_ABL
 #define BMC_WINO_ABL 0     // ablation bits for tools/ builds only: 1 no MFMAs, 2 no weight DMA, 4 no halo loads, 8 no epilogue stores,
                            // 16 no patch reads / input transform, 32 no weight fragment reads, 64 no barriers, 128 no output transform
@@ -513,9 +516,9 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         it.b = t / a.tiles_y;
         return it;
     };
-    // The three tile walkers (halo loader, weight loader, epilogue) visit t_first, t_first + t_stride, ...: they advance by the
-    // digits of t_stride with carries, and the operands' batch maps (a modulo each) are re-evaluated only when the image
-    // changes -- a runtime integer division is ~30 VALU instructions, and ~15 of them per tile and wave sat beside the MFMAs.
+
+    // The halo and weight loaders visit t_first, t_first + t_stride, ...: they advance by the digits of t_stride with carries
+    // (a decode() there is three runtime divisions of scalar code the compiler speculates into the per-stage path)
     const TileIt stp = decode(t_stride);
     auto advance = [&](TileIt it) {
         it.nt += stp.nt;
@@ -549,8 +552,9 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         xzm = 0;
 #pragma unroll
         for (int k = 0; k < NXD; ++k) {
-            int Q = (wave * NXD + k) * 64 + lane;
-            asm volatile("" : "+v"(Q));       // (recomputed here, once per tile and source: not a loop-invariant to keep in a register)
+            int ln;                           // (lane index re-derived here, once per tile and source: not a loop-invariant to keep
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));    // in a register -- or to spill)
+            const int Q = (wave * NXD + k) * 64 + ln;
             const int hy = Q / 96, rq = Q - hy * 96, hx = rq / 5, q = rq - hx * 5;
             const bool real = hy < HHT && hx < HWD && q < 4;            // a quad some patch read will touch
             int y = y0 - 1 + hy, x = x0 - 1 + hx;
@@ -589,7 +593,9 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
                 f32x4 z;
                 asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0"
                              : "=v"(z[0]), "=v"(z[1]), "=v"(z[2]), "=v"(z[3]));      // (made here: a zero quad kept live would be spilled)
-                *reinterpret_cast<f32x4*>(Xb + buf * XBUFA + ((wave * NXD + k) * 64 + lane) * 4) = z;
+                int zl;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(zl));
+                *reinterpret_cast<f32x4*>(Xb + buf * XBUFA + ((wave * NXD + k) * 64 + zl) * 4) = z;
             }
     };
 
@@ -726,10 +732,19 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         __builtin_amdgcn_sched_barrier(0);
     };
     // second half: after the barrier; vb_n / wb_n: the NEXT stage's (just published) operands, or nullptr
-    auto stage_tail = [&](int xi, const float* vb_n, const float* wb_n, const f32x4 (&ufB)[2], const f32x4 (&vfB)[2][2]) __attribute__((always_inline)) {
+    // (the DMA issue of the stage -- weights three stages ahead, after xi = 3 the halo two chunks ahead -- sits BETWEEN the two
+    //  MFMA groups: scalar address work placed in front of a stage's first MFMA is matrix-pipe idle time, because the two
+    //  waves of a SIMD leave the barrier together and reach it together)
+    auto stage_tail = [&](int xi, const float* vb_n, const float* wb_n, const f32x4 (&ufB)[2], const f32x4 (&vfB)[2][2], int xbuf) __attribute__((always_inline)) {
         load_first(vb_n, wb_n);
         __builtin_amdgcn_sched_barrier(0);
         mfma8(acc[4 * xi + 2], ufB[0], vfB[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (BMC_WINO_DMA_TAIL) {
+            issue_w();
+            if (xi == 3) load_x(xbuf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         mfma8(acc[4 * xi + 3], ufB[1], vfB[1]);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -770,14 +785,17 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         }
         const float* const resb = ep_res;
         const float* const maskb = ep_mask;
-        const int co = it.nt * BN + 16 * wave + 4 * lk;
+        int eln;      // (lane index re-derived: the epilogue's lane-dependent values are not kept -- or spilled -- across the stages)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(eln));
+        const int elk = eln >> 4, elj = eln & 15;
+        const int co = it.nt * BN + 16 * wave + 4 * elk;
         const bool cok = co < a.Cout;
         const bool simple = !resb && !maskb && !a.accumulate && (bias_pre || !biasg);
         f32x4 bq = {0.f, 0.f, 0.f, 0.f};
         if (biasg && !bias_pre && cok) bq = ldg16(biasg + co);
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
-            const int t = 16 * tb + lj, tr = t >> 3, tc = t & 7;
+            const int t = 16 * tb + elj, tr = t >> 3, tc = t & 7;
             bool pok[4];
             int pix[4];
 #pragma unroll
@@ -840,9 +858,10 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     xl_setup();
     wl_setup();
     load_x(0);
-    for (int k = 0; k < DW; ++k) issue_w();
+    for (int k = 0; k < (BMC_WINO_DMA_TAIL ? NWR : DW); ++k) issue_w();          // stage g's tail requests the weights of stage g + NWR
     dma_wait<0>();
     zero_x(0);
+    if (BMC_WINO_DMA_TAIL) load_x(1);                 // the halo of the second chunk: in flight across the first stages
     __syncthreads();
     {
         f32x4 d[4];
@@ -857,31 +876,31 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     // ring slots / buffers nobody reads any more), so that no stage carries an "is there a next one" branch and every wait
     // is a constant.  The DMA still in flight is drained before the workgroup ends.
     int gs = 0, gc = 0, rslot = 0;
-    TileIt ep_it = decode(t_first);
     for (int tile = t_first; tile < t_hi; tile += t_stride) {
         for (int c = 0; c < nchunks; ++c, ++gc) {
             const float* const xb = Xb + (gc & 1) * XBUFA;
             const float* const xbn = Xb + ((gc + 1) & 1) * XBUFA;
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi, ++gs) {
-                issue_w();
-                if (xi == 0) load_x((gc + 1) & 1);
+                if (!BMC_WINO_DMA_TAIL) {
+                    issue_w();
+                    if (xi == 0) load_x((gc + 1) & 1);
+                }
                 const int nslot = rslot == NWR - 1 ? 0 : rslot + 1;
                 f32x4 ufB[2], vfB[2][2];
                 stage_head(Vb + (gs & 1) * VSTAGE, Wb + rslot * WSTAGE, xi, xi == 3 ? xbn : xb, Vb + ((gs + 1) & 1) * VSTAGE, (xi + 1) & 3,
                            ufB, vfB);
-                // everything but the newest DMA is complete: stage gs + 1's weights (the DW = 2 ring runs one stage further ahead:
-                // this stage's 4 instructions, and at xi = 0 / 1 the NXD halo instructions issued behind stage gs + 1's); at
-                // xi = 2 / 3 the halo is older than stage gs + 1 and lands with it, in time for the next chunk
-                if (xi <= 1) dma_wait<4 + NXD>(); else dma_wait<4>();
+                // everything but the newest DMA is complete: stage gs + 1's weights have landed (younger than them: the 4
+                // instructions of stage gs + 2's weights, and at xi = 0 the NXD halo instructions issued right behind those in the
+                // previous stage's tail); the halo itself is complete by xi = 1, in time for the production at xi = 3
+                if (BMC_WINO_DMA_TAIL ? xi == 0 : xi <= 1) dma_wait<4 + NXD>(); else dma_wait<4>();
                 if (xi == 2) zero_x((gc + 1) & 1);       // the next chunk's halo has landed (it is older than stage gs + 1)
                 if (BMC_WINO_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else ring_publish();
-                stage_tail(xi, Vb + ((gs + 1) & 1) * VSTAGE, Wb + nslot * WSTAGE, ufB, vfB);
+                stage_tail(xi, Vb + ((gs + 1) & 1) * VSTAGE, Wb + nslot * WSTAGE, ufB, vfB, gc & 1);
                 rslot = nslot;
             }
         }
-        epilogue(ep_it);
-        ep_it = advance(ep_it);
+        epilogue(decode(tile));
     }
     dma_wait<0>();
 }
