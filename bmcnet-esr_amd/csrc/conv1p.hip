@@ -168,9 +168,6 @@ __global__ __launch_bounds__(512, (NCH == 8 && DEPTH == 1) ? 4 : 2) void conv1p_
     const float* maskb = nullptr;
     for (; tile < t_hi; tile += t_stride, ++n) {
         const bool more = tl < t_hi;
-        if (more) {      // tile n + DEPTH into the buffer tile n - 1 was read from (before the previous barrier)
-            issue_x(itl, nl % NS); itl = advance(itl); tl += t_stride; ++nl;
-        }
         if (it.b != ep_b) {
             ep_b = it.b;
             grp = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
@@ -180,15 +177,6 @@ __global__ __launch_bounds__(512, (NCH == 8 && DEPTH == 1) ? 4 : 2) void conv1p_
         }
         if (grp != w_grp || it.nt != w_nt) load_w(grp, it.nt);
 
-        const int co = it.nt * 128 + 16 * wave + 4 * lk;
-        const bool cok = co < a.Cout;
-        int pix[4];
-        bool ok[4];
-#pragma unroll
-        for (int pb = 0; pb < 4; ++pb) {
-            pix[pb] = it.pt * PX + pb * 16 + li;
-            ok[pb] = pix[pb] < HW && cok;
-        }
         // ---- the tile's MFMAs: chunk c's pixel fragments are read while chunk c - 1 is multiplied
         const float* const xb = lds + (n % NS) * SLOT;
         f32x4 acc[4];
@@ -207,6 +195,10 @@ __global__ __launch_bounds__(512, (NCH == 8 && DEPTH == 1) ? 4 : 2) void conv1p_
                     else acc[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][j], xfA[pb][j], acc[pb], 0, 0, 0);
                 }
             if (c + 2 < NCH) read_x(xb, c + 2, xfA);
+            if (c == 0 && more) {      // tile n + DEPTH into the buffer tile n - 1 was read from (before the previous barrier); requested
+                                       // here, between MFMA groups, not in front of the tile's first MFMA
+                issue_x(itl, nl % NS); itl = advance(itl); tl += t_stride; ++nl;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -216,6 +208,15 @@ __global__ __launch_bounds__(512, (NCH == 8 && DEPTH == 1) ? 4 : 2) void conv1p_
                 }
         }
 
+        const int co = it.nt * 128 + 16 * wave + 4 * lk;
+        const bool cok = co < a.Cout;
+        int pix[4];
+        bool ok[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            pix[pb] = it.pt * PX + pb * 16 + li;
+            ok[pb] = pix[pb] < HW && cok;
+        }
         // ---- epilogue (operands fetched after the MFMAs, one at a time: 16 registers instead of 48 across the MFMA loop; with
         //      four waves per SIMD the other waves cover the round trip)
         if (resb) {
