@@ -459,9 +459,10 @@ def wino_wgrad_ok(a_src, x_srcs, spec, taps, Cout, G):
     return k0 >= 0 and spec.kmap_host == list(range(k0, k0 + 128))
 
 
-def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias=True):
+def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias=True, k0=None, full=None):
     """(dW, db) of a convolution wino_wgrad_ok() accepted, with reduce_wgrad's conventions: None where the sums went straight
-    into a leaf parameter's .grad."""
+    into a leaf parameter's .grad.  k0 / full: the launch covers only the weight columns [k0, k0 + 128) of a wider convolution
+    (one 128-channel source of a multi-source launch: split_wgrad_ok)."""
     nsplit = lib._ww_nsplit(B, H, W)
     part = torch.empty(nsplit * 16 * 128 * 128, device=dev, dtype=torch.float32)
     bpart = torch.empty(nsplit * 128, device=dev, dtype=torch.float32) if want_bias else None
@@ -470,7 +471,8 @@ def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want
     lib.call(lib._ww, "bmc_wgrad_wino", C.byref(a_src), C.byref(x_src), B, H, W, nsplit, part.data_ptr(),
              bpart.data_ptr() if want_bias else None, _stream())
     _prof_end(e0, "wgrad_wino<9>", 2.0 * B * H * W * 128 * 9 * 128)
-    k0, full = spec.kmap_host[0], spec.covers_all
+    k0 = spec.kmap_host[0] if k0 is None else k0
+    full = spec.covers_all if full is None else full
     sg = sink_group([w_param, b_param] if want_bias else [w_param], full) if w_param is not None else None
     if sg is not None:
         (gw, *rest), acc = sg
@@ -482,6 +484,35 @@ def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want
     lib.call(lib._ww_red, "bmc_wgrad_wino_reduce", part.data_ptr(), nsplit, dw.data_ptr(), spec.cin, k0, 0,
              bpart.data_ptr() if want_bias else None, db.data_ptr() if want_bias else None, _stream())
     return dw.view(w_shape), db
+
+
+def split_wgrad(spec, metas):
+    """A multi-source 3x3 convolution with 128 outputs whose weight gradient is worth splitting: every dense 128-channel
+    source (contiguous weight columns, no batch map) takes the Winograd kernel, the narrow rest ONE pixel-reduction launch
+    over a sub-spec of the same weight tensor (the shared part of conv_fs: two 128-channel sources + 2 x 16 channels;
+    conv_fpst, conv_fps: one + 16 / 32).  -> ([(source index, k0)], [narrow source indices], sub-spec or None) or None.
+    Cached on the spec."""
+    hit = getattr(spec, "_split", None)
+    if hit is not None:
+        return hit or None
+    big, rest, off = [], [], 0
+    for i, n in enumerate(spec.nch):
+        seg = spec.kmap_host[off:off + n]
+        c0, nch, shift, mod, b0 = metas[i]
+        if n == 128 and nch == 128 and shift == 0 and mod is None and seg[0] >= 0 and seg == list(range(seg[0], seg[0] + 128)):
+            big.append((i, seg[0]))
+        else:
+            rest.append(i)
+        off += n
+    res = False
+    if big and len(spec.nch) > 1:
+        sub = None
+        if rest:
+            offs = [sum(spec.nch[:i]) for i in range(len(spec.nch))]
+            sub = ConvSpec([spec.kmap_host[offs[i]:offs[i] + spec.nch[i]] for i in rest], cin=spec.cin)
+        res = (big, rest, sub)
+    spec._split = res
+    return res or None
 
 
 def relu_bwd(dy, y):
@@ -789,7 +820,26 @@ class ConvFn(torch.autograd.Function):
             wb = ctx.has_bias and need[2]
             wp_, bp_ = ctx.params
             v0 = meta.views[0]
-            if wino_wgrad_ok(a_src, srcs, spec, taps, Cout, G) and not isinstance(wp_, (tuple, list)):
+            sp = None
+            if (WINO and WINO_WGRAD and MATH == 0 and taps == 9 and G == 1 and Cout == 128 and nsrc > 1 and not ngp
+                    and is_sink(wp_) and (not wb or is_sink(bp_)) and a_src.pix_stride == 128
+                    and all(t.shape[3] == 128 for t, n in zip(src_ts, spec.nch) if n == 128)):
+                sp = split_wgrad(spec, meta.views)
+            if sp is not None:
+                # multi-source convolution on leaf parameters: the 128-channel sources through the Winograd kernel (each its own
+                # column window of the weight gradient), the narrow ones through one pixel-reduction launch; all of them add
+                # into the same .grad (the first one zero-fills it: none defines every column)
+                big, rest, sub = sp
+                for n, (i, k0) in enumerate(big):
+                    wgrad_wino(a_src, srcs[i], B, H, W, spec, dev, wp_, bp_ if (wb and n == 0) else None, weight.shape,
+                               want_bias=wb and n == 0, k0=k0, full=False)
+                if rest:
+                    with wgrad_side(B * H * W, [wp_], (g, *src_ts)):
+                        r_pg = pgemm_raw(a_src, [srcs[i] for i in rest], B, H, W, taps, B, Cout, sub.kpad, dev,
+                                         flops=2.0 * B * H * W * Cout * taps * sub.kreal)
+                        reduce_wgrad(r_pg[0], r_pg[1], 1, taps, Cout, sub, dev, None, wp_, None, weight.shape)
+                dw = db = None
+            elif wino_wgrad_ok(a_src, srcs, spec, taps, Cout, G) and not isinstance(wp_, (tuple, list)):
                 dw, db = wgrad_wino(a_src, srcs[0], B, H, W, spec, dev, wp_, bp_ if wb else None, weight.shape, want_bias=wb)
             elif (ngp and 1 < G <= 4 and len(wp_) == G and wino_wgrad_ok(a_src, srcs, spec, taps, Cout, 1) and v0[2] == 0
                   and v0[3] is None):
