@@ -492,9 +492,10 @@ def split_wgrad(spec, metas):
     over a sub-spec of the same weight tensor (the shared part of conv_fs: two 128-channel sources + 2 x 16 channels;
     conv_fpst, conv_fps: one + 16 / 32).  -> ([(source index, k0)], [narrow source indices], sub-spec or None) or None.
     Cached on the spec."""
-    hit = getattr(spec, "_split", None)
-    if hit is not None:
-        return hit or None
+    cache = spec.__dict__.setdefault("_split", {})
+    key = tuple(tuple(m) for m in metas)
+    if key in cache:
+        return cache[key] or None
     big, rest, off = [], [], 0
     for i, n in enumerate(spec.nch):
         seg = spec.kmap_host[off:off + n]
@@ -511,7 +512,7 @@ def split_wgrad(spec, metas):
             offs = [sum(spec.nch[:i]) for i in range(len(spec.nch))]
             sub = ConvSpec([spec.kmap_host[offs[i]:offs[i] + spec.nch[i]] for i in rest], cin=spec.cin)
         res = (big, rest, sub)
-    spec._split = res
+    cache[key] = res
     return res or None
 
 

@@ -133,3 +133,24 @@ def test_stacked_weight_cache_follows_parameter_versions():
     s2 = ops.stacked((c, b), lambda: torch.stack([c.detach(), b.detach()]))
     assert s2 is not s1 and torch.equal(s2[0], c.detach())
     assert ops.stacked((a, b), build) is s1 and len(calls) == 2
+
+
+def test_split_wgrad_plan_of_multi_source_convolutions():
+    """ops.split_wgrad (host logic, no launch): dense 128-channel sources without a batch map go to the Winograd weight-gradient
+    kernel with their own column offset, everything else into one sub-spec over the SAME weight tensor; single-source and
+    all-narrow convolutions are not split; the plan is cached per view set."""
+    from bmc_hip import ops
+    sp = ops.ConvSpec([list(range(0, 128)), list(range(128, 256)), list(range(256, 272)), list(range(272, 288))])
+    plain = [(0, 128, 0, None, 0), (0, 128, 0, None, 4), (0, 16, 0, None, 0), (0, 16, 0, None, 4)]
+    big, rest, sub = ops.split_wgrad(sp, plain)
+    assert big == [(0, 0), (1, 128)] and rest == [2, 3]
+    assert sub.cin == sp.cin and sub.kmap_host == list(range(256, 288)) and not sub.covers_all
+    assert ops.split_wgrad(sp, plain) is ops.split_wgrad(sp, plain)
+    big, rest, sub = ops.split_wgrad(sp, [(0, 128, 1, 8, 0)] + plain[1:])          # source 0 read through a batch rotation
+    assert big == [(1, 128)] and rest == [0, 2, 3] and sub.kmap_host[:128] == list(range(0, 128))
+    # padded narrow sources (conv_fpst: 6 real channels in a 16-channel window) keep their -1 entries in the sub-spec
+    sp2 = ops.ConvSpec([list(range(0, 6)) + [-1] * 10, list(range(6, 134)), list(range(134, 150))])
+    big, rest, sub = ops.split_wgrad(sp2, [(0, 16, 0, None, 0), (0, 128, 0, None, 0), (0, 16, 0, None, 0)])
+    assert big == [(1, 6)] and rest == [0, 2] and sub.kmap_host[:8] == [0, 1, 2, 3, 4, 5, -1, -1] and sub.cin == 150
+    assert ops.split_wgrad(ops.ConvSpec.dense(128), [(0, 128, 0, None, 0)]) is None
+    assert ops.split_wgrad(ops.ConvSpec.dense(16, 32), [(0, 16, 0, None, 0), (0, 32, 0, None, 0)]) is None
