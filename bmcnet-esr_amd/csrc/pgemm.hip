@@ -475,7 +475,9 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
 }
 
 // threads sharing one output's splits: at most four loads per thread, all in flight at once (the kernel is latency-bound)
-static int reduce_parts(int nsplit) { return nsplit <= 4 ? 1 : nsplit <= 8 ? 2 : nsplit <= 16 ? 4 : 8; }
+// (many splits: 16 / 32 threads per output quad -- the 1x1 weight gradients have only 4 096 quads, 8 parts left half the
+//  CUs without a block and every thread with 8 dependent rounds of loads)
+static int reduce_parts(int nsplit) { return nsplit <= 4 ? 1 : nsplit <= 8 ? 2 : nsplit <= 16 ? 4 : nsplit <= 64 ? 8 : nsplit <= 128 ? 16 : 32; }
 
 extern "C" int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, int taps, int M, int N, const int* kmap,
                                        int Cin, float* dw, int accumulate, const float* bias_slabs, float* db,
