@@ -713,3 +713,49 @@ def test_paired_residual_blocks_match_separate_launches():
     worst = max(rel_l2(ga[k], gb[k]) for k in ga)
     print("paired vs separate: loss %.6f / %.6f, worst parameter-gradient difference %.2e" % (la, lb, worst))
     assert worst < 2e-4
+
+
+@pytest.mark.parametrize("cins", [[16, 128, 16], [128, 128, 16, 16], [128, 32]])
+def test_split_multi_source_weight_gradient_vs_float64(cins):
+    """ops.split_wgrad on the GPU: a multi-source 3x3 convolution on LEAF parameters -- the 128-channel sources' weight gradients
+    through the Winograd kernel (each into its own column window of .grad), the narrow ones through one pixel-reduction launch,
+    the bias from the first -- against float64 autograd, and against the single direct launch (BMC_WINO_WGRAD off)."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from bmc_hip.ops import ConvSpec, View
+    torch.manual_seed(sum(cins))
+    B, H, W, Cout = 2, 13, 22, 128
+    xs = [torch.randn(B, H, W, c, device=dev) for c in cins]
+    w = torch.nn.Parameter(torch.randn(Cout, sum(cins), 3, 3, device=dev) * 0.05)
+    b = torch.nn.Parameter(torch.randn(Cout, device=dev) * 0.1)
+    go = torch.randn(B, H, W, Cout, device=dev)
+    spec = ConvSpec.dense(*cins)
+    ops.set_accumulate_param_grads(True)
+
+    def grads():
+        w.grad = b.grad = None
+        y = ops.conv([View(x) for x in xs], w, b, spec, relu=True)
+        y.backward(go)
+        return w.grad.detach().clone(), b.grad.detach().clone()
+
+    assert ops.split_wgrad(spec, [View(x).meta() for x in xs]) is not None
+    gw, gb = grads()
+    old = ops.WINO_WGRAD
+    ops.WINO_WGRAD = False
+    try:
+        gw_d, gb_d = grads()
+    finally:
+        ops.WINO_WGRAD = old
+    x64 = torch.cat([x.cpu().double() for x in xs], -1).permute(0, 3, 1, 2)
+    w64 = w.detach().cpu().double().requires_grad_(True)
+    b64 = b.detach().cpu().double().requires_grad_(True)
+    y64 = F.relu(F.conv2d(x64, w64, b64, padding=1))
+    y64.backward(go.cpu().double().permute(0, 3, 1, 2))
+    rel = lambda a, r: float((a.cpu().double() - r).norm() / r.norm())
+    e_w, e_b, e_d = rel(gw, w64.grad), rel(gb, b64.grad), rel(gw_d, w64.grad)
+    print("sources %s: split dW %.2e db %.2e, single launch dW %.2e" % (cins, e_w, e_b, e_d))
+    assert e_w < 2e-6 and e_b < 2e-6 and e_d < 2e-6
+    # a second backward accumulates (gradient accumulation over micro-batches): exactly twice the first
+    y = ops.conv([View(x) for x in xs], w, b, spec, relu=True)
+    y.backward(go)
+    assert rel(w.grad, 2 * w64.grad) < 2e-6 and rel(b.grad, 2 * b64.grad) < 2e-6
