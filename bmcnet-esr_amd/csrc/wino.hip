@@ -56,6 +56,24 @@ __device__ __attribute__((aligned(16))) const float g_zero4w[4] = {0.f, 0.f, 0.f
 // four (row >> 2) & 3 classes is: the 16-lane groups of ds_read_b128 hold one row of each class per row & 3)
 __device__ __forceinline__ int wswz(int row) { return swz(row); }
 
+// packed pair arithmetic for the input transform of wino2 (exact: a - b, a * b + c)
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2w pk_subw(f32x2w a, f32x2w b) {
+    f32x2w d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2w pk_fmaw(f32x2w a, f32x2w b, f32x2w c) {
+    f32x2w d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x4 sub4w(f32x4 a, f32x4 b) {
+    const f32x2w lo = pk_subw(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2w hi = pk_subw(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
 // 8 KB linear copy global -> LDS by this wave: 8 LDS-DMA instructions of 1 KB (lane l moves bytes [16 l, 16 l + 16) of a
 // piece).  One asm block: the base pointer reaches its SGPR pair once; the instruction's immediate offset advances the
 // global AND the LDS address alike (LDS address = M0 + offset + 16 lane), so m0 is written once per 4 KB (the immediate
@@ -666,14 +684,16 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     // (VALU instructions are the scarce resource here -- beside fp32 MFMAs each costs ~16-20 cycles of matrix-pipe time
     //  (ablation) -- so the wave-uniform sign of the column combination is a multiplier of an exact fma, not a
     //  select between a sum and a difference: 12 instructions per thread and stage)
+    // (packed arithmetic: v_pk_add_f32 with negated second operand for the differences -- the compiler emits four v_sub_f32 for
+    //  an f32x4 subtraction -- and v_pk_fma_f32 for the signed sum: 6 instead of 12 VALU instructions per thread and stage)
     const float psgn = pnu == 1 ? 1.f : -1.f;
+    const f32x2w psgn2 = {psgn, psgn};
     auto produce_store = [&](float* vb, int xi, const f32x4 (&d)[4]) __attribute__((always_inline)) {
-        const f32x4 ta = xi == 1 ? d[0] + d[1] : d[0] - d[1];      // (B^T d) at column ca
-        const f32x4 tb = xi == 1 ? d[2] + d[3] : d[2] - d[3];      //          at column cb
-        f32x4 v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(tb[k], psgn, ta[k]);
-        *reinterpret_cast<f32x4*>(vb + vst) = v;
+        const f32x4 ta = xi == 1 ? d[0] + d[1] : sub4w(d[0], d[1]);      // (B^T d) at column ca
+        const f32x4 tb = xi == 1 ? d[2] + d[3] : sub4w(d[2], d[3]);      //          at column cb
+        const f32x2w lo = pk_fmaw(__builtin_shufflevector(tb, tb, 0, 1), psgn2, __builtin_shufflevector(ta, ta, 0, 1));
+        const f32x2w hi = pk_fmaw(__builtin_shufflevector(tb, tb, 2, 3), psgn2, __builtin_shufflevector(ta, ta, 2, 3));
+        *reinterpret_cast<f32x4*>(vb + vst) = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
     };
 
     // One stage = 32 MFMAs, split in two halves AROUND the barrier that publishes the next stage (conv.hip's pattern): the
