@@ -776,22 +776,19 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         pin_acc();
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
+            if (!(BMC_WINO_ABL & 128)) {
+                // Y = A^T M A on whole accumulator quads (the four output channels of a lane at once): packed adds
+                f32x4 ta[4], y[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (BMC_WINO_ABL & 128) break;
-                float y[4];
+                for (int nu = 0; nu < 4; ++nu) ta[nu] = (acc[nu][tb] + acc[4 + nu][tb]) + acc[8 + nu][tb];
+                y[0] = (ta[0] + ta[1]) + ta[2];
+                y[1] = sub4w(sub4w(ta[1], ta[2]), ta[3]);
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    float ta[4];
+                for (int nu = 0; nu < 4; ++nu) ta[nu] = sub4w(sub4w(acc[4 + nu][tb], acc[8 + nu][tb]), acc[12 + nu][tb]);
+                y[2] = (ta[0] + ta[1]) + ta[2];
+                y[3] = sub4w(sub4w(ta[1], ta[2]), ta[3]);
 #pragma unroll
-                    for (int nu = 0; nu < 4; ++nu)
-                        ta[nu] = h2 == 0 ? (acc[nu][tb][r] + acc[4 + nu][tb][r]) + acc[8 + nu][tb][r]
-                                         : (acc[4 + nu][tb][r] - acc[8 + nu][tb][r]) - acc[12 + nu][tb][r];
-                    y[2 * h2] = (ta[0] + ta[1]) + ta[2];
-                    y[2 * h2 + 1] = (ta[1] - ta[2]) - ta[3];
-                }
-#pragma unroll
-                for (int p = 0; p < 4; ++p) acc[p][tb][r] = y[p];
+                for (int p = 0; p < 4; ++p) acc[p][tb] = y[p];
             }
             pin_acc();
         }
