@@ -99,3 +99,44 @@ def raw_events_to_channels_batch(xs_i16, ys_i16, ps_f64, offsets, flips=None, se
     """GPU sequence encoder on raw HDF5 columns (int16 x/y, float64 p) with the flip augmentation folded in:
     replaces get_events -> augment_event -> event_formatting -> events_to_channels of the CPU workers."""
     return ops.encode_raw_events(xs_i16, ys_i16, ps_f64, offsets, flips, int(sensor_size[0]), int(sensor_size[1]))
+
+
+def events_to_image_torch(xs, ys, ps, device=None, sensor_size=(180, 240), clip_out_of_range=True, interpolation=None, padding=True):
+    """events_to_image_torch of the reference (dataloader/encodings.py:16-73) on the GPU: same signature, same side effects
+    (out-of-range events are reset in place to (0, 0) with weight 0), same summation order as its CPU index_put_ -> bit-identical.
+    xs / ys / ps: contiguous float32 CUDA tensors (sub-pixel positions for interpolation='bilinear')."""
+    import ctypes as C
+    from . import lib, ops
+    if interpolation not in (None, "bilinear"):
+        raise ValueError("interpolation must be None or 'bilinear'")
+    for t in (xs, ys, ps):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("bmc_hip.encodings.events_to_image_torch needs contiguous float32 CUDA tensors (the reference's long-"
+                               "coordinate variant: convert with .float())")
+    H, W = sensor_size
+    bil = interpolation == "bilinear"
+    shape = (H + 1, W + 1) if (bil and padding) else (H, W)
+    n = xs.numel()
+    out = torch.empty(shape, device=xs.device, dtype=torch.float32)
+    ws = torch.empty(lib._ev_torch_ws(n, H, W), device=xs.device, dtype=torch.int32)
+    lib.call(lib._ev_img_torch, "bmc_events_to_image_torch", xs.data_ptr(), ys.data_ptr(), ps.data_ptr(), n, H, W,
+             1 if clip_out_of_range else 0, 1 if bil else 0, 1 if padding else 0, out.data_ptr(), ws.data_ptr(), ops._stream())
+    return out
+
+
+def events_to_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240), temporal_bilinear=True):
+    """events_to_voxel_torch of the reference (dataloader/encodings.py:100-148), temporal_bilinear=True, on the GPU: [B, H, W];
+    zeros for <= 3 events or all-zero timestamps; xs / ys are reset in place where out of range, as the reference does."""
+    from . import lib, ops
+    if not temporal_bilinear:
+        raise NotImplementedError("bmc_hip.encodings.events_to_voxel_torch: only temporal_bilinear=True is implemented")
+    for t in (xs, ys, ts, ps):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("bmc_hip.encodings.events_to_voxel_torch needs contiguous float32 CUDA tensors")
+    H, W = sensor_size
+    n = xs.numel()
+    out = torch.empty((B, H, W), device=xs.device, dtype=torch.float32)
+    ws = torch.empty(lib._ev_torch_ws(n, H, W), device=xs.device, dtype=torch.int32)
+    lib.call(lib._ev_vox_torch, "bmc_events_to_voxel_torch", xs.data_ptr(), ys.data_ptr(), ts.data_ptr(), ps.data_ptr(), n, B, H, W,
+             out.data_ptr(), ws.data_ptr(), ops._stream())
+    return out

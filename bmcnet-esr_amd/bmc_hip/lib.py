@@ -79,6 +79,9 @@ _enc_raw = _sig("bmc_encode_raw_events", [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p
 _events_ws = _sig("bmc_events_binned_ws_bytes", [_ll, _i, _i, _i], C.c_longlong)
 _events_binned = _sig("bmc_events_to_channels_binned", [_p, _p, _p, _p, _ll, _i, _i, _i, _p, _i, _p, _ll, _p])
 _enc_raw_binned = _sig("bmc_encode_raw_events_binned", [_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p, _p, _ll, _p])
+_ev_torch_ws = _sig("bmc_events_torch_ws_ints", [_ll, _i, _i], C.c_longlong)
+_ev_img_torch = _sig("bmc_events_to_image_torch", [_p, _p, _p, _ll, _i, _i, _i, _i, _i, _p, _p, _p])
+_ev_vox_torch = _sig("bmc_events_to_voxel_torch", [_p, _p, _p, _p, _ll, _i, _i, _i, _p, _p, _p])
 _pack_w = _sig("bmc_pack_weight", [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p])
 _pack_wt = _sig("bmc_pack_weight_t", [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p])
 _pack_wino = _sig("bmc_pack_weight_wino", [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p])
@@ -117,7 +120,8 @@ EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_event
            "bmc_head_mse_fwd", "bmc_head_mse_bwd", "bmc_events_to_stack_polarity", "bmc_events_to_mask",
            "bmc_pgemm_reduce_weight_groups", "bmc_events_binned_ws_bytes", "bmc_events_to_channels_binned",
            "bmc_encode_raw_events_binned", "bmc_pack_weight_wino", "bmc_wgrad_wino_nsplit", "bmc_wgrad_wino",
-           "bmc_wgrad_wino_reduce"]
+           "bmc_wgrad_wino_reduce", "bmc_events_torch_ws_ints", "bmc_events_to_image_torch",
+           "bmc_events_to_voxel_torch"]
 
 
 def check(rc, what):

@@ -613,3 +613,198 @@ extern "C" int bmc_events_to_mask(float* xs, float* ys, float* ps, long long n, 
     BMC_CHECK_LAUNCH("bmc_events_to_mask");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The torch-tensor encodings of the reference (dataloader/encodings.py:16-73 events_to_image_torch with bilinear
+// interpolation, :100-148 events_to_voxel_torch).  Nothing in the reference calls them; they complete the encodings row.
+// Arbitrary float weights -> the summation order is part of the result, and it is the order of the reference's CPU
+// index_put_(accumulate=True): one pass per bilinear corner ((0,0), (0,1), (1,0), (1,1)), the events in order within a
+// pass.  Same ordered machinery as the voxel grid above: events are binned by their CELL (floor pixel) with integer
+// atomics, every cell's segment is put in event order, and every OUTPUT pixel then gathers -- pass by pass -- from the up
+// to four cells that reach it.  Deterministic, bit-identical to the single-threaded reference; float arithmetic is written
+// with explicit round-to-nearest intrinsics in the reference's operation order (no fused multiply-add).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void one_frame_offsets_kernel(long long* off, long long n) { off[0] = 0; off[1] = n; }
+
+// events_to_image_torch :33-38 (reset out-of-range events; MUTATES xs, ys, ps) and :48-64: cell of every event.
+// mode bit 0: bilinear, bit 1: padding, bit 2: clip_out_of_range.  cell[e] = iy * iw + ix; wts[e] = ps * mask (bilinear).
+__global__ void img_cells_kernel(float* __restrict__ xs, float* __restrict__ ys, float* __restrict__ ps, long long n, int H, int W,
+                                 int ih, int iw, int mode, int* __restrict__ cell, int* __restrict__ cnt,
+                                 unsigned char* __restrict__ bad_out, int mutate_ps, const int* __restrict__ live) {
+#pragma clang fp contract(off)
+    const bool mutate = live == nullptr || *live != 0;      // (events_to_voxel_torch returns before touching anything when ts is all zero)
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        float x = xs[e], y = ys[e];
+        const bool bad = (x >= (float)W) | (x < 0.f) | (y >= (float)H) | (y < 0.f);
+        if (bad) {
+            x = 0.f; y = 0.f;
+            if (mutate) {
+                xs[e] = 0.f; ys[e] = 0.f;
+                if (mutate_ps) ps[e] = 0.f;
+            }
+        }
+        if (bad_out) bad_out[e] = bad ? 1 : 0;
+        int ix, iy;
+        if (mode & 1) {
+            float m = 1.f;
+            if (mode & 4) {
+                const float clipx = (float)(iw - 1), clipy = (float)(ih - 1);
+                m = (x >= clipx ? 0.f : 1.f) * (y >= clipy ? 0.f : 1.f);
+            }
+            ix = (int)(floorf(x) * m);
+            iy = (int)(floorf(y) * m);
+        } else {
+            ix = (int)x; iy = (int)y;            // .long(): truncation; coordinates are >= 0 here
+        }
+        const int q = iy * iw + ix;
+        cell[e] = q;
+        atomicAdd(cnt + q, 1);
+    }
+}
+__global__ void cell_fill_kernel(const int* __restrict__ cell, long long n, int* __restrict__ cur, int* __restrict__ idx) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        idx[atomicAdd(cur + cell[e], 1)] = (int)e;
+}
+// every cell's segment into event order (insertion sort: segments are short, the long ones were sorted cooperatively before)
+__global__ void cell_sort_kernel(const int* __restrict__ seg, int ncell, int* __restrict__ idx) {
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ncell; q += gridDim.x * blockDim.x) {
+        const int a = seg[q], b = seg[q + 1];
+        for (int i = a + 1; i < b; ++i) {
+            const int v = idx[i];
+            int j = i - 1;
+            while (j >= a && idx[j] > v) { idx[j + 1] = idx[j]; --j; }
+            idx[j + 1] = v;
+        }
+    }
+}
+__global__ void img_gather_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ ps, int H, int W,
+                                  int ih, int iw, int mode, const int* __restrict__ seg, const int* __restrict__ idx,
+                                  float* __restrict__ out) {
+#pragma clang fp contract(off)      // every product is rounded before it is added, as the reference's tensor expressions are (the
+                                    // *_rn intrinsics are plain operators here: the compiler would fuse w * fx * fy + acc)
+    const int npx = ih * iw;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < npx; o += gridDim.x * blockDim.x) {
+        const int oy = o / iw, ox = o - oy * iw;
+        float acc = 0.f;
+        if (!(mode & 1)) {                       // interpolation=None: img[ys, xs] += ps, events in order
+            for (int i = seg[o]; i < seg[o + 1]; ++i) acc = acc + ps[idx[i]];
+            out[o] = acc;
+            continue;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {            // interpolate_to_image (:6-13): pass c adds corner (c >> 1, c & 1) of every event
+            const int cy = oy - (c >> 1), cx = ox - (c & 1);
+            if (cy < 0 || cx < 0) continue;
+            const int q = cy * iw + cx;
+            for (int i = seg[q]; i < seg[q + 1]; ++i) {
+                const int e = idx[i];
+                const float x = xs[e], y = ys[e];
+                float m = 1.f;
+                if (mode & 4) m = (x >= (float)(iw - 1) ? 0.f : 1.f) * (y >= (float)(ih - 1) ? 0.f : 1.f);
+                const float dx = x - floorf(x), dy = y - floorf(y);
+                const float w = ps[e] * m;
+                const float fx = (c & 1) ? dx : 1.0f - dx, fy = (c >> 1) ? dy : 1.0f - dy;
+                const float t = (w * fx) * fy;                               // weights * (1 - dxs | dxs) * (1 - dys | dys)
+                acc = acc + t;
+            }
+        }
+        out[o] = acc;
+    }
+}
+// events_to_voxel_torch :121-139: flag[0] = any timestamp != 0 (timestamps are >= 0: "ts.sum() == 0" <=> all zero)
+__global__ void any_nonzero_kernel(const float* __restrict__ ts, long long n, int* __restrict__ flag) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        if (ts[e] != 0.f) { *flag = 1; break; }
+}
+__global__ void voxel_torch_gather_kernel(const float* __restrict__ ts, const float* __restrict__ ps, long long n, int bins, int H, int W,
+                                          const int* __restrict__ seg, const int* __restrict__ idx,
+                                          const unsigned char* __restrict__ bad, const int* __restrict__ flag, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int HW = H * W;
+    const float t0 = ts[0];
+    const float dt = (ts[n - 1] - t0) + 1e-6f;
+    const float bm1 = (float)(bins - 1);
+    const bool live = *flag != 0;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < HW; o += gridDim.x * blockDim.x) {
+        for (int bi = 0; bi < bins; ++bi) {
+            float acc = 0.f;
+            if (live)
+                for (int i = seg[o]; i < seg[o + 1]; ++i) {
+                    const int e = idx[i];
+                    const float tn = ((ts[e] - t0) / dt) * bm1;
+                    float wgt = ps[e] * fmaxf(0.f, 1.0f - fabsf(tn - (float)bi));
+                    if (bad[e] && bi == 0) wgt = 0.f;        // the first bin's call zeroes the weights of out-of-range events (:38)
+                    acc = acc + wgt;
+                }
+            out[(long long)bi * HW + o] = acc;
+        }
+    }
+}
+
+int ordered_cells(float* xs, float* ys, float* ps, long long n, int H, int W, int ih, int iw, int mode, int* ws, unsigned char* bad,
+                  int mutate_ps, const int* live, hipStream_t st, int** seg_out, int** idx_out) {
+    const int ncell = ih * iw;
+    // ws: seg[ncell + 1] | cur[ncell + 1] | idx[n] | cell[n] | offsets (2 x int64, 8-byte aligned)
+    int* const seg = ws;
+    int* const cur = ws + (ncell + 1);
+    int* const idx = ws + 2 * (ncell + 1);
+    int* const cell = idx + n;
+    long long* const off = reinterpret_cast<long long*>(ws + ((2ll * (ncell + 1) + 2 * n + 1) / 2) * 2);
+    hipError_t e = hipMemsetAsync(seg, 0, (size_t)(ncell + 1) * sizeof(int), st);
+    if (e != hipSuccess) { bmc_set_error("events_to_image_torch: memset failed: %s", hipGetErrorString(e)); return -2; }
+    hipLaunchKernelGGL(one_frame_offsets_kernel, dim3(1), dim3(1), 0, st, off, n);
+    hipLaunchKernelGGL(img_cells_kernel, dim3(256), dim3(256), 0, st, xs, ys, ps, n, H, W, ih, iw, mode, cell, seg, bad, mutate_ps, live);
+    hipLaunchKernelGGL(voxel_scan_kernel, dim3(1), dim3(1024), 0, st, seg, cur, ncell);
+    hipLaunchKernelGGL(cell_fill_kernel, dim3(256), dim3(256), 0, st, cell, n, cur, idx);
+    hipLaunchKernelGGL(voxel_sort_long_kernel, dim3(1), dim3(1024), 0, st, off, ncell, seg, idx);
+    hipLaunchKernelGGL(cell_sort_kernel, dim3((ncell + 255) / 256), dim3(256), 0, st, seg, ncell, idx);
+    *seg_out = seg; *idx_out = idx;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" long long bmc_events_torch_ws_ints(long long n, int H, int W) {
+    return 2ll * ((long long)(H + 1) * (W + 1) + 1) + 2 * n + 8 + (n + 3) / 4 + 4;
+}
+
+extern "C" int bmc_events_to_image_torch(float* xs, float* ys, float* ps, long long n, int H, int W, int clip_out_of_range,
+                                         int bilinear, int padding, float* out, int* ws, bmc_stream_t s) {
+    BMC_CHECK_ARG(H > 0 && W > 0 && out && ws && n >= 0 && n < (1ll << 30), "bmc_events_to_image_torch: bad arguments");
+    BMC_CHECK_ARG(!(bilinear && !padding && !clip_out_of_range), "bmc_events_to_image_torch: bilinear interpolation without padding needs "
+                  "clip_out_of_range (the reference itself indexes out of bounds for an event in the last row / column)");
+    hipStream_t st = (hipStream_t)s;
+    const int ih = (bilinear && padding) ? H + 1 : H, iw = (bilinear && padding) ? W + 1 : W;
+    const int mode = (bilinear ? 1 : 0) | (padding ? 2 : 0) | (clip_out_of_range ? 4 : 0);
+    int *seg, *idx;
+    if (ordered_cells(xs, ys, ps, n, H, W, ih, iw, mode, ws, nullptr, 1, nullptr, st, &seg, &idx)) return -2;
+    hipLaunchKernelGGL(img_gather_kernel, dim3((ih * iw + 255) / 256), dim3(256), 0, st, xs, ys, ps, H, W, ih, iw, mode, seg, idx, out);
+    BMC_CHECK_LAUNCH("bmc_events_to_image_torch");
+    return 0;
+}
+
+extern "C" int bmc_events_to_voxel_torch(float* xs, float* ys, const float* ts, const float* ps, long long n, int bins, int H, int W,
+                                         float* out, int* ws, bmc_stream_t s) {
+    BMC_CHECK_ARG(bins >= 1 && H > 0 && W > 0 && out && ws && n >= 0 && n < (1ll << 30), "bmc_events_to_voxel_torch: bad arguments");
+    hipStream_t st = (hipStream_t)s;
+    if (n <= 3) {                                    // :121-122
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)bins * H * W * sizeof(float), st);
+        if (e != hipSuccess) { bmc_set_error("bmc_events_to_voxel_torch: memset failed: %s", hipGetErrorString(e)); return -2; }
+        return 0;
+    }
+    const long long base = 2ll * ((long long)H * W + 1) + 2 * n + 8;
+    unsigned char* const bad = reinterpret_cast<unsigned char*>(ws + base);
+    int* const flag = ws + base + (n + 3) / 4;
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
+    if (e != hipSuccess) { bmc_set_error("bmc_events_to_voxel_torch: memset failed: %s", hipGetErrorString(e)); return -2; }
+    hipLaunchKernelGGL(any_nonzero_kernel, dim3(64), dim3(256), 0, st, ts, n, flag);
+    int *seg, *idx;
+    // (coordinates are reset in place by the first bin's events_to_image_torch call; its weights are a temporary: ps stays)
+    if (ordered_cells(xs, ys, const_cast<float*>(ps), n, H, W, H, W, 0, ws, bad, 0, flag, st, &seg, &idx)) return -2;
+    hipLaunchKernelGGL(voxel_torch_gather_kernel, dim3((H * W + 255) / 256), dim3(256), 0, st, ts, ps, n, bins, H, W, seg, idx, bad, flag,
+                       out);
+    BMC_CHECK_LAUNCH("bmc_events_to_voxel_torch");
+    return 0;
+}

@@ -73,6 +73,21 @@ int bmc_encode_raw_events_binned(const short* xs, const short* ys, const double*
                                  const unsigned char* flips, long long nevents, int nframes, int H, int W, float* out,
                                  void* ws, long long ws_bytes, bmc_stream_t s);
 
+/* The torch-tensor encodings of the reference (no caller in the reference; they complete the encodings row):
+ * events_to_image_torch (dataloader/encodings.py:16-73) on one event list -> out [H][W], or [H+1][W+1] for bilinear
+ * interpolation with padding.  bilinear != 0: interpolate_to_image (:6-13), sub-pixel positions spread over the four
+ * neighbours; bilinear == 0: img[ys.long(), xs.long()] += ps.  Out-of-range events are reset IN PLACE to (0, 0) with weight 0
+ * (:33-38) -- xs, ys, ps are mutated like the reference's tensors.  The sums are taken in the order of the reference's CPU
+ * index_put_(accumulate=True) (one pass per corner, events in order): deterministic and bit-identical to it.
+ * ws: bmc_events_torch_ws_ints(n, H, W) ints.  bilinear without padding requires clip_out_of_range.
+ * events_to_voxel_torch (:100-148), temporal_bilinear=True: out [bins][H][W]; ts sorted ascending and >= 0; zeros for
+ * n <= 3 or all-zero timestamps (:121-122); xs, ys are reset in place by the first bin's call (ps is not touched). */
+long long bmc_events_torch_ws_ints(long long n, int H, int W);
+int bmc_events_to_image_torch(float* xs, float* ys, float* ps, long long n, int H, int W, int clip_out_of_range, int bilinear,
+                              int padding, float* out, int* ws, bmc_stream_t s);
+int bmc_events_to_voxel_torch(float* xs, float* ys, const float* ts, const float* ps, long long n, int bins, int H, int W,
+                              float* out, int* ws, bmc_stream_t s);
+
 /* events_to_voxel(): temporal-bilinear voxel grid [nframes][bins][H][W] (dataloader/encodings.py:272-287; ts already
  * normalised to [0,1] by event_formatting).  Same coordinate conventions and first-call side effect as above.  The
  * weights are arbitrary floats, so the order of summation is part of the result: a pixel's events are added in EVENT

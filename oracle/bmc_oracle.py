@@ -199,6 +199,61 @@ def events_to_mask_np(xs, ys, ps, sensor_size=(180, 240)):
     return mask, xs, ys, ps
 
 
+def events_to_image_torch_np(xs, ys, ps, sensor_size=(180, 240), clip_out_of_range=True, interpolation=None, padding=True):
+    """numpy restatement of events_to_image_torch (dataloader/encodings.py:16-73) with its CPU semantics: float32 arithmetic in
+    the reference's operation order, index_put_(accumulate=True) = one pass per corner, events in order within a pass.
+    MUTATES xs, ys, ps like the reference (:33-38: out-of-range events are reset to (0, 0) with weight 0).
+    xs / ys: float32 (sub-pixel positions) -- or integer arrays for the interpolation=None branch."""
+    H, W = sensor_size
+    bad = (xs >= W) | (xs < 0) | (ys >= H) | (ys < 0)                       # :33-35
+    xs[bad] = 0; ys[bad] = 0; ps[bad] = 0                                    # :36-38
+    bil = interpolation == "bilinear"
+    ih, iw = (H + 1, W + 1) if (bil and padding) else (H, W)                 # :42-45
+    mask = np.ones(xs.shape, np.float32)
+    if clip_out_of_range:                                                    # :48-53
+        clipx = iw if (interpolation is None and padding is False) else iw - 1
+        clipy = ih if (interpolation is None and padding is False) else ih - 1
+        mask = np.where(xs >= clipx, np.float32(0), np.float32(1)) * np.where(ys >= clipy, np.float32(0), np.float32(1))
+    img = np.zeros((ih, iw), np.float32)
+    if bil and not np.issubdtype(xs.dtype, np.integer):                      # :56-64
+        xf, yf = xs.astype(np.float32), ys.astype(np.float32)
+        pxs, pys = np.floor(xf), np.floor(yf)
+        dxs, dys = (xf - pxs).astype(np.float32), (yf - pys).astype(np.float32)
+        ix, iy = (pxs * mask).astype(np.int64), (pys * mask).astype(np.int64)
+        w = (ps.reshape(-1).astype(np.float32) * mask).astype(np.float32)
+        one = np.float32(1.0)
+        # interpolate_to_image (:6-13): four index_put_ passes, each adding the events in order
+        for (oy, ox, wt) in ((0, 0, w * (one - dxs) * (one - dys)), (0, 1, w * dxs * (one - dys)),
+                             (1, 0, w * (one - dxs) * dys), (1, 1, w * dxs * dys)):
+            wt = wt.astype(np.float32)
+            for k in range(len(wt)):
+                img[iy[k] + oy, ix[k] + ox] += wt[k]
+    else:                                                                    # :65-70
+        ix, iy = xs.astype(np.int64), ys.astype(np.int64)
+        pw = ps.astype(np.float32)
+        for k in range(len(pw)):
+            img[iy[k], ix[k]] += pw[k]
+    return img
+
+
+def events_to_voxel_torch_np(xs, ys, ts, ps, B, sensor_size=(180, 240)):
+    """numpy restatement of events_to_voxel_torch (dataloader/encodings.py:100-148), temporal_bilinear=True branch, float32:
+    bin b = events_to_image_torch(xs, ys, ps * max(0, 1 - |t_norm - b|), clip_out_of_range=False), t_norm =
+    (ts - ts[0]) / (ts[-1] - ts[0] + 1e-6) * (B - 1); all-zero timestamps or <= 3 events give zeros (:121-122).  MUTATES xs, ys
+    (the first bin's call resets out-of-range coordinates, :36-37)."""
+    H, W = sensor_size
+    if float(ts.sum()) == 0 or len(ts) <= 3:
+        return np.zeros((B, H, W), np.float32)
+    ts = ts.astype(np.float32)
+    dt = np.float32(ts[-1] - ts[0]) + np.float32(1e-6)
+    t_norm = ((ts - ts[0]) / dt * np.float32(B - 1)).astype(np.float32)
+    out = []
+    for bi in range(B):
+        wts = (ps.astype(np.float32) * np.maximum(np.float32(0), np.float32(1.0) - np.abs(t_norm - np.float32(bi)))).astype(np.float32)
+        out.append(events_to_image_torch_np(xs, ys, wts, sensor_size, clip_out_of_range=False))
+    return np.stack(out)
+
+
 def collate_windows(frames_inp, frames_gt, seqn=2):
     """The batch layout the trainer iterates over -- HDF5DataLoaderSequence.custom_collate + concat_dict
     (dataloader/h5dataloader.py:213-250): per time step the items of the batch are stacked on a new dim 0, then every

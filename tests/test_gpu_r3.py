@@ -759,3 +759,62 @@ def test_split_multi_source_weight_gradient_vs_float64(cins):
     y = ops.conv([View(x) for x in xs], w, b, spec, relu=True)
     y.backward(go)
     assert rel(w.grad, 2 * w64.grad) < 2e-6 and rel(b.grad, 2 * b64.grad) < 2e-6
+
+
+# ------------------------------------------------------------------ torch-tensor encodings (dataloader/encodings.py:16-73, 100-148)
+def test_torch_encodings_match_reference_golden_bit_for_bit():
+    """events_to_image_torch (bilinear with / without padding and clipping, interpolation=None) and events_to_voxel_torch on the
+    GPU against the REFERENCE's outputs on the same events (tests/golden/encodings_torch.npz): images, voxel grids and the
+    in-place resets of the inputs, bit for bit; plus the early-out cases."""
+    dev = _gpu()
+    from bmc_hip import encodings as E
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "encodings_torch.npz"))
+    H, W = 13, 17
+    T = lambda k: torch.tensor(g[k].copy(), device=dev)
+    for pad, clip in ((True, True), (True, False), (False, True)):
+        a, b, c = T("xs"), T("ys"), T("ps")
+        img = E.events_to_image_torch(a, b, c, sensor_size=(H, W), clip_out_of_range=clip, interpolation="bilinear", padding=pad)
+        tag = "img_pad%d_clip%d" % (pad, clip)
+        assert np.array_equal(img.cpu().numpy(), g[tag]), tag
+        for t, k in ((a, "_xs"), (b, "_ys"), (c, "_ps")):
+            assert np.array_equal(t.cpu().numpy(), g[tag + k]), tag + k
+    with pytest.raises(RuntimeError):
+        E.events_to_image_torch(T("xs"), T("ys"), T("ps"), sensor_size=(H, W), clip_out_of_range=False, interpolation="bilinear", padding=False)
+    a, b, c = T("xi"), T("yi"), T("ps")
+    assert np.array_equal(E.events_to_image_torch(a, b, c, sensor_size=(H, W)).cpu().numpy(), g["imgn"])
+    assert np.array_equal(a.cpu().numpy(), g["imgn_xs"]) and np.array_equal(c.cpu().numpy(), g["imgn_ps"])
+    a, b = T("xi"), T("yi")
+    vox = E.events_to_voxel_torch(a, b, T("ts"), T("ps"), 5, sensor_size=(H, W))
+    assert np.array_equal(vox.cpu().numpy(), g["vox"])
+    assert np.array_equal(a.cpu().numpy(), g["vox_xs"]) and np.array_equal(b.cpu().numpy(), g["vox_ys"])
+    a, b = T("xi"), T("yi")
+    z = E.events_to_voxel_torch(a, b, torch.zeros_like(T("ts")), T("ps"), 5, sensor_size=(H, W))
+    assert np.array_equal(z.cpu().numpy(), g["vox_zero_ts"]) and np.array_equal(a.cpu().numpy(), g["xi"])     # untouched inputs
+    z = E.events_to_voxel_torch(T("xi")[:3].clone(), T("yi")[:3].clone(), T("ts")[:3].clone(), T("ps")[:3].clone(), 5, sensor_size=(H, W))
+    assert np.array_equal(z.cpu().numpy(), g["vox_three"])
+
+
+def test_torch_encodings_vs_oracle_at_sensor_size():
+    """The same two encodings at 180x240 with 60 000 events (hot pixels included: one pixel receives 5 000 events) against the numpy
+    restatements of the reference (pinned to its outputs by tests/test_oracle_golden_r2.py): bit-identical, run to run as well."""
+    dev = _gpu()
+    from bmc_hip import encodings as E
+    from oracle import bmc_oracle as O
+    rng = np.random.default_rng(12)
+    H, W, n = 180, 240, 60000
+    xs = (rng.random(n) * (W + 2) - 1).astype(np.float32)
+    ys = (rng.random(n) * (H + 2) - 1).astype(np.float32)
+    xs[:5000] = 100.25; ys[:5000] = 50.75
+    ps = rng.standard_normal(n).astype(np.float32)
+    ref = O.events_to_image_torch_np(xs.copy(), ys.copy(), ps.copy(), (H, W), interpolation="bilinear")
+    outs = []
+    for _ in range(2):
+        a, b, c = (torch.tensor(v.copy(), device=dev) for v in (xs, ys, ps))
+        outs.append(E.events_to_image_torch(a, b, c, sensor_size=(H, W), interpolation="bilinear").cpu().numpy())
+    assert np.array_equal(outs[0], ref) and np.array_equal(outs[0], outs[1])
+    xi, yi = np.floor(xs), np.floor(ys)
+    ts = np.sort(rng.random(n).astype(np.float32) * np.float32(0.03) + np.float32(1.5))
+    refv = O.events_to_voxel_torch_np(xi.copy(), yi.copy(), ts, ps.copy(), 5, (H, W))
+    a, b = torch.tensor(xi.copy(), device=dev), torch.tensor(yi.copy(), device=dev)
+    vox = E.events_to_voxel_torch(a, b, torch.tensor(ts, device=dev), torch.tensor(ps, device=dev), 5, sensor_size=(H, W))
+    assert np.array_equal(vox.cpu().numpy(), refv)

@@ -163,3 +163,29 @@ def test_inference_loop_seqn3_golden():
         assert float((pred - ref).norm() / ref.norm()) < 2e-6
         assert abs(float(esr) - float(z["esr_mse%d" % i])) < 2e-6 * float(z["esr_mse%d" % i])
         assert abs(float(base) - float(z["bicubic_mse%d" % i])) < 2e-6 * float(z["bicubic_mse%d" % i])
+
+
+def test_torch_encodings_oracle_matches_reference_golden():
+    """events_to_image_torch (bilinear, padding / clipping variants, and interpolation=None) and events_to_voxel_torch of the
+    reference (dataloader/encodings.py:16-73, 100-148; golden from tests/golden/make_golden_r3b.py): the numpy restatements
+    reproduce the images, the voxel grids AND the mutated inputs bit for bit."""
+    import numpy as np
+    from oracle import bmc_oracle as O
+    g = np.load(os.path.join(GOLDEN, "encodings_torch.npz"))
+    H, W = 13, 17
+    for pad, clip in ((True, True), (True, False), (False, True)):
+        a, b, c = g["xs"].copy(), g["ys"].copy(), g["ps"].copy()
+        img = O.events_to_image_torch_np(a, b, c, (H, W), clip_out_of_range=clip, interpolation="bilinear", padding=pad)
+        tag = "img_pad%d_clip%d" % (pad, clip)
+        assert np.array_equal(img, g[tag]), tag
+        assert np.array_equal(a, g[tag + "_xs"]) and np.array_equal(b, g[tag + "_ys"]) and np.array_equal(c, g[tag + "_ps"])
+    a, b, c = g["xi"].copy(), g["yi"].copy(), g["ps"].copy()
+    assert np.array_equal(O.events_to_image_torch_np(a, b, c, (H, W)), g["imgn"])
+    assert np.array_equal(a, g["imgn_xs"]) and np.array_equal(b, g["imgn_ys"]) and np.array_equal(c, g["imgn_ps"])
+    a, b = g["xi"].copy(), g["yi"].copy()
+    assert np.array_equal(O.events_to_voxel_torch_np(a, b, g["ts"], g["ps"].copy(), 5, (H, W)), g["vox"])
+    assert np.array_equal(a, g["vox_xs"]) and np.array_equal(b, g["vox_ys"])
+    assert np.array_equal(O.events_to_voxel_torch_np(g["xi"].copy(), g["yi"].copy(), np.zeros_like(g["ts"]), g["ps"].copy(), 5, (H, W)),
+                          g["vox_zero_ts"])
+    assert np.array_equal(O.events_to_voxel_torch_np(g["xi"][:3].copy(), g["yi"][:3].copy(), g["ts"][:3], g["ps"][:3].copy(), 5, (H, W)),
+                          g["vox_three"])
