@@ -529,7 +529,8 @@ extern "C" int bmc_conv(const bmc_conv_args_t* h, bmc_stream_t stream) {
     }
     if (h->math != BMC_MATH_FP32)
         return bmc_conv_bf_launch(k, h->taps, BN, THv, h->math == BMC_MATH_BF16 ? 1 : 3, cus, (hipStream_t)stream);
-    if (h->taps == 1 && !getenv("BMC_NO_CONV1") && bmc_conv1_launch(k, cus, (hipStream_t)stream)) {
+    static const bool no_conv1 = getenv("BMC_NO_CONV1") != nullptr;      // (A/B runs; read once, not per launch)
+    if (h->taps == 1 && !no_conv1 && bmc_conv1_launch(k, cus, (hipStream_t)stream)) {
         BMC_CHECK_LAUNCH("bmc_conv (conv1)");
         return 0;
     }
