@@ -127,7 +127,7 @@ def _conv(srcs, w4, spec, owner, bias, out, B, relu=False, residual=None, mask=N
     """Forward-style launch: out[out_b0 : out_b0+B] = epi(conv(cat(srcs)) + bias)."""
     G, Cout, Cin, taps = w4.shape
     _, H, W, Co = out.shape
-    wn = ops.wino_ok(B, H, W, Cout, taps)
+    wn = ops.wino_ok(B, H, W, Cout, taps, fwd=not accumulate and mask is None)
     wp = _packed_weight(w4, spec, owner, wino=wn)
     conv_raw(srcs, wp, spec.kpad * taps * coutpad(Cout), bias, Cout if bias is not None else 0,
              out.data_ptr() + 4 * out_b0 * H * W * Co, H * W * Co, Co, B, H, W, Cout, taps, relu=relu, residual=residual,

@@ -260,13 +260,44 @@ WINO = os.environ.get("BMC_WINO", "1") != "0"
 WINO_MIN_TILES = int(os.environ.get("BMC_WINO_MIN_TILES", 200))   # >= ~1 tile per CU on most of the chip (31x56 at 4B: 256 tiles, +3.5 %)
 
 
-def wino_ok(B, H, W, Cout, taps):
-    """Does a launch of this geometry take the Winograd kernel?  (Decided ONCE per launch by the caller and handed to the
-    weight pack and to conv_raw alike: the two packed layouts are not interchangeable.)"""
-    if not WINO or MATH != 0 or taps != 9:
+# Round 4: F(4x4, 3x3) (csrc/wino4.hip: 36 instead of 144 multiplies per 4x4 output tile and channel pair -- 1.78x fewer than
+# F(2x2) -- fp32 throughout) for every launch that fills the chip with its 16-tile workgroups.  BMC_WINO4=0 keeps F(2x2).
+WINO4 = os.environ.get("BMC_WINO4", "1") != "0"
+WINO4_MIN_TILES = int(os.environ.get("BMC_WINO4_MIN_TILES", 300))    # workgroup tiles (16 tiles of 4x4 pixels x 128 channels)
+
+# Exact zeros.  With zero biases and a zero recurrent state (window 0 at initialisation) the reference's direct convolution
+# gives EXACTLY 0 wherever a pixel's receptive field holds no event, and relu'(0) = 0 gates the gradient there.  F(2x2)
+# preserves that (every output of its minimal algorithm is a combination of products of ITS OWN 3x3 field only); F(4x4) computes
+# such a pixel from a 6x6 patch through rounded transformed weights: +-1e-8 instead of 0, a coin flip of the ReLU mask that the
+# bias gradients of the first layers see (tools/wino_numerics.py, profiles/r04_wino_numerics.txt: conv_fps.bias 1.8e-1 off).
+# The model marks the FORWARD launches whose input can hold whole empty receptive fields -- the input-fusion convolutions on
+# the raw event counts and the residual blocks in front of the first BIE -- with this context; they keep F(2x2).
+_EXACT_ZERO = [0]
+
+
+class exact_zero_inputs:
+    def __enter__(self):
+        _EXACT_ZERO[0] += 1
+
+    def __exit__(self, *exc):
+        _EXACT_ZERO[0] -= 1
         return False
+
+
+def wino_ok(B, H, W, Cout, taps, fwd=False):
+    """Which kernel takes a launch of this geometry?  0: the direct kernel, 2: Winograd F(2x2, 3x3), 4: F(4x4, 3x3).
+    (Decided ONCE per launch by the caller and handed to the weight pack and to conv_raw alike: the packed layouts are not
+    interchangeable.)  fwd: a forward launch (subject to exact_zero_inputs)."""
+    if not WINO or MATH != 0 or taps != 9:
+        return 0
     cp = coutpad(Cout)
-    return cp % 128 == 0 and B * ((H + 7) // 8) * ((W + 15) // 16) * (cp // 128) >= WINO_MIN_TILES
+    if cp % 128 or B * ((H + 7) // 8) * ((W + 15) // 16) * (cp // 128) < WINO_MIN_TILES:
+        return 0
+    if WINO4 and not (fwd and _EXACT_ZERO[0]) and W >= 17 and H * W * 4 * 512 < 2 ** 31:
+        n4 = B * ((((H + 3) // 4) * ((W + 3) // 4) + 15) // 16) * (cp // 128)
+        if n4 >= WINO4_MIN_TILES:
+            return 4
+    return 2
 
 
 PAIR_SMALL = os.environ.get("BMC_PAIR_SMALL", "1") != "0"
@@ -287,14 +318,16 @@ def _packed_weight(w4: torch.Tensor, spec: ConvSpec, owner, wino=False):
     owner: the parameter tensor w4 was derived from (cache key), or None for no caching."""
     G, Cout, Cin, taps = w4.shape
     if wino:
-        hit = _cache_get(spec, ("fw",), owner)
+        npos = 36 if wino == 4 else 16
+        hit = _cache_get(spec, ("fw", npos), owner)
         if hit is not None:
             return hit
         cp = coutpad(Cout)
-        out = torch.empty(G * spec.kpad * 16 * cp, device=w4.device, dtype=torch.float32)
-        lib.call(lib._pack_wino, "bmc_pack_weight_wino", w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin,
+        out = torch.empty(G * spec.kpad * npos * cp, device=w4.device, dtype=torch.float32)
+        fn, nm = (lib._pack_wino4, "bmc_pack_weight_wino4") if wino == 4 else (lib._pack_wino, "bmc_pack_weight_wino")
+        lib.call(fn, nm, w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin,
                  spec.kpad, cp, 0, 0, 0, out.data_ptr(), _stream())
-        _cache_put(spec, ("fw",), owner, out)
+        _cache_put(spec, ("fw", npos), owner, out)
         return out
     hit = _cache_get(spec, ("f", MATH), owner)
     if hit is not None:
@@ -316,13 +349,15 @@ def _packed_weight_t(w4: torch.Tensor, spec: ConvSpec, src_index: int, owner, wi
     nkpad = coutpad(nk)
     c16 = round_up(Cout, CK)
     if wino:
-        hit = _cache_get(spec, ("tw", src_index), owner)
+        npos = 36 if wino == 4 else 16
+        hit = _cache_get(spec, ("tw", src_index, npos), owner)
         if hit is not None:
             return hit
-        out = torch.empty(G * c16 * 16 * nkpad, device=w4.device, dtype=torch.float32)
-        lib.call(lib._pack_wino, "bmc_pack_weight_wino", w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin,
+        out = torch.empty(G * c16 * npos * nkpad, device=w4.device, dtype=torch.float32)
+        fn, nm = (lib._pack_wino4, "bmc_pack_weight_wino4") if wino == 4 else (lib._pack_wino, "bmc_pack_weight_wino")
+        lib.call(fn, nm, w4.data_ptr(), spec.kmap(w4.device).data_ptr(), G, Cout, Cin,
                  c16, nkpad, 1, k0, nk, out.data_ptr(), _stream())
-        _cache_put(spec, ("tw", src_index), owner, out)
+        _cache_put(spec, ("tw", src_index, npos), owner, out)
         return out
     hit = _cache_get(spec, ("t", src_index, MATH), owner)
     if hit is not None:
@@ -343,8 +378,9 @@ def _packed_weight_t(w4: torch.Tensor, spec: ConvSpec, src_index: int, owner, wi
 def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stride, out_ptr, out_batch_stride,
              out_pix_stride, B, H, W, Cout, taps, relu=False, residual: Optional[lib.Src] = None, bpg=None,
              accumulate=False, flops=0.0, mask: Optional[lib.Src] = None, wino=False):
-    """wino: wpacked is the Winograd pack (the caller decided with wino_ok() and packed accordingly); w_group_stride is
-    still given for the direct layout ([K/16][9 taps][Coutpad][16]) and converted here (16 positions instead of 9 taps)."""
+    """wino (0 / 2 / 4): wpacked is the Winograd pack of F(2x2) / F(4x4) (the caller decided with wino_ok() and packed
+    accordingly); w_group_stride is still given for the direct layout ([K/16][9 taps][Coutpad][16]) and converted here (16 /
+    36 positions instead of 9 taps)."""
     a = lib.ConvArgs()
     a.nsrc = len(srcs)
     for i, s in enumerate(srcs):
@@ -355,8 +391,8 @@ def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stri
     a.math = MATH
     if wino:
         assert MATH == 0 and taps == 9
-        a.w_group_stride = w_group_stride // 9 * 16
-        a.math = 4          # BMC_MATH_FP32_WINO
+        a.w_group_stride = w_group_stride // 9 * (36 if wino == 4 else 16)
+        a.math = 5 if wino == 4 else 4          # BMC_MATH_FP32_WINO4 / BMC_MATH_FP32_WINO
     a.bias_group_stride = bias_group_stride
     a.batch_per_group = bpg if bpg else B
     a.out = out_ptr
@@ -371,7 +407,8 @@ def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stri
     a.accumulate = int(accumulate)
     e0 = _prof_begin()
     lib.call(lib._conv, "bmc_conv", C.byref(a), _stream())
-    _prof_end(e0, "wino_conv<9,128>" if wino else "conv_kernel<%d,%d>" % (taps, 32 if a.Coutpad == 32 else 128), flops)
+    _prof_end(e0, ("wino4_conv<9,128>" if wino == 4 else "wino_conv<9,128>") if wino else
+              "conv_kernel<%d,%d>" % (taps, 32 if a.Coutpad == 32 else 128), flops)
     if PROFILE is not None and e0 is not None:
         PROFILE_WINO[0 if wino else 1] += 1
 
@@ -769,7 +806,7 @@ class ConvFn(torch.autograd.Function):
         w4 = weight.detach().reshape(G, -1, meta.spec.cin, taps)
         Cout = w4.shape[1]
         ck = weight if meta.cache else None
-        wn = wino_ok(B, H, W, Cout, taps)
+        wn = wino_ok(B, H, W, Cout, taps, fwd=True)
         wp = _packed_weight(w4.contiguous(), meta.spec, ck, wino=wn)
         if meta.out is not None:       # write into a batch range of a preallocated buffer (see OutSlot)
             out = meta.out.t[meta.out.b0:meta.out.b0 + B]
@@ -1064,7 +1101,7 @@ class ResBlockFn(torch.autograd.Function):
         taps = w1.shape[-1] * w1.shape[-2]
         cp = coutpad(Cn)
         xs = _src(x.detach(), 0, Cn, 0, None, 0, B)
-        wn = wino_ok(B, H, W, Cn, taps)
+        wn = wino_ok(B, H, W, Cn, taps, fwd=True)
         wp1 = _packed_weight(w1.detach().reshape(1, Cn, Cn, taps), spec, w1, wino=wn)
         wp2 = _packed_weight(w2.detach().reshape(1, Cn, Cn, taps), spec, w2, wino=wn)
         fl = 2.0 * B * H * W * Cn * taps * Cn

@@ -518,13 +518,21 @@ extern "C" int bmc_conv(const bmc_conv_args_t* h, bmc_stream_t stream) {
     const long long ntiles = count(THv, BN);
     BMC_CHECK_ARG(ntiles < (1ll << 31), "bmc_conv: too many tiles");
     k.ntiles = (int)ntiles;
-    BMC_CHECK_ARG(h->math == BMC_MATH_FP32 || h->math == BMC_MATH_BF16 || h->math == BMC_MATH_BF16X6 || h->math == BMC_MATH_FP32_WINO,
+    BMC_CHECK_ARG(h->math == BMC_MATH_FP32 || h->math == BMC_MATH_BF16 || h->math == BMC_MATH_BF16X6 || h->math == BMC_MATH_FP32_WINO ||
+                      h->math == BMC_MATH_FP32_WINO4,
                   "bmc_conv: unknown math mode %d", h->math);
     if (h->math == BMC_MATH_FP32_WINO) {
         BMC_CHECK_ARG(h->taps == 9 && h->Coutpad % 128 == 0, "bmc_conv: the Winograd path serves 3x3 taps with Coutpad a multiple of 128");
         const int rc = bmc_conv_wino_launch(k, cus, (hipStream_t)stream);
         if (rc) return rc;
         BMC_CHECK_LAUNCH("bmc_conv (winograd)");
+        return 0;
+    }
+    if (h->math == BMC_MATH_FP32_WINO4) {
+        BMC_CHECK_ARG(h->taps == 9 && h->Coutpad % 128 == 0, "bmc_conv: the Winograd path serves 3x3 taps with Coutpad a multiple of 128");
+        const int rc = bmc_conv_wino4_launch(k, cus, (hipStream_t)stream);
+        if (rc) return rc;
+        BMC_CHECK_LAUNCH("bmc_conv (winograd F(4x4))");
         return 0;
     }
     if (h->math != BMC_MATH_FP32)

@@ -36,3 +36,6 @@ int bmc_conv1p_launch(ConvK k, int cus, hipStream_t st);
 // wino.hip: 3x3 convolution through the Winograd transform F(2x2, 3x3) on the fp32 MFMA (math = BMC_MATH_FP32_WINO; weights from
 // bmc_pack_weight_wino).  Returns 0, or < 0 with the error text set.
 int bmc_conv_wino_launch(ConvK k, int cus, hipStream_t st);
+// wino4.hip: the same through F(4x4, 3x3) (math = BMC_MATH_FP32_WINO4; weights from bmc_pack_weight_wino4; images at least 17
+// pixels wide, 32-bit pixel offsets).  Returns 0, or < 0 with the error text set.
+int bmc_conv_wino4_launch(ConvK k, int cus, hipStream_t st);

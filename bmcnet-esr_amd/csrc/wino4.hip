@@ -1,0 +1,602 @@
+// 3x3 convolution on the fp32 matrix cores through the Winograd transform F(4x4, 3x3):
+//
+//     Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray, points 0, +-1, +-2, inf; matrices below)
+//
+// 36 multiplies per 4x4 output tile and (ci, co) pair instead of 144 (direct) or 64 (F(2x2), wino.hip): 1.78x fewer MFMA
+// cycles than wino.hip's kernel, which ran the matrix pipes at 0.64-0.66 and was 45 % of the training step.
+// Numerics (tools/wino_numerics.py, profiles/r04_wino_numerics.txt): one convolution 1.9e-6 rel-L2 against float64 (direct
+// fp32 1.6e-7, F(2x2) 3.1e-7); two recurrent windows of the full network at 180x240 SR 1.0e-7 / 1.5e-7 (direct 4e-8 / 7e-8),
+// whole gradient 9.7e-6 (direct 8.6e-6) -- inside the parity budget (1e-4 / 1e-3 contract, 2e-5 / 2e-4 regression bars).
+// One restriction found by that experiment and enforced by the caller (bmc_hip/ops.py: `exact_zero`): convolutions whose
+// input can hold exact zeros over whole receptive fields (raw event counts, and what follows them before the first
+// normalisation, with zero biases and a zero state) keep F(2x2) in their FORWARD pass -- the reference gives exactly 0 there and
+// relu'(0) = 0 gates the gradient; a 6x6 patch through rounded transformed weights gives +-1e-8, a coin flip of the mask.
+// Same semantics as conv.hip (bmc_conv): multi-source NHWC operands, per-group weights, fused bias / residual / ReLU /
+// ReLU-mask / accumulate epilogue.
+//
+// Machine mapping (v_mfma_f32_16x16x4_f32, D rows = output channels, D columns = Winograd tiles):
+//   * workgroup = 8 waves = 16 CONSECUTIVE tiles of one image (flat tile index, row-major: a strip of 4 x 64 output pixels that
+//     may wrap onto the next tile rows -- no padded tile rows / columns whatever the image size) x 128 output channels;
+//     wave w = channels [16 w, 16 w + 16) x all 16 tiles x all 36 positions = 36 accumulator quads = 144 registers (AGPRs),
+//     two waves per SIMD.  Both transforms are in-lane (a lane owns one tile's column of D).
+//   * The transformed weights never touch LDS: wave w is the ONLY reader of its 16 rows of U = G g G^T, so it streams them from
+//     L2 straight into MFMA A-operand registers (global_load_dwordx4, one 1 KB instruction per position, a ring of D positions
+//     ahead; bmc_pack_weight_wino4 lays the 36 KB of a (chunk, wave) out in exactly that order).  No weight ring, no barrier
+//     for weights, 72 KB of LDS free for the transformed input of a WHOLE 16-channel chunk:
+//   * ONE barrier per chunk = per 144 MFMAs of every wave (wino.hip: per 32).  V = B^T d B of chunk c + 1 (36 positions x 16
+//     tiles x 16 channels, double-buffered) is produced while chunk c is multiplied: waves 0-5 each make row xi = w of the
+//     position grid for all (tile, channel quad) pairs -- 4 patch rows x 6 columns of 16-byte reads from the raw halo in LDS,
+//     4 FMAs per column with wave-uniform coefficients (row xi of B^T), the fixed 6 -> 6 transform along the row, 6 stores --
+//     spread over the chunk's MFMA pairs.
+//   * Waves 6-7 are the loaders: the raw halo strip of chunk c + 2 (6 rows x 72 pixel slots x 20 floats, padded so that the
+//     patch reads of four neighbouring tiles fall on different banks) goes straight into LDS by LDS-DMA, 17 instructions per
+//     loader wave per chunk with per-lane source offsets from a small per-wave LDS table rebuilt once per tile; pixels outside
+//     the image fetch the clamped edge pixel and are overwritten with zeros once landed (wino.hip's scheme).  Vector-memory
+//     operations complete in order, so only these two waves have HBM-latency operations in front of their weight loads: they
+//     run a ring of 12 positions (they hold no producer registers), waves 0-5 a ring of 6.  All waits are counted by hand
+//     (the U loads are inline asm; an over-count can only wait longer: hidden younger operations are never waited for less).
+//   * The epilogue applies A^T . A in place (in-lane, 100 quad operations), then finishes as conv.hip does: all loads, then all
+//     stores, 16 bytes per lane for each of the tile's 16 pixels.
+#include "bmc_common.h"
+#include "conv_k.h"
+#include "dma_ring.h"
+#include <stdlib.h>
+
+#ifndef BMC_W4_ABL
+#define BMC_W4_ABL 0       // ablation bits (tools/ builds only): 1 no MFMAs, 2 no weight loads, 4 no halo DMA, 8 no stores,
+                           // 16 no V production, 32 no V fragment reads, 64 no barriers, 128 no output transform
+#endif
+
+namespace {
+
+constexpr int CK = BMC_CK;
+constexpr int NT = 16, NPOS = 36, BN = 128;
+constexpr int RS = 20, NSLOT = 72;            // floats per pixel slot (16 + 4 pad), pixel slots per halo row
+constexpr int XROWF = NSLOT * RS;             // floats per halo row
+constexpr int XQUADS = 6 * XROWF / 4;         // 16-byte quads of a halo strip
+constexpr int NLW = 2, PPW = 17;              // loader waves, DMA instructions (64 quads each) per loader wave and chunk
+constexpr int XBUFA = NLW * PPW * 256;        // floats per X buffer as allocated
+constexpr int VBUF = NPOS * NT * CK;          // floats of transformed input per chunk
+constexpr int UBLK = NPOS * 256;              // floats of transformed weights per (chunk, wave): 36 positions x 1 KB
+constexpr int UCH = 8 * UBLK;                 // per chunk
+static_assert(XBUFA * 4 >= XQUADS * 16, "DMA coverage of the halo strip");
+
+template <int IMM>
+__device__ __forceinline__ void uload(f32x4& dst, const float* sbase, unsigned voff) {
+    if (BMC_W4_ABL & 2) { asm volatile("" : "=v"(dst)); return; }
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+// all but the newest N vector-memory operations of this wave are done; the two fragments are tied to the wait so that no
+// use of them can be scheduled above it
+template <int N>
+__device__ __forceinline__ void uwait(f32x4& x, f32x4& y) {
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N));
+}
+
+struct W4Tile { int nt, wt, b; };
+
+// LOADER = false: waves 0-5 (producer of row xi = wave of the position grid); true: waves 6-7 (halo DMA)
+template <bool LOADER>
+__device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int wave, const int t_first, const int t_hi,
+                                           const int t_stride) {
+    constexpr int D = LOADER ? 12 : 6;        // positions of U in flight
+    constexpr int NB = PPW;                   // vector-memory operations of a halo burst
+    float* const Xb = lds;
+    float* const Vb = lds + 2 * XBUFA;
+    int* const xtab = reinterpret_cast<int*>(lds + 2 * XBUFA + 2 * VBUF);          // [NLW][PPW][64]
+    const SrcDev* const tab = reinterpret_cast<const SrcDev*>(lds + 2 * XBUFA + 2 * VBUF + NLW * PPW * 64);
+    const unsigned xb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Xb;
+
+    const int lane = threadIdx.x & 63;
+    const int lj = lane & 15, lk = lane >> 4;
+    const int nchunks = a.nchunks;
+    const int tpi = a.tiles_x * a.tiles_y;            // Winograd tiles per image
+    const int wpi = (tpi + NT - 1) / NT;              // workgroup tiles per image
+
+    // (lane-dependent addresses that are needed once or twice per chunk are re-derived from v_mbcnt where they are used: kept
+    //  live across 144 MFMAs they are what the register allocator spills, and a scratch reload waits, in order, for every
+    //  weight request in flight)
+    auto lane_now = [&]() __attribute__((always_inline)) {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    auto decode = [&](int t) {
+        W4Tile it;
+        it.nt = t % a.ntn; t /= a.ntn;
+        it.wt = t % wpi;
+        it.b = t / wpi;
+        return it;
+    };
+
+    // ---------------------------------------------------------------- U stream (every wave: its own 16 rows)
+    const unsigned uvoff = (unsigned)(lane * 16);
+    auto ublock = [&](const W4Tile& it, int chunk) -> const float* {
+        const int grp = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
+        const float* p = static_cast<const float*>(a.w) + (long long)grp * a.w_group_stride + (long long)it.nt * nchunks * UCH +
+                         (long long)chunk * UCH + wave * UBLK;
+        const unsigned long long pv = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pv), hi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
+
+    // ---------------------------------------------------------------- X stream (loader waves), two chunks ahead of the MFMAs
+    const int wl = wave - (8 - NLW);                  // loader index
+    int xl_tile = t_first, xl_chunk = 0, s_idx = 0, c_in = 0, snch = 0, xl_buf = 0;
+    W4Tile xl_it = decode(t_first);
+    const float* sbase = nullptr;
+    int x_stride4 = 0;                                // pixel stride of the current source in bytes
+    unsigned xzm = 0, xzm_landed = 0;                 // bit k: instruction k's quad is a pixel outside the image
+    auto build_table = [&]() {                        // once per tile: pixel index / channel quad / zero flag of every quad this wave copies
+        const int T0 = xl_it.wt * NT;
+        const int ty0 = T0 / a.tiles_x, tx0 = T0 - ty0 * a.tiles_x;
+        // segments g = 0..3: the tiles of tile row ty0 + g, n_g of them from tile column (g == 0 ? tx0 : 0), pixel slots
+        // [st_g, st_g + 4 n_g + 2): neighbours in a row share two columns, every row break starts a fresh 6-column patch
+        int n = a.tiles_x - tx0; n = n < NT ? n : NT;
+        int left = NT - n;
+        const int st1 = 4 * n + 2;
+        n = left < a.tiles_x ? left : a.tiles_x; left -= n;
+        const int st2 = st1 + (n > 0 ? 4 * n + 2 : 0);
+        n = left < a.tiles_x ? left : a.tiles_x; left -= n;
+        const int st3 = st2 + (n > 0 ? 4 * n + 2 : 0);
+        n = left < a.tiles_x ? left : a.tiles_x;
+        const int st4 = st3 + (n > 0 ? 4 * n + 2 : 0);
+        xzm = 0;
+        const int l = lane_now();
+#pragma unroll 1
+        for (int k = 0; k < PPW; ++k) {
+            const int Q = (wl * PPW + k) * 64 + l;
+            const int r = Q / (XROWF / 4), rem = Q - r * (XROWF / 4);
+            const int s = rem / 5, q = rem - 5 * s;
+            const int g = (s >= st1 ? 1 : 0) + (s >= st2 ? 1 : 0) + (s >= st3 ? 1 : 0);       // (slots >= st4 are not real)
+            const int x = 4 * (g == 0 ? tx0 : 0) - 1 + (s - (g == 0 ? 0 : g == 1 ? st1 : g == 2 ? st2 : st3));
+            const int y = 4 * (ty0 + g) - 1 + r;
+            const bool real = r < 6 && s < st4 && q < 4;
+            const bool inside = y >= 0 && y < a.H && x >= 0 && x < a.W;
+            const int yc = y < 0 ? 0 : (y < a.H ? y : a.H - 1), xc = x < 0 ? 0 : (x < a.W ? x : a.W - 1);
+            const bool zero = real && !inside;
+            xzm |= zero ? (1u << k) : 0u;
+            xtab[(wl * PPW + k) * 64 + l] = real ? ((yc * a.W + xc) << 2) | q : 0;
+        }
+    };
+    auto src_select = [&]() {
+        const SrcDev S = tab[s_idx];
+        sbase = src_batch_ptr(S, xl_it.b);
+        snch = S.nch;
+        x_stride4 = S.pix_stride * 4;
+    };
+    auto xl_setup = [&]() {
+        s_idx = 0; c_in = 0; xl_chunk = 0;
+        build_table();
+        src_select();
+    };
+    auto load_x = [&]() {                             // the halo strip of the stream's next chunk -> buffer xl_buf
+        const float* const base = sbase + c_in;
+        xzm_landed = xzm;
+        const int l = lane_now();
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int e = xtab[(wl * PPW + k) * 64 + l];
+            const unsigned off = (unsigned)(e >> 2) * (unsigned)x_stride4 + (unsigned)(e & 3) * 16u;
+            if (!(BMC_W4_ABL & 4)) dma16(base, off, xb_lds + (unsigned)((xl_buf * XBUFA + (wl * PPW + k) * 256) * 4));
+        }
+        xl_buf ^= 1;
+        c_in += CK;
+        if (++xl_chunk == nchunks) {
+            xl_tile += t_stride;
+            if (xl_tile < t_hi) xl_it = decode(xl_tile);      // (past the last tile: the same tile again -- valid addresses, nobody reads it)
+            xl_setup();
+        } else if (c_in >= snch) {
+            c_in = 0; ++s_idx;
+            src_select();
+        }
+    };
+    auto zero_x = [&](int buf) {                      // after the burst has landed, before the barrier that publishes it
+        if (__builtin_amdgcn_ballot_w64(xzm_landed != 0) == 0) return;
+        const int l = lane_now();
+#pragma unroll
+        for (int k = 0; k < PPW; ++k)
+            if ((xzm_landed >> k) & 1)
+                *reinterpret_cast<f32x4*>(Xb + buf * XBUFA + ((wl * PPW + k) * 64 + l) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---------------------------------------------------------------- V production (waves 0-5), one chunk ahead of the MFMAs
+    // row xi = wave of B^T restricted to the rows it touches: (rows, coefficients)
+    const int xi = wave;
+    const int pr0 = xi == 0 ? 0 : 1, pr1 = (xi == 0 || xi == 5) ? (xi == 0 ? 2 : 3) : 2, pr2 = xi == 0 ? 4 : (xi == 5 ? 5 : 3),
+              pr3 = xi == 0 ? 4 : (xi == 5 ? 5 : 4);
+    const float pk0 = (xi == 0 || xi == 5 || xi == 2) ? 4.f : (xi == 1 ? -4.f : (xi == 3 ? -2.f : 2.f));
+    const float pk1 = (xi == 0 || xi == 5) ? -5.f : ((xi == 1 || xi == 2) ? -4.f : -1.f);
+    const float pk2 = (xi == 0 || xi == 5 || xi == 1) ? 1.f : (xi == 2 ? -1.f : (xi == 3 ? 2.f : -2.f));
+    const float pk3 = (xi == 0 || xi == 5) ? 0.f : 1.f;
+    int prow[4];                                      // float offsets of (patch row k, this lane's tile, channel quad) in an X buffer
+    auto prod_setup = [&](int t) {                    // geometry of the tile whose chunks the producer is working on
+        const W4Tile it = decode(t);
+        int pln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(pln));
+        const int ptile = pln >> 2, pq = pln & 3;
+        const int T0 = it.wt * NT;
+        const int ty0 = T0 / a.tiles_x;
+        const int ty = (T0 + ptile) / a.tiles_x;
+        const int slot = 4 * ptile + 2 * (ty - ty0);
+        prow[0] = pr0 * XROWF + slot * RS + pq * 4;
+        prow[1] = pr1 * XROWF + slot * RS + pq * 4;
+        prow[2] = pr2 * XROWF + slot * RS + pq * 4;
+        prow[3] = pr3 * XROWF + slot * RS + pq * 4;
+    };
+    // An item = row xi of (tile, channel quad) is made in two halves of two channels each (h = 0, 1): 6 + 4 + 4 register
+    // pairs live instead of quads -- with 144 accumulators, the U ring and the V fragments the quads did not fit (90 spills)
+    typedef float f32x2p __attribute__((ext_vector_type(2)));
+    f32x2p pt[6];
+    auto prod_col = [&](const float* xb, int h, int c, f32x2p (&d)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = *reinterpret_cast<const f32x2p*>(xb + prow[k] + c * RS + 2 * h);
+    };
+    auto prod_fma = [&](int c, const f32x2p (&d)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) pt[c][e] = __builtin_fmaf(pk3, d[3][e], __builtin_fmaf(pk2, d[2][e], __builtin_fmaf(pk1, d[1][e], pk0 * d[0][e])));
+    };
+    // along the row: (4 0 -5 0 1 0) (0 -4 -4 1 1 0) (0 4 -4 -1 1 0) (0 -2 -1 2 1 0) (0 2 -1 -2 1 0) (0 4 0 -5 0 1)
+    auto prod_row_a = [&](f32x2p& ta, f32x2p& tb, f32x2p& tc, f32x2p& te) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            ta[e] = __builtin_fmaf(-4.f, pt[2][e], pt[4][e]);
+            tb[e] = __builtin_fmaf(-4.f, pt[1][e], pt[3][e]);
+            tc[e] = pt[4][e] - pt[2][e];
+            te[e] = pt[3][e] - pt[1][e];
+            pt[0][e] = __builtin_fmaf(4.f, pt[0][e], __builtin_fmaf(-5.f, pt[2][e], pt[4][e]));
+            pt[5][e] = __builtin_fmaf(4.f, pt[1][e], __builtin_fmaf(-5.f, pt[3][e], pt[5][e]));
+        }
+    };
+    auto prod_row_b = [&](const f32x2p& ta, const f32x2p& tb, const f32x2p& tc, const f32x2p& te) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            pt[1][e] = ta[e] + tb[e];
+            pt[2][e] = ta[e] - tb[e];
+            pt[3][e] = __builtin_fmaf(2.f, te[e], tc[e]);
+            pt[4][e] = __builtin_fmaf(-2.f, te[e], tc[e]);
+        }
+    };
+    auto prod_store = [&](float* vb, int h) __attribute__((always_inline)) {
+        const int l = lane_now();
+        const int vst = xi * 6 * NT * CK + (l >> 2) * CK + (((l & 3) ^ swz(l >> 2)) * 4);          // + nu * NT * CK
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x2p*>(vb + vst + nu * NT * CK + 2 * h) = pt[nu];
+    };
+
+    // ---------------------------------------------------------------- MFMA side
+    const int voff = lj * CK + ((lk ^ swz(lj)) * 4);                                  // + pos * NT * CK
+    f32x4 acc[NPOS];
+    auto pin_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < NPOS; ++p) asm volatile("" : "+v"(acc[p]));
+    };
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int p = 0; p < NPOS; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 ur[D];
+    f32x4 vf[2][2];
+    auto read_v = [&](const float* vb, int pair, f32x4 (&v)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (BMC_W4_ABL & 32) { v[i] = f32x4{4.f, 3.f, 2.f, 1.f}; asm volatile("" : "+v"(v[i])); continue; }
+            v[i] = *reinterpret_cast<const f32x4*>(vb + (2 * pair + i) * NT * CK + voff);
+        }
+    };
+    auto mfma8 = [&](f32x4& c0, f32x4& c1, const f32x4& u0, const f32x4& u1, const f32x4 (&v)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (BMC_W4_ABL & 1) { c0[m] += u0[m] * v[0][m]; c1[m] += u1[m] * v[1][m]; continue; }
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[m], v[0][m], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[m], v[1][m], c1, 0, 0, 0);
+        }
+    };
+
+    // One chunk: 18 pairs of positions.  ucur / unx: this wave's U blocks of this chunk and of the next one (positions that
+    // the ring requests past 35); vb: this chunk's V; xbn / vbn: the producer's input and output (next chunk).
+    auto chunk = [&](const float* ucur, const float* unx, const float* vb, const float* xbn, float* vbn, const int gbuf)
+                     __attribute__((always_inline)) {
+        f32x2p pd[4], ta, tb, tc, te;
+        // the producer's timetable: half h of its item takes pairs PH0 + 8 h + (0..5: one patch column each, reads in front of
+        // the pair's MFMAs, FMAs behind them), + 6 (along the row, first part), + 7 (second part, stores)
+        constexpr int PH0 = 1;
+#pragma unroll
+        for (int pp = 0; pp < NPOS / 2; ++pp) {
+            const int ph = pp >= PH0 + 8 ? 1 : 0, ps = pp - PH0 - 8 * ph;      // half, step within it (valid for PH0 <= pp < PH0 + 16)
+            const bool pact = !LOADER && !(BMC_W4_ABL & 16) && pp >= PH0 && pp < PH0 + 16;
+            const int p0 = 2 * pp, p1 = p0 + 1, s0 = p0 % D, s1 = p1 % D;
+            // U(p0), U(p1) have landed: younger are the D - 2 requests behind them and, on a loader wave, this chunk's halo
+            // burst (issued behind pair 0's requests U(D), U(D + 1)) while the fragments waited for are older than it:
+            // pairs 1 .. D / 2
+            if (LOADER && pp >= 1 && pp <= D / 2) uwait<D - 2 + NB>(ur[s0], ur[s1]); else uwait<D - 2>(ur[s0], ur[s1]);
+            if (LOADER && pp == D / 2 + 1) zero_x(gbuf);         // (the wait above was the first behind the burst: it has landed)
+            __builtin_amdgcn_sched_barrier(0);
+            if (pp < NPOS / 2 - 1) read_v(vb, pp + 1, vf[(pp + 1) & 1]);
+            if (pact && ps < 6) prod_col(xbn, ph, ps, pd);
+            if (pp == NPOS / 2 - 1) {
+                // the chunk's barrier sits in front of its LAST pair: V of the next chunk is complete (lgkmcnt(0)), the halo
+                // two chunks ahead has landed and is patched; behind it the next chunk's first fragments are read under
+                // this pair's MFMAs (their own fragments are in registers since the previous pair)
+                if (BMC_W4_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else ring_publish();
+                read_v(vbn, 0, vf[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(acc[p0], acc[p1], ur[s0], ur[s1], vf[pp & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            // the ring slots just consumed take positions p0 + D, p1 + D
+            {
+                const int q0 = p0 + D;
+                if (q0 < NPOS) {
+                    const float* const b = ucur + (q0 / 4) * 1024;
+                    if (q0 % 4 == 0) { uload<0>(ur[s0], b, uvoff); uload<1024>(ur[s1], b, uvoff); }
+                    else { uload<2048>(ur[s0], b, uvoff); uload<3072>(ur[s1], b, uvoff); }
+                } else {
+                    const float* const b = unx + ((q0 - NPOS) / 4) * 1024;
+                    if ((q0 - NPOS) % 4 == 0) { uload<0>(ur[s0], b, uvoff); uload<1024>(ur[s1], b, uvoff); }
+                    else { uload<2048>(ur[s0], b, uvoff); uload<3072>(ur[s1], b, uvoff); }
+                }
+            }
+            if (LOADER && pp == 0) load_x();          // (behind pair 0's requests: the burst is in front of everything pair D / 2 needs)
+            if (pact) {
+                if (ps < 6) prod_fma(ps, pd);
+                if (ps == 6) prod_row_a(ta, tb, tc, te);
+                if (ps == 7) { prod_row_b(ta, tb, tc, te); prod_store(vbn, ph); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    int ep_b = -1;
+    const float* ep_res = nullptr;
+    const float* ep_mask = nullptr;
+    auto epilogue = [&](const W4Tile& it) __attribute__((always_inline)) {
+        pin_acc();
+        if (!(BMC_W4_ABL & 128)) {
+            // Y = A^T M A, rows of A^T: (1 1 1 1 1 0) (0 1 -1 2 -2 0) (0 1 1 4 4 0) (0 1 -1 8 -8 1); columns first, in place
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) {
+                const f32x4 m0 = acc[nu], m1 = acc[6 + nu], m2 = acc[12 + nu], m3 = acc[18 + nu], m4 = acc[24 + nu], m5 = acc[30 + nu];
+                const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                acc[nu] = (m0 + s1) + s2;
+                acc[6 + nu] = d1 + 2.f * d2;
+                acc[12 + nu] = s1 + 4.f * s2;
+                acc[18 + nu] = (d1 + 8.f * d2) + m5;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 m0 = acc[6 * i], m1 = acc[6 * i + 1], m2 = acc[6 * i + 2], m3 = acc[6 * i + 3], m4 = acc[6 * i + 4], m5 = acc[6 * i + 5];
+                const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                acc[4 * i] = (m0 + s1) + s2;          // (4 i + j <= 6 i + j: never overwrites an unread input of a later row)
+                acc[4 * i + 1] = d1 + 2.f * d2;
+                acc[4 * i + 2] = s1 + 4.f * s2;
+                acc[4 * i + 3] = (d1 + 8.f * d2) + m5;
+            }
+        }
+        const int g = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
+        const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
+        float* const outb = a.out + (long long)it.b * a.out_batch_stride;
+        if (it.b != ep_b) {
+            ep_b = it.b;
+            ep_res = a.residual.ptr ? src_batch_ptr(a.residual, it.b) : nullptr;
+            ep_mask = a.mask.ptr ? src_batch_ptr(a.mask, it.b) : nullptr;
+        }
+        const float* const resb = ep_res;
+        const float* const maskb = ep_mask;
+        // (lane index re-derived: the epilogue's lane-dependent values must not be kept -- or spilled -- across the chunks; a
+        //  scratch reload inside the chunk loop waits, in order, for every weight request in flight)
+        int eln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(eln));
+        const int elj = eln & 15, elk = eln >> 4;
+        const int co = it.nt * BN + 16 * wave + 4 * elk;
+        const bool cok = co < a.Cout;
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (biasg && cok) bq = ldg16(biasg + co);
+        const int T = it.wt * NT + elj;
+        const int ty = T / a.tiles_x, tx = T - ty * a.tiles_x;
+        const int y0 = 4 * ty, x0 = 4 * tx;
+        const int pix0 = y0 * a.W + x0;
+        // pixel (i, j) of the tile: in the image?  (tiles past the image's last one have ty >= tiles_y: y0 >= H)
+        auto pok = [&](int i, int j) { return cok && y0 + i < a.H && x0 + j < a.W; };
+        auto fetch = [&](const float* base, int stride, float fill, auto&& apply) __attribute__((always_inline)) {
+            // one tile row at a time: 4 loads, then their use (16 registers in flight)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 dd[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dd[j] = f32x4{fill, fill, fill, fill};
+                    if (pok(i, j)) dd[j] = ldg16(base + ((pix0 + i * a.W + j) * stride + co));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) apply(acc[4 * i + j], dd[j]);
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < 16; ++p) acc[p] += bq;
+        if (resb) fetch(resb, a.residual.pix_stride, 0.f, [](f32x4& v, const f32x4& d) { v += d; });
+        if (a.relu) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[p][k] = fmaxf(acc[p][k], 0.f);
+        }
+        if (maskb) fetch(maskb, a.mask.pix_stride, 1.f, [](f32x4& v, const f32x4& d) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = d[k] > 0.f ? v[k] : 0.f;
+        });
+        if (a.accumulate) fetch(outb, a.out_pix_stride, 0.f, [](f32x4& v, const f32x4& d) { v += d; });
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (pok(i, j) && !((BMC_W4_ABL & 8) && acc[4 * i + j][0] != 12345.678f))
+                    stg16(outb + ((pix0 + i * a.W + j) * a.out_pix_stride + co), acc[4 * i + j]);
+        init_acc();
+    };
+
+    // ---------------------------------------------------------------- prologue
+    const W4Tile it0 = decode(t_first);
+    const float* ublk = ublock(it0, 0);
+    if (LOADER) {
+        xl_setup();
+        load_x();                                     // chunk 0 -> buffer 0
+    }
+    // the first D positions of U
+#pragma unroll
+    for (int p = 0; p < D; p += 2) {
+        const float* const b = ublk + (p / 4) * 1024;
+        if (p % 4 == 0) { uload<0>(ur[p], b, uvoff); uload<1024>(ur[p + 1], b, uvoff); }
+        else { uload<2048>(ur[p], b, uvoff); uload<3072>(ur[p + 1], b, uvoff); }
+    }
+    if (LOADER) {
+        dma_wait<D>();                                // the first burst (older than the D requests) has landed
+        zero_x(0);
+        load_x();                                     // chunk 1 -> buffer 1
+    }
+    __syncthreads();
+    if (!LOADER) {
+        prod_setup(t_first);
+        if (!(BMC_W4_ABL & 16)) {
+            f32x2p pd[4], ta, tb, tc, te;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) { prod_col(Xb, h, c, pd); prod_fma(c, pd); }
+                prod_row_a(ta, tb, tc, te);
+                prod_row_b(ta, tb, tc, te);
+                prod_store(Vb, h);
+            }
+        }
+    } else {
+        dma_wait<0>();
+        zero_x(1);
+    }
+    __syncthreads();
+    init_acc();
+    read_v(Vb, 0, vf[0]);
+
+    // ---------------------------------------------------------------- main loop
+    // The streams never stop: past the workgroup's last tile the loaders and the producers work on that tile again (valid
+    // addresses, buffers nobody reads), so no pair carries an "is there a next one" branch and every wait is a constant.
+    int gc = 0;
+    for (int tile = t_first; tile < t_hi; tile += t_stride) {
+        const W4Tile it = decode(tile);
+        const int tile_n = tile + t_stride < t_hi ? tile + t_stride : tile;
+        for (int c = 0; c < nchunks; ++c, ++gc) {
+            const float* unx;
+            if (c + 1 < nchunks) unx = ublk + UCH;
+            else unx = ublock(decode(tile_n), 0);
+            if (!LOADER && c == nchunks - 1) prod_setup(tile_n);         // the producer moves on to the next tile's first chunk
+            chunk(ublk, unx, Vb + (gc & 1) * VBUF, Xb + ((gc + 1) & 1) * XBUFA, Vb + ((gc + 1) & 1) * VBUF, gc & 1);
+            ublk = unx;
+        }
+        epilogue(it);
+    }
+    dma_wait<0>();
+}
+
+__global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const ConvK a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * XBUFA + 2 * VBUF + NLW * PPW * 64 + BMC_MAX_SRC * 8];
+    SrcDev* const tab = reinterpret_cast<SrcDev*>(lds + 2 * XBUFA + 2 * VBUF + NLW * PPW * 64);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int i = 0; i < BMC_MAX_SRC; ++i)
+        if (tid == i) tab[i] = a.src[i];
+    __syncthreads();
+
+    const int ntiles = a.ntiles;
+    constexpr int NX_ = 8;
+    const bool xcd_map = (gridDim.x % NX_) == 0 && ntiles >= (int)gridDim.x;
+    const int xcd = blockIdx.x % NX_, xj = blockIdx.x / NX_, per_x = gridDim.x / NX_;
+    const int t_lo = xcd_map ? (int)((long long)ntiles * xcd / NX_) : 0;
+    const int t_hi = xcd_map ? (int)((long long)ntiles * (xcd + 1) / NX_) : ntiles;
+    const int t_first = xcd_map ? t_lo + xj : (int)blockIdx.x;
+    const int t_stride = xcd_map ? per_x : (int)gridDim.x;
+    if (t_first >= t_hi) return;
+    if (wave >= 8 - NLW) wino4_body<true>(a, lds, wave, t_first, t_hi, t_stride);
+    else wino4_body<false>(a, lds, wave, t_first, t_hi, t_stride);
+}
+
+// U = G g G^T (6x6 from 3x3, G rows (1/4 0 0) (-1/6 -1/6 -1/6) (-1/6 1/6 -1/6) (1/24 1/12 1/6) (1/24 -1/12 1/6) (0 0 1)), made in
+// double and rounded once, in the kernel's streaming order out[g][ntile][K chunk][wave 8][position 36][lane 64][4]: lane l of
+// wave w holds row co = 128 ntile + 16 w + (l & 15), channels k = 16 chunk + 4 (l >> 4) + 0..3.  Row / K conventions as
+// pack_wino_kernel (wino.hip): forward rows = output channels, K = packed input channels (kmap); transposed (data gradient
+// w.r.t. packed source channels [k0, k0 + nk)): rows = n = k - k0, K = output channels, taps mirrored.
+__global__ void pack_wino4_kernel(const float* __restrict__ w, const int* __restrict__ kmap, int G, int Cout, int Cin, int kpad,
+                                  int rows_pad, int transposed, int k0, int nk, float* __restrict__ out) {
+    const long long total = (long long)G * (kpad / CK) * rows_pad * CK;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int kk = idx % CK;
+        long long r = idx / CK;
+        const int row = r % rows_pad; r /= rows_pad;
+        const int chunk = r % (kpad / CK);
+        const int g = r / (kpad / CK);
+        const int k = chunk * CK + kk;
+        double gt[3][3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) gt[i / 3][i % 3] = 0.0;
+        int co, ci;
+        if (!transposed) { co = row; ci = kmap ? kmap[k] : (k < Cin ? k : -1); }
+        else { co = k; ci = row < nk ? (kmap ? kmap[k0 + row] : k0 + row) : -1; }
+        if (co < Cout && ci >= 0) {
+            const float* p = w + (((long long)g * Cout + co) * Cin + ci) * 9;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) gt[i / 3][i % 3] = transposed ? p[8 - i] : p[i];
+        }
+        const double Gm[6][3] = {{0.25, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
+                                 {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
+        double gg[6][3];
+#pragma unroll
+        for (int x = 0; x < 6; ++x)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) gg[x][b] = Gm[x][0] * gt[0][b] + Gm[x][1] * gt[1][b] + Gm[x][2] * gt[2][b];
+        const int ntile = row / BN, wv = (row % BN) / 16, l = (row & 15) + 16 * (kk >> 2);
+        float* const o = out + ((((long long)g * (rows_pad / BN) + ntile) * (kpad / CK) + chunk) * 8 + wv) * UBLK + l * 4 + (kk & 3);
+#pragma unroll
+        for (int x = 0; x < 6; ++x)
+#pragma unroll
+            for (int n = 0; n < 6; ++n)
+                o[(x * 6 + n) * 256] = (float)(gg[x][0] * Gm[n][0] + gg[x][1] * Gm[n][1] + gg[x][2] * Gm[n][2]);
+    }
+}
+
+}  // namespace
+
+// Called by bmc_conv (conv.hip) for math == BMC_MATH_FP32_WINO4 once the argument block is validated.
+int bmc_conv_wino4_launch(ConvK k, int cus, hipStream_t st) {
+    k.tiles_x = (k.W + 3) / 4;
+    k.tiles_y = (k.H + 3) / 4;
+    k.ntn = k.Coutpad / BN;
+    if (k.tiles_x < 5) { bmc_set_error("bmc_conv (winograd F(4x4)): images narrower than 17 pixels are not served"); return -1; }
+    long long max_stride = k.out_pix_stride;
+    for (int i = 0; i < k.nsrc; ++i) max_stride = k.src[i].pix_stride > max_stride ? k.src[i].pix_stride : max_stride;
+    if (k.residual.ptr && k.residual.pix_stride > max_stride) max_stride = k.residual.pix_stride;
+    if (k.mask.ptr && k.mask.pix_stride > max_stride) max_stride = k.mask.pix_stride;
+    if ((long long)k.H * k.W * max_stride * 4 >= (1ll << 31) || (long long)k.H * k.W >= (1ll << 24)) {
+        bmc_set_error("bmc_conv (winograd F(4x4)): image too large for 32-bit offsets (H*W*pix_stride*4 must stay below 2^31)");
+        return -1;
+    }
+    const long long wpi = ((long long)k.tiles_x * k.tiles_y + NT - 1) / NT;
+    const long long ntiles = (long long)k.B * wpi * k.ntn;
+    if (ntiles >= (1ll << 31)) { bmc_set_error("bmc_conv (winograd F(4x4)): too many tiles"); return -1; }
+    k.ntiles = (int)ntiles;
+    dim3 grid((unsigned)(ntiles < cus ? ntiles : cus));
+    hipLaunchKernelGGL(wino4_conv_kernel, grid, dim3(512), 0, st, k);
+    return 0;
+}
+
+extern "C" int bmc_pack_weight_wino4(const float* w, const int* kmap, int G, int Cout, int Cin, int Kpad, int Coutpad,
+                                     int transposed, int k0, int nk, float* out, bmc_stream_t s) {
+    BMC_CHECK_ARG(w && out && G >= 1 && Cout >= 1 && Cin >= 1, "bmc_pack_weight_wino4: bad arguments");
+    BMC_CHECK_ARG(Kpad > 0 && Kpad % CK == 0 && Coutpad > 0 && Coutpad % 128 == 0,
+                  "bmc_pack_weight_wino4: Kpad must be a multiple of 16 and the row count a multiple of 128");
+    BMC_CHECK_ARG(!transposed || (k0 >= 0 && nk >= 1 && nk <= Coutpad && Kpad >= Cout), "bmc_pack_weight_wino4: bad transposed window");
+    const long long total = (long long)G * (Kpad / CK) * Coutpad * CK;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_wino4_kernel, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)s, w, kmap, G,
+                       Cout, Cin, Kpad, Coutpad, transposed, k0, nk, out);
+    BMC_CHECK_LAUNCH("bmc_pack_weight_wino4");
+    return 0;
+}

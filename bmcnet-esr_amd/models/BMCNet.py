@@ -12,6 +12,8 @@ Execution differs from the reference on purpose (results do not):
 """
 import torch.nn.functional as F
 
+import contextlib
+
 from .submodules import *  # noqa: F401,F403  (same star-import surface as the reference)
 from .submodules import BIE, PixelUnShuffle, ResidualBlock_noBN, initialize_weights, to_nchw, to_nhwc
 from bmc_hip import bie, ops
@@ -31,21 +33,28 @@ class ParallelBlk(nn.Module):
         self.gBIE = BIE(nf)   # global BIE
         initialize_weights([self.conv1, self.conv2, self.conv1_st, self.conv2_st], 0.1)
 
-    def forward_nhwc(self, x12, xs, xst12, xsst12, need_st=True):
+    def forward_nhwc(self, x12, xs, xst12, xsst12, need_st=True, first=False):
         """x12 = [x_1; x_2], xst12 = [x_1_st; x_2_st], xsst12 = [x_1_s_st; x_2_s_st] (batch-stacked twins).
-        need_st=False: the caller will not read the returned xst12 (it is None then)."""
+        need_st=False: the caller will not read the returned xst12 (it is None then).
+        first: this is the backbone's first block -- its two leading residual blocks read activations that can still hold
+        exact zeros over whole receptive fields (ops.exact_zero_inputs)."""
+        fused = need_st or (bie.FUSE_FIRST and bie.chain_supported(x12.shape[-1]))
+        with (ops.exact_zero_inputs() if first else contextlib.nullcontext()):
+            if fused:
+                # both residual blocks write into the halves of one buffer, so the two lBIE calls (and, inside them, the
+                # weight-shared conv1/conv2 and convf1/convf2 pairs) run as ONE fused twin node over 4B samples
+                pair = self._res_pair(x12, xst12)
+            else:
+                x12 = self.conv1.forward_nhwc(x12)
+                xst12 = self.conv1_st.forward_nhwc(xst12)
         if need_st:
-            # both residual blocks write into the halves of one buffer, so the two lBIE calls (and, inside them, the
-            # weight-shared conv1/conv2 and convf1/convf2 pairs) run as ONE fused twin node over 4B samples
-            o, xsst12 = self.lBIE.forward_twin(self._res_pair(x12, xst12), xsst12)
+            o, xsst12 = self.lBIE.forward_twin(pair, xsst12)
             x12, xst12 = bie.Unstack2Fn.unstack(o)
-        elif bie.FUSE_FIRST and bie.chain_supported(x12.shape[-1]):
+        elif fused:
             # the same with only the first output of the local BIE (one fused node again: BIE.forward_first)
-            x12, xsst12 = self.lBIE.forward_first(self._res_pair(x12, xst12), xsst12)
+            x12, xsst12 = self.lBIE.forward_first(pair, xsst12)
             xst12 = None
         else:
-            x12 = self.conv1.forward_nhwc(x12)
-            xst12 = self.conv1_st.forward_nhwc(xst12)
             x12, xst12, xsst12 = self.lBIE.forward_pair(x12, xst12, xsst12, need_second=False)
         x12, xs = self.gBIE.forward_twin(x12, xs)
         return x12, xs, xst12, xsst12
@@ -124,6 +133,15 @@ class Backbone(nn.Module):
         Returns x_h, x_h_p, x_h_n, x_o (NHWC)."""
         B = o12.shape[0] // 2
         hpn = h3[:2 * B]
+        # (the input-fusion convolutions read raw event counts: ops.exact_zero_inputs)
+        with ops.exact_zero_inputs():
+            st12, s12, sst12, xs = self._input_fusion(xin12, h3, hpn, o12, B)
+        n_layers = len(self.para_reschunk)
+        for i, layer in enumerate(self.para_reschunk):      # x*_st of the last block is never read: skip what only feeds it
+            s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12, need_st=i + 1 < n_layers, first=i == 0)
+        return self._tail(s12, xs, sst12, B)
+
+    def _input_fusion(self, xin12, h3, hpn, o12, B):
         st12 = ops.conv([View(xin12), View(hpn), View(o12)], self.conv_fpst.weight, self.conv_fpst.bias, self._sp_fpst,
                         relu=True)                                         # [xp_st; xn_st]
         s12 = ops.conv([View(xin12), View(hpn)], self.conv_fps.weight, self.conv_fps.bias, self._sp_fps,
@@ -134,10 +152,9 @@ class Backbone(nn.Module):
                           self.conv_fs.bias, self._sp_fs_shared, B=B)      # input channels of xp_st, xn_st, o (+ the bias)
         fs3 = ops.conv([View(h3)], wfs, None, self._sp_fs_h, B=3 * B, relu=True,
                        residual=View(shared, mod=B))                       # + those of h*: [xs_p_st; xs_n_st; xs]
-        sst12, xs = fs3[:2 * B], fs3[2 * B:]
-        n_layers = len(self.para_reschunk)
-        for i, layer in enumerate(self.para_reschunk):      # x*_st of the last block is never read: skip what only feeds it
-            s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12, need_st=i + 1 < n_layers)
+        return st12, s12, fs3[:2 * B], fs3[2 * B:]
+
+    def _tail(self, s12, xs, sst12, B):
         # the three new states go into ONE buffer [x_h; x_h_p; x_h_n]: the next window reads them as h3 without a copy
         # (ops.stack_states recognises the adjacent views)
         hbuf = torch.empty((3 * B,) + tuple(xs.shape[1:]), device=xs.device, dtype=xs.dtype)

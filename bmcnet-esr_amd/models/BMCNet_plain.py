@@ -38,11 +38,17 @@ class Backbone(nn.Module):
 
     def forward_nhwc(self, xin12, h, o12):
         B = h.shape[0]
-        x12 = ops.conv([View(xin12), View(h, mod=B), View(o12)], self.conv_f1.weight, self.conv_f1.bias, self._sp_f1,
-                       B=2 * B, relu=True)
-        xs = ops.conv([View(xin12, b0=0), View(xin12, b0=B), View(h), View(o12, b0=0), View(o12, b0=B)],
-                      self.conv_fs.weight, self.conv_fs.bias, self._sp_fs, B=B, relu=True)
-        for layer in self.para_reschunk:
+        # (the input-fusion convolutions and the first BIE's residual blocks: ops.exact_zero_inputs)
+        with ops.exact_zero_inputs():
+            x12 = ops.conv([View(xin12), View(h, mod=B), View(o12)], self.conv_f1.weight, self.conv_f1.bias, self._sp_f1,
+                           B=2 * B, relu=True)
+            xs = ops.conv([View(xin12, b0=0), View(xin12, b0=B), View(h), View(o12, b0=0), View(o12, b0=B)],
+                          self.conv_fs.weight, self.conv_fs.bias, self._sp_fs, B=B, relu=True)
+        for i, layer in enumerate(self.para_reschunk):
+            if i == 0:
+                with ops.exact_zero_inputs():
+                    x12, xs = layer.forward_twin(x12, xs)
+                continue
             x12, xs = layer.forward_twin(x12, xs)
         x_h = ops.conv([View(xs)], self.conv_h.weight, self.conv_h.bias, self._sp_h, relu=True)
         w_o, b_o = self.conv_o.weight, self.conv_o.bias

@@ -148,6 +148,7 @@ int bmc_pack_weight_t(const float* w, const int* kmap, int G, int Cout, int Cin,
 #define BMC_MATH_BF16 1
 #define BMC_MATH_BF16X6 3
 #define BMC_MATH_FP32_WINO 4 /* bmc_conv only: fp32 MFMA through the Winograd transform F(2x2, 3x3), below */
+#define BMC_MATH_FP32_WINO4 5 /* bmc_conv only: the same through F(4x4, 3x3) (bmc_pack_weight_wino4) */
 int bmc_split_weight(const float* packed, void* out, long long nsteps, int Coutpad, int planes, bmc_stream_t s);
 
 /* Conv weights [G][Cout][Cin][3][3] -> the TRANSFORMED weights U = G g G^T of Winograd's F(2x2, 3x3) minimal filtering
@@ -159,6 +160,15 @@ int bmc_split_weight(const float* packed, void* out, long long nsteps, int Coutp
  *                    to Coutpad), K = the Cout output channels (padded to Kpad), taps mirrored (as bmc_pack_weight_t). */
 int bmc_pack_weight_wino(const float* w, const int* kmap, int G, int Cout, int Cin, int Kpad, int Coutpad, int transposed,
                          int k0, int nk, float* out, bmc_stream_t s);
+
+/* The same for F(4x4, 3x3) (36 values per (co, ci) pair, made in double and rounded once; points 0, +-1, +-2, inf), in the
+ * streaming order of bmc_conv with math = BMC_MATH_FP32_WINO4: [G][Coutpad/128][Kpad/16][8 (wave)][36 (position)][64 (lane)][4],
+ * lane l of wave w = row 128 ntile + 16 w + (l & 15), channels 16 chunk + 4 (l >> 4) + 0..3 -- the MFMA A-operand image a wave
+ * loads with one 1 KB instruction per position.  Arguments as bmc_pack_weight_wino; w_group_stride of the launch =
+ * Kpad * Coutpad * 36 floats.  Replaces the weight operand of the 3x3 F.conv2d calls at models/submodules.py:31-35 (the
+ * residual blocks: 100 of the 103 3x3 convolutions of a window, models/BMCNet.py:19-32) and models/BMCNet.py:64-82. */
+int bmc_pack_weight_wino4(const float* w, const int* kmap, int G, int Cout, int Cin, int Kpad, int Coutpad, int transposed,
+                          int k0, int nk, float* out, bmc_stream_t s);
 
 /* ---- implicit-GEMM convolution (fp32 MFMA) -------------------------------
  * Replaces F.conv2d at models/submodules.py:25-26,33-34,44-53,63-67,75 and

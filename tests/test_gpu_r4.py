@@ -1,0 +1,164 @@
+"""GPU parity tests added in round 4 (-m gpu), all through the C ABI of libbmc_hip.so: the Winograd F(4x4, 3x3) convolution
+kernel (csrc/wino4.hip) against float64, against the direct kernel with every epilogue, over ragged geometries; the routing
+rule for exact-zero inputs (ops.exact_zero_inputs)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from test_gpu_r2 import _gpu, oracle_params, rel_l2, scaled_init  # noqa: E402,F401
+
+
+@pytest.fixture
+def force_wino4():
+    """Send every eligible 3x3 launch through the F(4x4) kernel, whatever its size (default: only launches that fill the chip)."""
+    from bmc_hip import ops
+    old = ops.WINO_MIN_TILES, ops.WINO4_MIN_TILES, ops.WINO4
+    ops.WINO_MIN_TILES, ops.WINO4_MIN_TILES, ops.WINO4 = 0, 0, True
+    yield ops
+    ops.WINO_MIN_TILES, ops.WINO4_MIN_TILES, ops.WINO4 = old
+
+
+@pytest.mark.parametrize("B,H,W,cins,cout,relu,res", [
+    (1, 4, 64, [128], 128, True, False),              # exactly one workgroup tile: one row of 16 tiles
+    (2, 9, 19, [128], 128, False, False),             # 5 x 3 tiles: the strip wraps twice, ragged in both directions
+    (2, 19, 37, [128], 128, True, True),              # 10 x 5 tiles: 4 workgroup tiles per image, the last one partial
+    (2, 13, 21, [16, 128, 16], 128, True, False),     # multi-source with narrow sources
+    (1, 11, 18, [16, 128, 16, 16, 32], 128, True, False),
+    (2, 5, 40, [256], 256, False, True),              # two channel tiles, 16 chunks
+    (3, 17, 33, [32], 128, False, False),
+    (1, 45, 80, [128], 128, True, True),              # the reference's own LR frame size
+])
+def test_winograd4_conv_fwd_bwd_vs_float64(force_wino4, B, H, W, cins, cout, relu, res):
+    """Forward and data gradient through wino4.hip (weight gradient: the F(2x2) / pixel-reduction kernels), against float64.
+    One F(4x4) convolution measures 1.9e-6 (forward) / 2.3e-6 (data gradient) in the CPU emulation (profiles/r04_wino_numerics.txt)."""
+    dev = _gpu()
+    ops = force_wino4
+    from bmc_hip.ops import ConvSpec, View
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(B, cout, H, W, generator=g) if res else None
+    go = torch.randn(B, cout, H, W, generator=g)
+    xs_c = [x.double().requires_grad_() for x in xs]
+    w_c, b_c = w.double().requires_grad_(), b.double().requires_grad_()
+    r_c = r.double().requires_grad_() if res else None
+    y = F.conv2d(torch.cat(xs_c, 1), w_c, b_c, padding=1)
+    if res:
+        y = y + r_c
+    if relu:
+        y = torch.relu(y)
+    y.backward(go.double())
+    assert ops.wino_ok(B, H, W, cout, 9, fwd=True) == 4
+    xs_g = [nhwc(x).to(dev).requires_grad_() for x in xs]
+    w_g, b_g = w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    r_g = nhwc(r).to(dev).requires_grad_() if res else None
+    ops.PROFILE = []
+    yg = ops.conv([View(x) for x in xs_g], w_g, b_g, ConvSpec.dense(*cins), relu=relu, residual=View(r_g) if res else None)
+    yg.backward(nhwc(go).to(dev))
+    names = [p[0] for p in ops.PROFILE]
+    ops.PROFILE = None
+    assert names.count("wino4_conv<9,128>") >= 1 + sum(1 for c in cins if c % 128 == 0), names      # the kernel under test really ran
+    assert rel_l2(yg.permute(0, 3, 1, 2), y) < 1e-5
+    for xg, xc in zip(xs_g, xs_c):
+        assert rel_l2(xg.grad.permute(0, 3, 1, 2), xc.grad) < 1e-5
+    assert rel_l2(w_g.grad, w_c.grad) < 2e-5
+    assert rel_l2(b_g.grad, b_c.grad) < 2e-5
+    if res:
+        assert rel_l2(r_g.grad.permute(0, 3, 1, 2), r_c.grad) < 2e-5
+
+
+def test_winograd4_matches_direct_kernel_with_every_epilogue(force_wino4):
+    """The same launches through the direct fp32 kernel and through the F(4x4) kernel: per-group bias, residual with a batch
+    rotation, ReLU, ReLU mask, accumulate, per-group weights, output written into a channel window of a wider tensor."""
+    dev = _gpu()
+    from bmc_hip.ops import _packed_weight, _src, conv_raw, coutpad, ConvSpec
+    torch.manual_seed(12)
+    B, H, W, Cn = 4, 21, 35, 128
+    spec = ConvSpec.dense(Cn)
+    x = torch.randn(B, H, W, Cn, device=dev)
+    res = torch.randn(B, H, W, Cn, device=dev)
+    msk = torch.randn(B, H, W, Cn, device=dev)
+    w = torch.randn(2, Cn, Cn, 9, device=dev) * 0.03
+    bias = torch.randn(2, Cn, device=dev)
+    cp = coutpad(Cn)
+
+    def run(wino, G, relu, use_res, use_mask, accumulate, wide):
+        w4 = w[:G].contiguous()
+        wp = _packed_weight(w4, spec, None, wino=wino)
+        Co = 2 * Cn if wide else Cn
+        out = torch.full((B, H, W, Co), 0.25, device=dev)
+        conv_raw([_src(x, 0, Cn, 0, None, 0, B)], wp, spec.kpad * 9 * cp, bias[:G].contiguous(), Cn,
+                 out.data_ptr() + (4 * Cn if wide else 0), H * W * Co, Co, B, H, W, Cn, 9, relu=relu,
+                 residual=_src(res, 0, Cn, 2, B, 0, B) if use_res else None, bpg=B // G, accumulate=accumulate,
+                 mask=_src(msk, 0, Cn, 0, None, 0, B) if use_mask else None, wino=wino)
+        return out
+
+    for G, relu, use_res, use_mask, accumulate, wide in [(1, False, False, False, False, False), (1, True, True, False, False, False),
+                                                         (2, False, False, True, False, False), (2, True, True, False, True, True),
+                                                         (1, False, True, True, True, False)]:
+        a, b = run(4, G, relu, use_res, use_mask, accumulate, wide), run(0, G, relu, use_res, use_mask, accumulate, wide)
+        assert rel_l2(a, b) < 1e-5, (G, relu, use_res, use_mask, accumulate, wide)
+        if wide:
+            assert torch.equal(a[..., :Cn], torch.full_like(a[..., :Cn], 0.25))      # the other channel window is untouched
+
+
+def test_winograd4_geometry_fuzz_vs_direct_kernel(force_wino4):
+    """Random image sizes (every tiles-per-row count from 5 up, strips that wrap 0-3 times, partial last workgroup tiles, more
+    workgroup tiles than CUs so that the persistent walk and the streams' hand-over between tiles run), against the direct
+    kernel; every operand ends at the end of its own allocation."""
+    dev = _gpu()
+    from bmc_hip.ops import _packed_weight, _src, conv_raw, coutpad, ConvSpec
+    g = torch.Generator().manual_seed(404)
+    Cn = 128
+    spec = ConvSpec.dense(Cn)
+    cp = coutpad(Cn)
+    w = (torch.randn(1, Cn, Cn, 9, generator=g) * 0.03).to(dev)
+    bias = torch.randn(1, Cn, generator=g).to(dev)
+    shapes = [(1, 4, 17), (1, 5, 20), (3, 7, 23), (2, 16, 24), (1, 33, 28), (2, 30, 61), (1, 64, 64), (5, 31, 56), (16, 64, 96), (2, 180, 240)]
+    for B, H, W in shapes + [(int(torch.randint(1, 4, (1,), generator=g)), int(torch.randint(1, 70, (1,), generator=g)),
+                              int(torch.randint(17, 90, (1,), generator=g))) for _ in range(12)]:
+        x = torch.randn(B, H, W, Cn, generator=g).to(dev)
+        outs = []
+        for wino in (4, 0):
+            wp = _packed_weight(w, spec, None, wino=wino)
+            out = torch.full((B, H, W, Cn), 7.0, device=dev)
+            conv_raw([_src(x, 0, Cn, 0, None, 0, B)], wp, spec.kpad * 9 * cp, bias, Cn, out.data_ptr(), H * W * Cn, Cn, B, H, W, Cn, 9,
+                     relu=False, bpg=B, wino=wino)
+            outs.append(out)
+        assert rel_l2(outs[0], outs[1]) < 1e-5, (B, H, W, rel_l2(outs[0], outs[1]))
+
+
+def test_exact_zero_rule_keeps_reference_relu_gates(force_wino4):
+    """Sparse event counts, zero biases, zero state: the input-fusion convolutions must give EXACTLY 0 where a pixel's
+    receptive field holds no event (the reference's relu'(0) = 0 gates the gradient there).  Under ops.exact_zero_inputs the
+    forward launch keeps F(2x2), whose outputs are combinations of products of their own 3x3 field only; outside the context
+    the same launch takes F(4x4) and leaves rounding residue there -- which is why the rule exists."""
+    dev = _gpu()
+    ops = force_wino4
+    from bmc_hip.ops import ConvSpec, View
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cn = 2, 40, 64, 128
+    x = torch.poisson(torch.full((B, H, W, Cn), 0.02), generator=g)
+    x = x * (torch.rand(B, H, W, 1, generator=g) < 0.15)                 # most pixels hold no event at all
+    w = (torch.randn(Cn, Cn, 3, 3, generator=g) * 0.05).to(dev)
+    xg = x.to(dev)
+    occupied = F.max_pool2d(x.abs().sum(-1, keepdim=True).permute(0, 3, 1, 2), 3, 1, 1).permute(0, 2, 3, 1) > 0
+    empty = (~occupied).expand(B, H, W, Cn).to(dev)
+    assert empty.float().mean() > 0.1
+    with ops.exact_zero_inputs():
+        assert ops.wino_ok(B, H, W, Cn, 9, fwd=True) == 2 and ops.wino_ok(B, H, W, Cn, 9) == 4
+        y_safe = ops.conv([View(xg)], w, None, ConvSpec.dense(Cn), relu=True)
+    y_f4 = ops.conv([View(xg)], w, None, ConvSpec.dense(Cn), relu=True)
+    assert torch.count_nonzero(y_safe[empty]) == 0
+    assert rel_l2(y_f4, y_safe) < 1e-5
+    print("F(4x4) residue on empty receptive fields: %d of %d outputs non-zero" % (torch.count_nonzero(y_f4[empty]), int(empty.sum())))

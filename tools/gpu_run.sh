@@ -1,0 +1,28 @@
+#!/bin/bash
+# One parameterised GPU-box script (replaces round 3's one-shot tools/r03_gpu*.sh): runs the steps named on the command line
+# from the repo root, every log under gpurun_out/<tag>_*.  usage: bash tools/gpu_run.sh <tag> <step> [<step> ...]
+#   steps:  t4 (tests/test_gpu_r4.py)  tall (all -m gpu tests)  time4 (isolated F(4x4) / F(2x2) / direct launch)
+#           bench (default bench line)  benchq (bench without side runs)  stats (rocprofv3 --kernel-trace --stats of benchq)
+#           pmc (the three PMC passes of tools/pmc_summary.py)
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
+TAG=$1; shift
+cd $R
+export TMPDIR=/tmp
+for step in "$@"; do
+  case $step in
+    t4)    timeout 900 python -m pytest tests/test_gpu_r4.py -x -q -m gpu -s > $O/${TAG}_t4.log 2>&1; tail -5 $O/${TAG}_t4.log ;;
+    tall)  timeout 3000 python -m pytest tests -x -q -m gpu > $O/${TAG}_tall.log 2>&1; tail -5 $O/${TAG}_tall.log ;;
+    time4) timeout 300 python tools/time_wino4.py > $O/${TAG}_time4.log 2>&1; cat $O/${TAG}_time4.log ;;
+    bench) timeout 1500 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; head -c 600 $O/${TAG}_bench.json ;;
+    benchq) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16x6 --also none > $O/${TAG}_benchq.json 2> $O/${TAG}_benchq.err; head -c 700 $O/${TAG}_benchq.json ;;
+    stats) cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-bf16x6 --also none > $O/${TAG}_stats.log 2>&1
+           find /tmp/prof_$TAG -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats.csv \; ; head -12 $O/${TAG}_kernel_stats.csv; cd $R ;;
+    pmc)   cd /tmp
+           for p in "sq:SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+             rocprofv3 --kernel-trace --pmc ${p#*:} -d /tmp/pmcw_$TAG/pmc_fp32_${p%%:*} -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-bf16x6 --also none > $O/${TAG}_pmc_${p%%:*}.log 2>&1
+           done
+           cd $R; python3 tools/pmc_summary.py /tmp/pmcw_$TAG $TAG > $O/${TAG}_pmc_summary.log 2>&1; cp /tmp/pmcw_$TAG/${TAG}_pmc_summary.json $O/ 2>/dev/null ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
