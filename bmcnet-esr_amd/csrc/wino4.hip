@@ -47,6 +47,17 @@
                            // 16 no V production, 32 no V fragment reads, 64 no barriers, 128 no output transform
 #endif
 
+#ifdef BMC_W4_STAMP      // diagnostic build (tools/ only): per-workgroup cycle stamps, read back with bmc_w4_read_stamps
+__device__ unsigned long long g_w4_stamp[1024][16];
+#define W4_STAMP(i) do { if (threadIdx.x == 0 && (i) < 14) g_w4_stamp[blockIdx.x][(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// per-wave stamps of workgroup 8 (an XCD-0 workgroup), first 24 chunks: [wave][chunk][k]
+__device__ unsigned long long g_w4_wstamp[8][24][8];
+#define W4_WSTAMP(chunk, k) do { if (blockIdx.x == 8 && (threadIdx.x & 63) == 0 && (chunk) < 24) g_w4_wstamp[threadIdx.x >> 6][(chunk)][(k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W4_STAMP(i) do { } while (0)
+#define W4_WSTAMP(chunk, k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int CK = BMC_CK;
@@ -74,6 +85,18 @@ __device__ __forceinline__ void uwait(f32x4& x, f32x4& y) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N));
 }
 
+// the same with the count given as a value that folds to a constant once the pair loop is unrolled
+__device__ __forceinline__ void uwait_n(int n, f32x4& x, f32x4& y) {
+    switch (n) {
+#define W4_CASE(N) case N: uwait<N>(x, y); break;
+        W4_CASE(4) W4_CASE(5) W4_CASE(6) W4_CASE(7) W4_CASE(8) W4_CASE(9) W4_CASE(10) W4_CASE(11) W4_CASE(12) W4_CASE(13) W4_CASE(14)
+        W4_CASE(15) W4_CASE(16) W4_CASE(17) W4_CASE(18) W4_CASE(19) W4_CASE(20) W4_CASE(21) W4_CASE(22) W4_CASE(23) W4_CASE(24)
+        W4_CASE(25) W4_CASE(26) W4_CASE(27) W4_CASE(28)
+#undef W4_CASE
+        default: uwait<0>(x, y); break;
+    }
+}
+
 struct W4Tile { int nt, wt, b; };
 
 // LOADER = false: waves 0-5 (producer of row xi = wave of the position grid); true: waves 6-7 (halo DMA)
@@ -81,7 +104,17 @@ template <bool LOADER>
 __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int wave, const int t_first, const int t_hi,
                                            const int t_stride) {
     constexpr int D = LOADER ? 12 : 6;        // positions of U in flight
-    constexpr int NB = PPW;                   // vector-memory operations of a halo burst
+    constexpr int XLAST = (PPW - 1) / 2;      // the pairs 0 .. XLAST of a chunk issue the halo pieces 2 pp, 2 pp + 1
+    static_assert(2 * (NPOS / 2 - XLAST - 1) >= PPW && XLAST + D / 2 + 1 < NPOS / 2, "table rebuild / landing fit behind the pieces");
+    // halo pieces issued behind the requests of the pairs pp - D / 2 .. pp - 1 (pair indices modulo the chunk)
+    auto xyounger = [](int pp) {
+        int n = 0;
+        for (int j = pp - D / 2; j < pp; ++j) {
+            const int jj = (j + NPOS / 2) % (NPOS / 2);
+            n += jj > XLAST ? 0 : (2 * jj + 1 < PPW ? 2 : 1);
+        }
+        return n;
+    };
     float* const Xb = lds;
     float* const Vb = lds + 2 * XBUFA;
     int* const xtab = reinterpret_cast<int*>(lds + 2 * XBUFA + 2 * VBUF);          // [NLW][PPW][64]
@@ -127,69 +160,106 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     W4Tile xl_it = decode(t_first);
     const float* sbase = nullptr;
     int x_stride4 = 0;                                // pixel stride of the current source in bytes
-    unsigned xzm = 0, xzm_landed = 0;                 // bit k: instruction k's quad is a pixel outside the image
-    auto build_table = [&]() {                        // once per tile: pixel index / channel quad / zero flag of every quad this wave copies
+    unsigned xzm = 0, xzm_next = 0, xzm_landed = 0;   // bit k: instruction k's quad is a pixel outside the image (table in use / being rebuilt / in flight)
+    bool xl_rebuild = false;                          // the stream has moved on to another tile: the table is rebuilt piece by piece
+    int tb_ty0 = 0, tb_tx0 = 0, tb_st1 = 0, tb_st2 = 0, tb_st3 = 0, tb_st4 = 0;
+    // once per tile: pixel index / channel quad / zero flag of every quad this wave copies
+    auto table_setup = [&]() {
         const int T0 = xl_it.wt * NT;
-        const int ty0 = T0 / a.tiles_x, tx0 = T0 - ty0 * a.tiles_x;
+        tb_ty0 = T0 / a.tiles_x; tb_tx0 = T0 - tb_ty0 * a.tiles_x;
         // segments g = 0..3: the tiles of tile row ty0 + g, n_g of them from tile column (g == 0 ? tx0 : 0), pixel slots
         // [st_g, st_g + 4 n_g + 2): neighbours in a row share two columns, every row break starts a fresh 6-column patch
-        int n = a.tiles_x - tx0; n = n < NT ? n : NT;
+        int n = a.tiles_x - tb_tx0; n = n < NT ? n : NT;
         int left = NT - n;
-        const int st1 = 4 * n + 2;
+        tb_st1 = 4 * n + 2;
         n = left < a.tiles_x ? left : a.tiles_x; left -= n;
-        const int st2 = st1 + (n > 0 ? 4 * n + 2 : 0);
+        tb_st2 = tb_st1 + (n > 0 ? 4 * n + 2 : 0);
         n = left < a.tiles_x ? left : a.tiles_x; left -= n;
-        const int st3 = st2 + (n > 0 ? 4 * n + 2 : 0);
+        tb_st3 = tb_st2 + (n > 0 ? 4 * n + 2 : 0);
         n = left < a.tiles_x ? left : a.tiles_x;
-        const int st4 = st3 + (n > 0 ? 4 * n + 2 : 0);
-        xzm = 0;
+        tb_st4 = tb_st3 + (n > 0 ? 4 * n + 2 : 0);
+        xzm_next = 0;
+    };
+    auto table_piece = [&](int k) __attribute__((always_inline)) {
         const int l = lane_now();
-#pragma unroll 1
-        for (int k = 0; k < PPW; ++k) {
-            const int Q = (wl * PPW + k) * 64 + l;
-            const int r = Q / (XROWF / 4), rem = Q - r * (XROWF / 4);
-            const int s = rem / 5, q = rem - 5 * s;
-            const int g = (s >= st1 ? 1 : 0) + (s >= st2 ? 1 : 0) + (s >= st3 ? 1 : 0);       // (slots >= st4 are not real)
-            const int x = 4 * (g == 0 ? tx0 : 0) - 1 + (s - (g == 0 ? 0 : g == 1 ? st1 : g == 2 ? st2 : st3));
-            const int y = 4 * (ty0 + g) - 1 + r;
-            const bool real = r < 6 && s < st4 && q < 4;
-            const bool inside = y >= 0 && y < a.H && x >= 0 && x < a.W;
-            const int yc = y < 0 ? 0 : (y < a.H ? y : a.H - 1), xc = x < 0 ? 0 : (x < a.W ? x : a.W - 1);
-            const bool zero = real && !inside;
-            xzm |= zero ? (1u << k) : 0u;
-            xtab[(wl * PPW + k) * 64 + l] = real ? ((yc * a.W + xc) << 2) | q : 0;
-        }
+        const int Q = (wl * PPW + k) * 64 + l;
+        const int r = Q / (XROWF / 4), rem = Q - r * (XROWF / 4);
+        const int s = rem / 5, q = rem - 5 * s;
+        const int g = (s >= tb_st1 ? 1 : 0) + (s >= tb_st2 ? 1 : 0) + (s >= tb_st3 ? 1 : 0);       // (slots >= st4 are not real)
+        const int x = 4 * (g == 0 ? tb_tx0 : 0) - 1 + (s - (g == 0 ? 0 : g == 1 ? tb_st1 : g == 2 ? tb_st2 : tb_st3));
+        const int y = 4 * (tb_ty0 + g) - 1 + r;
+        const bool real = r < 6 && s < tb_st4 && q < 4;
+        const bool inside = y >= 0 && y < a.H && x >= 0 && x < a.W;
+        const int yc = y < 0 ? 0 : (y < a.H ? y : a.H - 1), xc = x < 0 ? 0 : (x < a.W ? x : a.W - 1);
+        xzm_next |= (real && !inside) ? (1u << k) : 0u;
+        xtab[(wl * PPW + k) * 64 + l] = real ? ((yc * a.W + xc) << 2) | q : 0;
     };
     auto src_select = [&]() {
         const SrcDev S = tab[s_idx];
-        sbase = src_batch_ptr(S, xl_it.b);
-        snch = S.nch;
-        x_stride4 = S.pix_stride * 4;
+        const unsigned long long pv = reinterpret_cast<unsigned long long>(src_batch_ptr(S, xl_it.b));
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pv), hi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
+        sbase = reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+        snch = __builtin_amdgcn_readfirstlane(S.nch);
+        x_stride4 = __builtin_amdgcn_readfirstlane(S.pix_stride * 4);
     };
-    auto xl_setup = [&]() {
+    auto xl_setup = [&]() {                           // prologue: the whole table at once
         s_idx = 0; c_in = 0; xl_chunk = 0;
-        build_table();
+        table_setup();
+#pragma unroll 1
+        for (int k = 0; k < PPW; ++k) table_piece(k);
+        xzm = xzm_next;
         src_select();
     };
-    auto load_x = [&]() {                             // the halo strip of the stream's next chunk -> buffer xl_buf
-        const float* const base = sbase + c_in;
-        xzm_landed = xzm;
+    // piece k of the halo strip of the stream's chunk -> buffer xl_buf: uniform base in SGPRs + per-lane byte offset.  The 17
+    // offsets live in registers and change only with the tile or the source (pixel stride): recomputed from the table then,
+    // at the top of a chunk (read from LDS per piece, each piece paid an LDS round trip + address arithmetic in front of its
+    // DMA: ~400 cycles per piece, stamps)
+    unsigned xoff[PPW];
+    bool xl_newoff = true;
+    auto offsets_from_table = [&]() {
         const int l = lane_now();
 #pragma unroll
         for (int k = 0; k < PPW; ++k) {
             const int e = xtab[(wl * PPW + k) * 64 + l];
-            const unsigned off = (unsigned)(e >> 2) * (unsigned)x_stride4 + (unsigned)(e & 3) * 16u;
-            if (!(BMC_W4_ABL & 4)) dma16(base, off, xb_lds + (unsigned)((xl_buf * XBUFA + (wl * PPW + k) * 256) * 4));
+            xoff[k] = __umul24((unsigned)(e >> 2), (unsigned)x_stride4) + (unsigned)(e & 3) * 16u;
         }
+        xl_newoff = false;
+    };
+    auto load_x_piece = [&](int k) __attribute__((always_inline)) {
+        const unsigned la = xb_lds + (unsigned)((xl_buf * XBUFA + (wl * PPW + k) * 256) * 4);
+        if (!(BMC_W4_ABL & 4))
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(xoff[k]), "s"(sbase + c_in), "s"(la) : "memory");
+    };
+    auto load_x_begin = [&]() {
+        if (xl_rebuild) { xzm = xzm_next; xl_rebuild = false; }
+        if (xl_newoff) offsets_from_table();
+        xzm_landed = xzm;
+    };
+    auto load_x_advance = [&]() {                     // all pieces of the stream's chunk are issued: on to the next one
         xl_buf ^= 1;
         c_in += CK;
         if (++xl_chunk == nchunks) {
             xl_tile += t_stride;
             if (xl_tile < t_hi) xl_it = decode(xl_tile);      // (past the last tile: the same tile again -- valid addresses, nobody reads it)
-            xl_setup();
+            s_idx = 0; c_in = 0; xl_chunk = 0;
+            table_setup();
+            src_select();
+            xl_rebuild = true;
+            xl_newoff = true;
         } else if (c_in >= snch) {
             c_in = 0; ++s_idx;
             src_select();
+            xl_newoff = true;
+        }
+    };
+    auto load_x_all = [&]() {                         // prologue: a whole strip at once
+        load_x_begin();
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) load_x_piece(k);
+        load_x_advance();
+        if (xl_rebuild) {
+#pragma unroll 1
+            for (int k = 0; k < PPW; ++k) table_piece(k);
         }
     };
     auto zero_x = [&](int buf) {                      // after the burst has landed, before the barrier that publishes it
@@ -296,7 +366,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
 
     // One chunk: 18 pairs of positions.  ucur / unx: this wave's U blocks of this chunk and of the next one (positions that
     // the ring requests past 35); vb: this chunk's V; xbn / vbn: the producer's input and output (next chunk).
-    auto chunk = [&](const float* ucur, const float* unx, const float* vb, const float* xbn, float* vbn, const int gbuf)
+    auto chunk = [&](const float* ucur, const float* unx, const float* vb, const float* xbn, float* vbn, const int gbuf, const int gcx)
                      __attribute__((always_inline)) {
         f32x2p pd[4], ta, tb, tc, te;
         // the producer's timetable: half h of its item takes pairs PH0 + 8 h + (0..5: one patch column each, reads in front of
@@ -307,23 +377,40 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
             const int ph = pp >= PH0 + 8 ? 1 : 0, ps = pp - PH0 - 8 * ph;      // half, step within it (valid for PH0 <= pp < PH0 + 16)
             const bool pact = !LOADER && !(BMC_W4_ABL & 16) && pp >= PH0 && pp < PH0 + 16;
             const int p0 = 2 * pp, p1 = p0 + 1, s0 = p0 % D, s1 = p1 % D;
-            // U(p0), U(p1) have landed: younger are the D - 2 requests behind them and, on a loader wave, this chunk's halo
-            // burst (issued behind pair 0's requests U(D), U(D + 1)) while the fragments waited for are older than it:
-            // pairs 1 .. D / 2
-            if (LOADER && pp >= 1 && pp <= D / 2) uwait<D - 2 + NB>(ur[s0], ur[s1]); else uwait<D - 2>(ur[s0], ur[s1]);
-            if (LOADER && pp == D / 2 + 1) zero_x(gbuf);         // (the wait above was the first behind the burst: it has landed)
+            // U(p0), U(p1) have landed: younger are the D - 2 requests behind them and, on a loader wave, the halo pieces
+            // issued since (behind the requests of pairs pp - D / 2 .. pp - 1: xyounger)
+            if (LOADER) uwait_n(D - 2 + xyounger(pp), ur[s0], ur[s1]); else uwait<D - 2>(ur[s0], ur[s1]);
+            if (LOADER && pp == XLAST + D / 2 + 1) zero_x(gbuf);     // (the wait above was the first behind the strip's last piece: it has landed)
             __builtin_amdgcn_sched_barrier(0);
             if (pp < NPOS / 2 - 1) read_v(vb, pp + 1, vf[(pp + 1) & 1]);
             if (pact && ps < 6) prod_col(xbn, ph, ps, pd);
+            if (pp == 1) W4_WSTAMP(gcx, 1);
+            if (pp == 7) W4_WSTAMP(gcx, 2);
+            if (pp == 12) W4_WSTAMP(gcx, 3);
+            if (pp == NPOS / 2 - 1) W4_WSTAMP(gcx, 4);
             if (pp == NPOS / 2 - 1) {
                 // the chunk's barrier sits in front of its LAST pair: V of the next chunk is complete (lgkmcnt(0)), the halo
                 // two chunks ahead has landed and is patched; behind it the next chunk's first fragments are read under
                 // this pair's MFMAs (their own fragments are in registers since the previous pair)
                 if (BMC_W4_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else ring_publish();
                 read_v(vbn, 0, vf[0]);
+                W4_WSTAMP(gcx, 5);
             }
+            if (pp == 0) W4_WSTAMP(gcx, 0);
             __builtin_amdgcn_sched_barrier(0);
+#if defined(BMC_W4_EXP) && BMC_W4_EXP == 1      // experiment (ablation builds only): dependent MFMAs 4 apart instead of 2
+            if (pp & 1) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    acc[p0 - 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[(p0 - 2) % D][m], vf[0][0][m], acc[p0 - 2], 0, 0, 0);
+                    acc[p0 - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[(p0 - 1) % D][m], vf[0][1][m], acc[p0 - 1], 0, 0, 0);
+                    acc[p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[s0][m], vf[1][0][m], acc[p0], 0, 0, 0);
+                    acc[p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[s1][m], vf[1][1][m], acc[p1], 0, 0, 0);
+                }
+            }
+#else
             mfma8(acc[p0], acc[p1], ur[s0], ur[s1], vf[pp & 1]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             // the ring slots just consumed take positions p0 + D, p1 + D
             {
@@ -338,7 +425,19 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
                     else { uload<2048>(ur[s0], b, uvoff); uload<3072>(ur[s1], b, uvoff); }
                 }
             }
-            if (LOADER && pp == 0) load_x();          // (behind pair 0's requests: the burst is in front of everything pair D / 2 needs)
+            if (LOADER) {
+                // the halo strip two chunks ahead: two pieces behind each of the pairs 0 .. XLAST (the last one: one) -- spread
+                // out, a piece costs this wave ~100 cycles between its MFMAs; as one burst the 17 cost 3 000 - 6 800 cycles, and
+                // every weight request behind the burst waited for all of it (in-order completion): 7 400 cycles (stamps)
+                if (pp == 0) load_x_begin();
+                if (pp <= XLAST) { load_x_piece(2 * pp); if (2 * pp + 1 < PPW) load_x_piece(2 * pp + 1); }
+                if (pp == XLAST + 1) load_x_advance();
+                if (pp > XLAST && xl_rebuild) {       // a new tile: its table, two pieces per pair
+                    const int k = 2 * (pp - XLAST - 1);
+                    if (k < PPW) table_piece(k);
+                    if (k + 1 < PPW) table_piece(k + 1);
+                }
+            }
             if (pact) {
                 if (ps < 6) prod_fma(ps, pd);
                 if (ps == 6) prod_row_a(ta, tb, tc, te);
@@ -441,7 +540,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     const float* ublk = ublock(it0, 0);
     if (LOADER) {
         xl_setup();
-        load_x();                                     // chunk 0 -> buffer 0
+        load_x_all();                                 // chunk 0 -> buffer 0
     }
     // the first D positions of U
 #pragma unroll
@@ -453,7 +552,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     if (LOADER) {
         dma_wait<D>();                                // the first burst (older than the D requests) has landed
         zero_x(0);
-        load_x();                                     // chunk 1 -> buffer 1
+        load_x_all();                                 // chunk 1 -> buffer 1
     }
     __syncthreads();
     if (!LOADER) {
@@ -476,6 +575,8 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     __syncthreads();
     init_acc();
     read_v(Vb, 0, vf[0]);
+    W4_STAMP(1);
+    int stamp_i = 2;
 
     // ---------------------------------------------------------------- main loop
     // The streams never stop: past the workgroup's last tile the loaders and the producers work on that tile again (valid
@@ -489,10 +590,12 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
             if (c + 1 < nchunks) unx = ublk + UCH;
             else unx = ublock(decode(tile_n), 0);
             if (!LOADER && c == nchunks - 1) prod_setup(tile_n);         // the producer moves on to the next tile's first chunk
-            chunk(ublk, unx, Vb + (gc & 1) * VBUF, Xb + ((gc + 1) & 1) * XBUFA, Vb + ((gc + 1) & 1) * VBUF, gc & 1);
+            chunk(ublk, unx, Vb + (gc & 1) * VBUF, Xb + ((gc + 1) & 1) * XBUFA, Vb + ((gc + 1) & 1) * VBUF, gc & 1, gc);
             ublk = unx;
         }
+        W4_STAMP(stamp_i); ++stamp_i;
         epilogue(it);
+        W4_STAMP(stamp_i); ++stamp_i;
     }
     dma_wait<0>();
 }
@@ -501,6 +604,9 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const ConvK a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * XBUFA + 2 * VBUF + NLW * PPW * 64 + BMC_MAX_SRC * 8];
     SrcDev* const tab = reinterpret_cast<SrcDev*>(lds + 2 * XBUFA + 2 * VBUF + NLW * PPW * 64);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef BMC_W4_STAMP
+    if (tid == 0) { g_w4_stamp[blockIdx.x][0] = __builtin_amdgcn_s_memtime(); g_w4_stamp[blockIdx.x][14] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 #pragma unroll
     for (int i = 0; i < BMC_MAX_SRC; ++i)
         if (tid == i) tab[i] = a.src[i];
@@ -517,6 +623,9 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const ConvK a) {
     if (t_first >= t_hi) return;
     if (wave >= 8 - NLW) wino4_body<true>(a, lds, wave, t_first, t_hi, t_stride);
     else wino4_body<false>(a, lds, wave, t_first, t_hi, t_stride);
+#ifdef BMC_W4_STAMP
+    if (tid == 0) { g_w4_stamp[blockIdx.x][13] = __builtin_amdgcn_s_memtime(); g_w4_stamp[blockIdx.x][15] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // U = G g G^T (6x6 from 3x3, G rows (1/4 0 0) (-1/6 -1/6 -1/6) (-1/6 1/6 -1/6) (1/24 1/12 1/6) (1/24 -1/12 1/6) (0 0 1)), made in
@@ -586,6 +695,15 @@ int bmc_conv_wino4_launch(ConvK k, int cus, hipStream_t st) {
     hipLaunchKernelGGL(wino4_conv_kernel, grid, dim3(512), 0, st, k);
     return 0;
 }
+
+#ifdef BMC_W4_STAMP
+extern "C" int bmc_w4_read_stamps(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w4_stamp), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? 0 : -1;
+}
+extern "C" int bmc_w4_read_wstamps(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w4_wstamp), sizeof(unsigned long long) * 8 * 24 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int bmc_pack_weight_wino4(const float* w, const int* kmap, int G, int Cout, int Cin, int Kpad, int Coutpad,
                                      int transposed, int k0, int nk, float* out, bmc_stream_t s) {
