@@ -103,7 +103,10 @@ struct W4Tile { int nt, wt, b; };
 template <bool LOADER>
 __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int wave, const int t_first, const int t_hi,
                                            const int t_stride) {
-    constexpr int D = LOADER ? 12 : 6;        // positions of U in flight
+#ifndef BMC_W4_DP
+#define BMC_W4_DP 6
+#endif
+    constexpr int D = LOADER ? 12 : BMC_W4_DP;        // positions of U in flight
     constexpr int XLAST = (PPW - 1) / 2;      // the pairs 0 .. XLAST of a chunk issue the halo pieces 2 pp, 2 pp + 1
     static_assert(2 * (NPOS / 2 - XLAST - 1) >= PPW && XLAST + D / 2 + 1 < NPOS / 2, "table rebuild / landing fit behind the pieces");
     // halo pieces issued behind the requests of the pairs pp - D / 2 .. pp - 1 (pair indices modulo the chunk)
@@ -691,6 +694,10 @@ int bmc_conv_wino4_launch(ConvK k, int cus, hipStream_t st) {
     const long long ntiles = (long long)k.B * wpi * k.ntn;
     if (ntiles >= (1ll << 31)) { bmc_set_error("bmc_conv (winograd F(4x4)): too many tiles"); return -1; }
     k.ntiles = (int)ntiles;
+#ifdef BMC_W4_STAMP
+    static const int grid_cap = getenv("BMC_W4_GRID") ? atoi(getenv("BMC_W4_GRID")) : 0;      // (diagnostic builds: fewer workgroups than CUs)
+    if (grid_cap > 0 && grid_cap < cus) cus = grid_cap;
+#endif
     dim3 grid((unsigned)(ntiles < cus ? ntiles : cus));
     hipLaunchKernelGGL(wino4_conv_kernel, grid, dim3(512), 0, st, k);
     return 0;

@@ -15,7 +15,7 @@ for step in "$@"; do
     t4)    timeout 900 python -m pytest tests/test_gpu_r4.py -x -q -m gpu -s > $O/${TAG}_t4.log 2>&1; tail -5 $O/${TAG}_t4.log ;;
     tall)  timeout 3000 python -m pytest tests -x -q -m gpu > $O/${TAG}_tall.log 2>&1; tail -5 $O/${TAG}_tall.log ;;
     time4) timeout 300 python tools/time_wino4.py > $O/${TAG}_time4.log 2>&1; cat $O/${TAG}_time4.log ;;
-    abl4)  for n in 0 1 2 4 8 16 32 64 128 6 22 54 118 246 254 255; do
+    abl4)  for n in ${W4_ABLS:-0 2 4 8 16 32 64 128 6 22 54 118 246 254}; do
              lib=$R/bmcnet-esr_amd/csrc/libbmc_hip_w4abl$n.so; [ $n = 0 ] && lib=$R/bmcnet-esr_amd/csrc/libbmc_hip.so
              [ -f $lib ] && echo "abl $n: $(W4_ONLY=1 KB_ITERS=200 BMC_HIP_LIB=$lib timeout 120 python tools/time_wino4.py 2>&1 | grep 'F(4x4)' | tr '\n' ' ' | sed 's/algorithmic[^=]*=//g')"
            done > $O/${TAG}_abl4.log 2>&1; cat $O/${TAG}_abl4.log ;;

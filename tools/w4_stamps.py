@@ -30,10 +30,11 @@ rd = lib._lib.bmc_w4_read_stamps
 rd.argtypes = [C.c_void_p]
 host = np.zeros((1024, 16), dtype=np.uint64)
 assert rd(host.ctypes.data) == 0
-s = host[:256].astype(np.int64)
+NWG = int(os.environ.get('BMC_W4_GRID', 256))
+s = host[:NWG].astype(np.int64)
 t0 = s[:, 0].min()
 ntile = ((s[:, 2:13] > 0).sum(1)) // 2
-print("workgroups 256; tiles per workgroup: %s" % np.bincount(ntile))
+print("workgroups %d; tiles" % NWG if False else "workgroups; tiles per workgroup: %s" % np.bincount(ntile))
 print("start skew (cycles after the first workgroup's start): median %d, p90 %d, max %d" % tuple(np.percentile(s[:, 0] - t0, [50, 90, 100])))
 print("prologue: median %d cycles" % np.median(s[:, 1] - s[:, 0]))
 for i in range(int(ntile.max())):
