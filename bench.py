@@ -43,9 +43,9 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6           # 16 x the fp32 rate (v_mfma_f32_32x32x
 KERNEL_PEAK = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16": PEAK_BF16_MFMA_TFLOPS}
 KERNEL_NAME = {"fp32": "conv_kernel<9,128>", "bf16x6": "conv_bf_kernel<9,128,8,3>", "bf16": "conv_bf_kernel<9,128,8,1>"}
 PMC_KERNEL = {"fp32": "conv_kernel<9,128,8>", "bf16x6": "conv_bf_kernel<9,128,8,3>", "bf16": "conv_bf_kernel<9,128,8,1>"}
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
 DTYPE = {"fp32": "f32", "bf16x6": "f32 (3xbf16 split, 6 products)", "bf16": "bf16"}
-ARITH = {"fp32": "fp32 (native fp32 MFMA)", "bf16x6": "fp32-equivalent (3 bf16 planes, 6 products, fp32 accumulate)",
+ARITH = {"fp32": "fp32 (native fp32 MFMA; 3x3 convolutions through Winograd F(4x4,3x3) / F(2x2,3x3) transforms in fp32)", "bf16x6": "fp32-equivalent (3 bf16 planes, 6 products, fp32 accumulate)",
          "bf16": "bf16 operands, fp32 accumulate and storage"}
 SHAPES = {(180, 240): "NFS-shaped 180x240 (BASELINE configs[1] / [2])", (31, 56): "EventZoom 31x56 (BASELINE configs[3] shape)",
           (180, 190): "RGB 180x190 (BASELINE configs[4] per-GPU shape)", (45, 80): "NFS 45x80 (the reference's own LR size, config/train_nfs.yml)"}
@@ -78,6 +78,7 @@ def cpu_baseline(dev=None, budget_hw=(180, 240), threads=16):
     """CPU oracle (the PyTorch-CPU restatement of the reference path, oracle/bmc_oracle.py) timed on this host, the protocol
     of SURVEY 8(d) / BASELINE.md 4: 2 warm-up + 3 timed iterations, median, thread and core counts stated.
       (ii) one BMCNet window forward+backward, B=1, one 180x240 LR frame -> the headline `value` in frames per second;
+      (iii) `other_samples`: one window, and the full 8-window BPTT of train.py:202-237, at B=1 on the reference's own 45x80 frame;
       (i)  events_to_channels on one 180x240 LR frame (24 576 events) and one 720x960 HR frame (393 216 events), numpy
            restatement, one thread -- with the GPU scatter kernel's time for the same frames beside it.
     16 threads is the measured optimum of torch-CPU on the GPU box's host for this network (8: 1.08 s, 16: 0.67 s, 32: 1.08 s,
@@ -108,6 +109,28 @@ def cpu_baseline(dev=None, budget_hw=(180, 240), threads=16):
             p.grad = None
     t = _median(times[2:])
     frames = (H * W) / (180.0 * 240.0)
+    # (iii) the reference's own LR frame (45x80, config/train_nfs.yml): one window forward+backward, and the FULL training-loop
+    # body of train.py:202-237 -- 8 recurrent windows forward, summed MSE, one backward through all of them -- at B = 1.
+    # (At 180x240 the 8-window BPTT of the CPU path keeps ~62 GB of activations -- SURVEY Appendix A.11 -- and takes > 60 s per
+    # iteration: it is timed at 45x80, where it fits the bounded-sample budget; 1 warm-up + 2 timed iterations.)
+    h2, w2, L = 45, 80, 9
+    x2 = torch.poisson(torch.full((1, L, 2, h2, w2), 0.284))
+    g2 = torch.poisson(torch.full((1, L, 2, scale * h2, scale * w2), 0.284))
+    legs = {}
+    for tag, nwin, iters in (("one_window_45x80", 1, 4), ("bptt_8_windows_45x80", L - 1, 3)):
+        xs = [x2[:, i:i + 2].transpose(1, 2) for i in range(nwin)]
+        gts = [g2[:, i + 1] for i in range(nwin)]
+        ts = []
+        for it in range(iters):
+            t0 = time.perf_counter()
+            loss, _, _ = O.bptt_loss(params, xs, gts, n_c, scale)
+            loss.backward()
+            ts.append(time.perf_counter() - t0)
+            for p in seen.values():
+                p.grad = None
+        tm = _median(ts[1:])
+        legs[tag] = {"seconds_per_iteration": round(tm, 3), "LR_frames_per_s": round(nwin / tm, 3), "frame": "%dx%d" % (h2, w2),
+                     "windows": nwin, "B": 1, "iterations": "1 warm-up + %d timed (median)" % (iters - 1)}
     # (i) the event -> count scatter
     rng = np.random.default_rng(3407)
     ev = {}
@@ -138,15 +161,28 @@ def cpu_baseline(dev=None, budget_hw=(180, 240), threads=16):
             "sample": "oracle/bmc_oracle.py BMCNet(4,128,5) 1 window fwd+bwd, B=1, LR %dx%d (%.2f of a 180x240 frame), "
                       "2 warm-up + 3 timed (median %.2fs; all five: %s), %d torch threads" %
                       (H, W, frames, t, " ".join("%.2f" % v for v in times), torch.get_num_threads()),
+            "other_samples": legs,
             "events_to_channels": dict(ev, note="numpy restatement (oracle.events_to_channels_np), 1 thread, 2 warm-up + 3 timed "
                                                 "(median); gpu = bmc_events_to_channels, ONE frame per launch (the step batches 36 frames per launch)")}
 
 
-def dominant_kernel_roofline(step_fn, iso, math, shape_key):
-    """roofline block for the dominant kernel, conv_kernel<9,128> (3x3 implicit GEMM: forward + data gradients,
-    ~59 % of the step's algorithmic FLOPs).  One extra, untimed step runs with an event pair around every launch of
-    that kernel on its launch stream (torch's current stream); achieved = sum of the launches' algorithmic FLOPs /
-    sum of their durations, avg_launch_ms is directly comparable with rocprofv3 --stats' average for the kernel."""
+# Executed / algorithmic multiplies of a kernel kind (ops.py's profile names): the Winograd kernels do not execute the
+# multiplies the metric counts (F(4x4): 36 of 144 per 4x4 tile; F(2x2): 16 of 36 per 2x2 tile), the fused centre chain's
+# backward executes 5 of the 6 C^2 it is credited with.  `roofline.frac` is built on EXECUTED work: a utilisation, <= 1.
+EXECUTED = {"wino4_conv<9,128>": 36.0 / 144.0, "wino_conv<9,128>": 16.0 / 36.0, "wgrad_wino<9>": 16.0 / 36.0, "chain_kernel<bwd>": 5.0 / 6.0}
+KERNEL_LABEL = {"wino4_conv<9,128>": "wino4_conv_kernel [Winograd F(4x4,3x3) on the fp32 MFMA, csrc/wino4.hip]",
+                "wino_conv<9,128>": "wino2_conv_kernel [Winograd F(2x2,3x3) on the fp32 MFMA, csrc/wino.hip]",
+                "wgrad_wino<9>": "wino_wgrad_kernel [Winograd F(2x2,3x3) weight gradient, csrc/wino_wgrad.hip]"}
+PMC_NAME = {"wino4_conv<9,128>": "wino4_conv_kernel", "wino_conv<9,128>": "wino2_conv_kernel"}
+
+
+def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
+    """roofline block for the dominant kernel = the kernel kind with the largest share of the step's GPU time (round 4: the
+    F(4x4) Winograd 3x3 convolution, forward + data gradients).  One extra, untimed step runs with an event pair around every
+    launch on its launch stream (torch's current stream); per kind: algorithmic FLOPs / time (what the metric counts) and
+    EXECUTED FLOPs / time (what its matrix instructions sustain).  `achieved` / `frac` are the executed figures -- a
+    utilisation of the dense MFMA peak, never above 1; `achieved_algorithmic` / `frac_algorithmic` stand beside them.
+    avg_launch_ms is directly comparable with rocprofv3 --stats' average for the kernel."""
     from bmc_hip import ops
     ops.PROFILE = []
     step_fn()
@@ -156,44 +192,47 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key):
     for kind, flops, e0, e1 in rec:
         a = agg.setdefault(kind, [0, 0.0, 0.0])
         a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1)
-    # the dominant kernel of the fp32 step is the Winograd 3x3 kernel (csrc/wino.hip) when the frames are large enough for it
-    # (bmc_hip.ops.wino_ok), else the direct implicit-GEMM kernel
-    dom = "wino_conv<9,128>" if math == "fp32" and "wino_conv<9,128>" in agg else "conv_kernel<9,128>"
+    peak = KERNEL_PEAK[math]
+    total_ms = sum(v[2] for v in agg.values())
+
+    def row(kind):
+        n, fl, ms = agg[kind]
+        alg = fl / (ms * 1e-3) / 1e12 if fl else None
+        ex = alg * EXECUTED.get(kind, 1.0) if alg else None
+        return {"kernel": kind, "launches": n, "avg_launch_ms": round(ms / n, 4), "ms_per_step": round(ms, 2),
+                "share_of_profiled_kernel_time": round(ms / total_ms, 4),
+                "achieved_algorithmic_tflops": round(alg, 2) if alg else None, "frac_algorithmic": round(alg / peak, 4) if alg else None,
+                "executed_tflops": round(ex, 2) if ex else None, "frac": round(ex / peak, 4) if ex else None,
+                "executed_over_algorithmic": round(EXECUTED.get(kind, 1.0), 4)}
+
+    mfma_kinds = [k for k, v in agg.items() if v[1] > 0]
+    dom = max(mfma_kinds, key=lambda k: agg[k][2])
     n, fl, ms = agg[dom]
-    ach = fl / (ms * 1e-3) / 1e12
-    # HBM bytes per launch: from the committed rocprofv3 PMC passes over one bench step (the AVERAGE in-step launch of this
-    # kernel, FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py) -- never computed
-    # here, and attached ONLY when the summary was collected on this very workload (its `_workload` record): the bytes of an
-    # average launch depend on the frame size and the batch
+    d = row(dom)
+    # HBM bytes per launch and the PMC figures: from the committed rocprofv3 PMC passes over one bench step (the AVERAGE in-step
+    # launch of this kernel, FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py) --
+    # STATIC data, not measured in this run, attached ONLY when the summary was collected on this very workload and kernel
     traffic, pmc = None, None
     if os.path.exists(PMC_FILE):
         summ = json.load(open(PMC_FILE))
         if summ.get("_workload") == shape_key:
-            entry = summ.get(math, {}).get("wino2_conv_kernel" if dom.startswith("wino") else PMC_KERNEL[math])
+            entry = summ.get(math, {}).get(PMC_NAME.get(dom, PMC_KERNEL[math]))
             if entry:
                 traffic = entry.get("hbm_bytes_per_launch")
                 pmc = {k: entry[k] for k in ("mfma_busy_frac", "in_kernel_clock_GHz", "hbm_GBps", "lds_bank_conflict_frac") if k in entry}
-                pmc["source"] = "profiles/" + os.path.basename(PMC_FILE)
-    peak = KERNEL_PEAK[math]
-    out = {"bound": "mfma", "kernel": "%s (3x3 convolution fwd + dgrad, %d launches of one step)" %
-                                      ("wino2_conv_kernel [Winograd F(2x2,3x3) on the fp32 MFMA]" if dom.startswith("wino") else KERNEL_NAME[math], n),
-           "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-           "frac": round(ach / peak, 4), "traffic": traffic,
-           "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n, "launches_per_step": n,
+                pmc.update({"static": True, "source": "profiles/" + os.path.basename(PMC_FILE), "collected_at_commit": summ.get("_commit")})
+    out = {"bound": "mfma", "kernel": "%s (3x3 convolution fwd + dgrad, %d launches of one step)" % (KERNEL_LABEL.get(dom, KERNEL_NAME[math] if dom.startswith("conv_kernel<9") else dom), n),
+           "achieved": d["executed_tflops"], "peak": round(peak, 1), "unit": "TFLOP/s", "frac": d["frac"],
+           "achieved_algorithmic": d["achieved_algorithmic_tflops"], "frac_algorithmic": d["frac_algorithmic"],
+           "note": "achieved / frac: EXECUTED matrix FLOPs of the kernel (algorithmic x %.4f) over its in-situ time, against the dense "
+                   "fp32 MFMA peak -- a utilisation; the algorithmic rate (2 x 9 x Cin x Cout FLOP per pixel, what the metric counts) is "
+                   "achieved_algorithmic" % EXECUTED.get(dom, 1.0),
+           "traffic": traffic, "traffic_static": traffic is not None,
+           "avg_launch_ms": d["avg_launch_ms"], "flop_per_launch": fl / n, "launches_per_step": n,
            "isolated_2B_128to128": iso, "pmc": pmc,
-           "other_kernels": {k: {"launches": v[0], "achieved_tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2),
-                                 "avg_launch_ms": round(v[2] / v[0], 4)} for k, v in agg.items() if k != dom}}
-    ww = out["other_kernels"].get("wgrad_wino<9>")
-    if ww:      # the Winograd weight-gradient kernel (csrc/wino_wgrad.hip): algorithmic rate, and what its MFMAs execute (16/36 of it)
-        ww["executed_mfma_tflops"] = round(ww["achieved_tflops"] * 16.0 / 36.0, 2)
-        ww["executed_frac_of_peak"] = round(ww["achieved_tflops"] * 16.0 / 36.0 / peak, 4)
-    if dom.startswith("wino"):
-        # `achieved` / `frac` are ALGORITHMIC (2 x 9 x Cin x Cout FLOP per pixel, what the metric is defined on): the kernel
-        # executes 16 multiplies per 2x2 output tile and channel pair instead of 36, so the algorithmic rate may exceed the
-        # matrix peak; what its MFMAs actually sustain is stated beside it
-        out["executed_mfma"] = {"tflops": round(ach * 16.0 / 36.0, 2), "frac_of_peak": round(ach * 16.0 / 36.0 / peak, 4),
-                                "note": "Winograd F(2x2,3x3): executed multiplies = 16/36 of the algorithmic ones; "
-                                        "frac above is algorithmic / dense fp32-MFMA peak and may exceed 1"}
+           # every kernel kind with >= 4 % of the profiled kernel time, the same two rates each
+           "kernels": [row(k) for k in sorted(agg, key=lambda k: -agg[k][2]) if agg[k][2] >= 0.04 * total_ms],
+           "profiled_kernel_ms_per_step": round(total_ms, 1)}
     return out
 
 
@@ -217,7 +256,11 @@ def isolated_conv(dev, B, H, W, n_c, iters=30):
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * (2 * B * H * W) * n_c * (9 * n_c)
-    return {"avg_launch_ms": round(ms, 4), "achieved_tflops": round(flops / (ms * 1e-3) / 1e12, 2)}
+    wn = ops.wino_ok(2 * B, H, W, n_c, 9)
+    ex = {4: 36.0 / 144.0, 2: 16.0 / 36.0}.get(wn, 1.0)
+    return {"avg_launch_ms": round(ms, 4), "achieved_algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+            "executed_tflops": round(flops * ex / (ms * 1e-3) / 1e12, 2), "frac": round(flops * ex / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "kernel": {4: "wino4_conv_kernel", 2: "wino2_conv_kernel"}.get(wn, "conv_kernel<9,128>")}
 
 
 def workload_string(n_c, n_b, H, W, B, L, math, scale=4, dist_on=False, recompute=False, graph=False):
@@ -435,8 +478,8 @@ def main():
         frames_per_step = world * B * windows
         value = frames_per_step * args.steps / dt
         if step_flops:
-            roof["step_achieved_tflops_per_gpu"] = round(step_flops * args.steps / dt / 1e12, 2)
-            roof["step_frac_of_peak"] = round(step_flops * args.steps / dt / 1e12 / KERNEL_PEAK[args.math], 4)
+            roof["step_algorithmic_tflops_per_gpu"] = round(step_flops * args.steps / dt / 1e12, 2)
+            roof["step_frac_algorithmic"] = round(step_flops * args.steps / dt / 1e12 / KERNEL_PEAK[args.math], 4)
         out = {
             "metric": "LR-voxel-frames/sec x4 SR train step, %s, %s" % (shape_name(H, W), DTYPE[args.math]),
             "value": round(value, 3), "unit": "LR-voxel-frames/s", "n_gpus": world, "steps": args.steps,

@@ -41,7 +41,7 @@ for step in "$@"; do
            for p in "sq:SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
              rocprofv3 --kernel-trace --pmc ${p#*:} -d /tmp/pmcw_$TAG/pmc_fp32_${p%%:*} -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-bf16x6 --also none > $O/${TAG}_pmc_${p%%:*}.log 2>&1
            done
-           cd $R; python3 tools/pmc_summary.py /tmp/pmcw_$TAG $TAG > $O/${TAG}_pmc_summary.log 2>&1; cp /tmp/pmcw_$TAG/${TAG}_pmc_summary.json $O/ 2>/dev/null ;;
+           cd $R; python3 tools/pmc_summary.py /tmp/pmcw_$TAG ${PMC_TAG:-$TAG} > $O/${TAG}_pmc_summary.log 2>&1; cp /tmp/pmcw_$TAG/${PMC_TAG:-$TAG}_pmc_summary.json $O/ 2>/dev/null ;;
     *) echo "unknown step $step" ;;
   esac
 done

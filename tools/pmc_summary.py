@@ -51,6 +51,7 @@ def main(root, tag, steps=3):      # bench.py --steps 1 --warmup 1 runs 3 steps:
     out = {"_comment": __doc__.split("\n\n")[0] + " Counters: rocprofv3 --pmc, one pass per counter group; "
            "FETCH_SIZE doubled (gfx950), KiB -> bytes; clock = GRBM_GUI_ACTIVE / 8 / duration.",
            # the workload the passes ran (bench.py defaults): bench.py attaches these numbers to a run of THIS workload only
+           "_commit": os.environ.get("BMC_PMC_COMMIT"),
            "_workload": json.loads(os.environ.get("BMC_PMC_WORKLOAD", '{"H": 180, "W": 240, "B": 4, "L": 9, "n_c": 128, "n_b": 5}'))}
     for mode in ("fp32", "bf16x6"):
         rows = {}
