@@ -10,18 +10,7 @@
 // within 20 % of it (tools / DESIGN.md) -- far inside the 1e-4 budget.  Same semantics as conv.hip (bmc_conv): multi-source
 // NHWC operands, per-group weights, fused bias / residual / ReLU / ReLU-mask / accumulate epilogue.
 //
-// Machine mapping (v_mfma_f32_32x32x2_f32, D rows = output channels, D columns = WINOGRAD TILES):
-//   * workgroup = 4 waves = 8 x 16 output pixels = 4 x 8 tiles of 2 x 2; wave w = all 32 tiles x output channels [32w, 32w + 32)
-//     x all 16 transform positions = 16 accumulator tiles = 256 registers per lane: one workgroup per CU, one wave per SIMD;
-//   * lane (tile t = lane & 31, k-half h = lane >> 5) builds ITS tile's transformed input B^T d B in registers, straight from
-//     the raw (8 + 2) x (16 + 2) halo tile in LDS (two patch rows per transform row xi: 8 ds_read_b128, 32 x 4 adds): the
-//     MFMA's pixel operand never goes back to LDS, and both transforms are in-lane sums -- no shuffles;
-//   * the transformed weights U = G g G^T (packed once per weight version by bmc_pack_weight_wino, [chunk][xi][nu][co][16 ci],
-//     quads pre-swizzled) stream from L2 through a 3-stage LDS ring by LDS-DMA, one (chunk, xi) stage = 4 positions x 128 x 16
-//     floats = 32 KB, two stages ahead; wave w copies position nu = w of a stage (8 instructions of 1 KB);
-//   * one barrier per stage = per 32 MFMAs (2 048 matrix-pipe cycles) of every wave;
-//   * the epilogue applies A^T . A in place (24 adds per accumulator register), then finishes as conv.hip does: all loads,
-//     then all stores, 16 bytes per lane (a lane owns 4 consecutive channels of each of its tile's 4 pixels).
+// Machine mapping: wino2_conv_kernel below (8 waves of v_mfma_f32_16x16x4_f32, two per SIMD).
 // The bias rides in the accumulators of position (1, 1): A^T m A passes that position into all four outputs with weight 1.
 #include "bmc_common.h"
 #include "conv_k.h"
@@ -43,13 +32,11 @@ constexpr int RS = 20;                  // floats per halo pixel in LDS (16 + 4 
 constexpr int TH = 8, TW = 16;          // output pixels per workgroup tile
 constexpr int HHT = TH + 2, HWD = TW + 2;
 constexpr int XROW = (HWD * RS + 63) / 64 * 64;      // halo row stride (as conv.hip: rows start on a 256-byte boundary)
-constexpr int XBUF = HHT * XROW;
 constexpr int XBUFA = 4096;              // floats per X buffer as allocated: 16 DMA instructions x 64 lanes x 4 floats >= XBUF
 constexpr int BN = 128;                 // output channels per workgroup tile
 constexpr int WSTAGE = 4 * BN * CK;     // floats per weight stage: 4 positions (nu) x 128 rows x 16 channels
 constexpr int NWR = 3, DW = 2;          // weight ring: stages, stages ahead
 constexpr int VSTAGE = 4 * 32 * CK;     // floats of transformed input per stage: 4 positions (nu) x 32 tiles x 16 channels
-__device__ __attribute__((aligned(16))) const float g_zero4w[4] = {0.f, 0.f, 0.f, 0.f};
 
 // quad swizzle of 16-float LDS rows: dma_ring.h's table {0,2,3,1}[(row >> 2) & 3] -- conflict-free for the 16-row x 4-quad
 // fragment reads of the 16x16x4 MFMA (wino2 below) AND for the 32-row reads of the 32x32x2 MFMA (any bijection of the
@@ -74,399 +61,7 @@ __device__ __forceinline__ f32x4 sub4w(f32x4 a, f32x4 b) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
-// 8 KB linear copy global -> LDS by this wave: 8 LDS-DMA instructions of 1 KB (lane l moves bytes [16 l, 16 l + 16) of a
-// piece).  One asm block: the base pointer reaches its SGPR pair once; the instruction's immediate offset advances the
-// global AND the LDS address alike (LDS address = M0 + offset + 16 lane), so m0 is written once per 4 KB (the immediate
-// is 13 bits signed).  ~1.3 instructions per piece instead of ~9 (dma_ring.h's dma16 re-derives everything per piece) --
-// instructions that a wave alone on its SIMD issues INSTEAD of MFMAs.
-__device__ __forceinline__ void dma8k(const void* gbase, unsigned lane_off, unsigned lds_addr) {
-    const unsigned long long pv = reinterpret_cast<unsigned long long>(gbase);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pv), hi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
-    const unsigned long long b0 = ((unsigned long long)hi << 32) | lo, b1 = b0 + 4096;
-    const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr);
-    asm volatile(
-        "s_mov_b32 m0, %3\n\ts_nop 4\n\t"
-        "global_load_lds_dwordx4 %0, %1\n\t"
-        "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-        "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
-        "global_load_lds_dwordx4 %0, %1 offset:3072\n\t"
-        "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, %2\n\t"
-        "global_load_lds_dwordx4 %0, %2 offset:1024\n\t"
-        "global_load_lds_dwordx4 %0, %2 offset:2048\n\t"
-        "global_load_lds_dwordx4 %0, %2 offset:3072"
-        ::"v"(lane_off), "s"(b0), "s"(b1), "s"(la) : "memory", "scc");
-}
-
-__global__ __launch_bounds__(256, 1) void wino_conv_kernel(const ConvK a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * XBUFA + NWR * WSTAGE + 2 * VSTAGE + BMC_MAX_SRC * 8 + BN];
-    static_assert(XBUFA >= XBUF && HHT * 96 <= 16 * 64, "X buffer / DMA coverage");
-    float* const Xb = lds;
-    float* const Wb = lds + 2 * XBUFA;
-    float* const Vb = lds + 2 * XBUFA + NWR * WSTAGE;
-    SrcDev* const tab = reinterpret_cast<SrcDev*>(lds + 2 * XBUFA + NWR * WSTAGE + 2 * VSTAGE);
-    float* const init_lds = lds + 2 * XBUFA + NWR * WSTAGE + 2 * VSTAGE + BMC_MAX_SRC * 8;
-    const unsigned wb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Wb;
-    const bool bias_pre = a.bias != nullptr && a.batch_per_group >= a.B && a.ntn == 1;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < BMC_MAX_SRC; ++i)
-        if (tid == i) tab[i] = a.src[i];
-    if (tid < BN) init_lds[tid] = (bias_pre && tid < a.Cout) ? a.bias[tid] : 0.f;
-    __syncthreads();
-
-    // ---- persistent walk over tiles, XCD-contiguous ranges (as conv.hip)
-    const int ntiles = a.ntiles;
-    constexpr int NX_ = 8;
-    const bool xcd_map = (gridDim.x % NX_) == 0 && ntiles >= (int)gridDim.x;
-    const int xcd = blockIdx.x % NX_, xj = blockIdx.x / NX_, per_x = gridDim.x / NX_;
-    const int t_lo = xcd_map ? (int)((long long)ntiles * xcd / NX_) : 0;
-    const int t_hi = xcd_map ? (int)((long long)ntiles * (xcd + 1) / NX_) : ntiles;
-    const int t_first = xcd_map ? t_lo + xj : (int)blockIdx.x;
-    const int t_stride = xcd_map ? per_x : (int)gridDim.x;
-    const int my_tiles = t_first < t_hi ? (t_hi - t_first + t_stride - 1) / t_stride : 0;
-    if (my_tiles == 0) return;
-    const int nchunks = a.nchunks;
-    const int total_chunks = my_tiles * nchunks, total_stages = 4 * total_chunks;
-
-    struct TileIt { int nt, tx, ty, b; };
-    auto decode = [&](int t) {
-        TileIt it;
-        it.nt = t % a.ntn; t /= a.ntn;
-        it.tx = t % a.tiles_x; t /= a.tiles_x;
-        it.ty = t % a.tiles_y;
-        it.b = t / a.tiles_y;
-        return it;
-    };
-
-    // ---- X loader: the raw halo tile of one 16-channel chunk, straight into LDS by LDS-DMA with per-lane source addresses
-    // (no staging registers -- the 256 accumulators leave none to spare -- and no ds_write).  The LDS image is the padded
-    // layout the patch reads want ([halo row][18 pixels x 20 floats], rows 384 floats apart) seen as a linear stream of
-    // 16-byte quads: quad Q = halo row Q / 96, pixel (Q % 96) / 5, channel quad (Q % 96) % 5; lanes on a pad quad (fifth quad
-    // of a pixel, row tail) or on a pixel outside the image fetch 16 bytes of zeros.  16 instructions (1 KB each) cover a
-    // tile, 4 per wave.
-    constexpr int NXD = 4;
-    int xl_tile = t_first, xl_chunk = 0, s_idx = 0, c_in = 0, snch = 0;
-    TileIt xl_it = decode(t_first);
-    const float* sbase = nullptr;
-    unsigned xoff[NXD];               // byte offset from the source's batch pointer (+ channel chunk), valid lanes
-    unsigned xokm = 0;                // bit k: instruction k's lane reads the image
-    auto src_select = [&]() {         // (once per tile and source: the lane's halo coordinates are recomputed, not kept)
-        const SrcDev S = tab[s_idx];
-        sbase = src_batch_ptr(S, xl_it.b); snch = S.nch;
-        const int y0 = xl_it.ty * TH, x0 = xl_it.tx * TW;
-        xokm = 0;
-#pragma unroll
-        for (int k = 0; k < NXD; ++k) {
-            const int Q = (wave * NXD + k) * 64 + lane, hy = Q / 96, rq = Q - hy * 96, hx = rq / 5, q = rq - hx * 5;
-            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const bool ok = hy < HHT && hx < HWD && q < 4 && y >= 0 && y < a.H && x >= 0 && x < a.W;
-            xokm |= ok ? (1u << k) : 0u;
-            xoff[k] = ok ? (unsigned)(((y * a.W + x) * S.pix_stride + q * 4) * 4) : 0u;
-        }
-    };
-    auto xl_setup = [&]() {
-        s_idx = 0; c_in = 0; xl_chunk = 0;
-        src_select();
-    };
-    const unsigned xb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Xb;
-    auto load_x = [&](int buf) {      // the next chunk of the stream -> X buffer `buf`
-        const char* const base = reinterpret_cast<const char*>(sbase + c_in);
-#pragma unroll
-        for (int k = 0; k < NXD; ++k) {
-            const void* src = (xokm >> k) & 1 ? static_cast<const void*>(base + xoff[k]) : static_cast<const void*>(g_zero4w);
-            if (BMC_WINO_ABL & 4) src = g_zero4w;
-            dma16v(src, xb_lds + (unsigned)((buf * XBUFA + (wave * NXD + k) * 256) * 4));
-        }
-        c_in += CK;
-        if (++xl_chunk == nchunks) {
-            xl_tile += t_stride;
-            if (xl_tile < t_hi) { xl_it = decode(xl_tile); xl_setup(); }
-        } else if (c_in >= snch) {
-            c_in = 0; ++s_idx;
-            src_select();
-        }
-    };
-
-    // ---- W ring loader: stage (tile, chunk, xi) = 4 positions; wave w copies position nu = w (8 KB = 8 DMA instructions)
-    int wl_tile = t_first, wl_sub = 0, wl_cnt = 0;      // wl_sub: stage index inside the tile (4 * chunk + xi)
-    const float* wl_base = nullptr;
-    const long long wrow = (long long)a.Coutpad * CK;     // floats per position block of a stage in global memory
-    auto wl_setup = [&]() {
-        const TileIt it = decode(wl_tile);
-        const int grp = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
-        wl_base = static_cast<const float*>(a.w) + (long long)grp * a.w_group_stride + (long long)it.nt * BN * CK;
-        wl_sub = 0;
-    };
-    auto issue_w = [&]() {
-        const float* p = wl_base + ((long long)wl_sub * 4 + wave) * wrow;
-        const unsigned dst = wb_lds + (unsigned)(((wl_cnt % NWR) * WSTAGE + wave * BN * CK) * 4);
-        if (!(BMC_WINO_ABL & 2)) dma8k(p, (unsigned)(lane * 16), dst);
-        ++wl_cnt;
-        if (++wl_sub == 4 * nchunks) {
-            wl_tile += t_stride;
-            if (wl_tile < t_hi) wl_setup();
-        }
-    };
-
-    // ---- fragment addressing.  The input transform B^T d B is shared: every thread produces a slice of the NEXT stage's
-    // transformed tile V[nu][tile][16 ch] into LDS (thread = tile tid & 31, channel quad (tid >> 5) & 3, position pair
-    // nu in {2 pr, 2 pr + 1}, pr = tid >> 7: 8 patch reads, 24 adds, 2 stores) while it multiplies this stage's -- each of
-    // the four waves needs all 32 tiles as its MFMA column operand, and transforming them four times over cost 64 VALU
-    // instructions per 32 MFMAs on a SIMD that has nothing else to hide them behind (the fp32 MFMA and the VALU share the
-    // same issue slot: ablation).  V rows (a tile's 16 channels) are swizzled like the weight rows.
-    const int tr = li >> 3, tc = li & 7;
-    const int pq = 2 * (wave & 1) + lh, pr = wave >> 1;                     // producer role: channel quad, position pair
-    const int poff = (2 * tr) * XROW + (2 * tc) * RS + 4 * pq;              // + r * XROW + c * RS
-    const int vst = li * CK + ((pq ^ wswz(li)) * 4);                        // + nu * 32 * CK
-    const int wrow_l = 32 * wave + li;                                      // this lane's weight row inside a position block
-    int woff[2], voff[2];
-#pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
-        woff[kg] = wrow_l * CK + (((lh + 2 * kg) ^ wswz(wrow_l)) * 4);
-        voff[kg] = li * CK + (((lh + 2 * kg) ^ wswz(li)) * 4);
-    }
-
-    f32x16 acc[16];
-    auto init_acc = [&]() {
-#pragma unroll
-        for (int p = 0; p < 16; ++p)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {        // bias (or zeros) into position (1, 1): it reaches every output with weight 1
-            const f32x4 v = *reinterpret_cast<const f32x4*>(init_lds + 32 * wave + 4 * lh + 8 * rq);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[5][4 * rq + k] = v[k];
-        }
-    };
-
-    auto pin_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int p = 0; p < 16; ++p) asm volatile("" : "+a"(acc[p]));
-    };
-    auto pin_acc4 = [&]() __attribute__((always_inline)) {      // after the output transform only tiles 0-3 are live
-#pragma unroll
-        for (int p = 0; p < 4; ++p) asm volatile("" : "+a"(acc[p]));
-    };
-
-    // Producer half of a stage: this thread's slice of V for transform row xi of the chunk in xb -> vb.
-    // Rows of the 4x4 patch that B^T's row xi combines: (0, 2 : -) (1, 2 : +) (2, 1 : -) (1, 3 : -).
-    auto produce_load = [&](const float* xb, int xi, f32x4 (&da)[4], f32x4 (&db)[4]) __attribute__((always_inline)) {
-        const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (BMC_WINO_ABL & 16) { da[c] = f32x4{1.f, 2.f, 3.f, 4.f}; db[c] = f32x4{4.f, 3.f, 2.f, 1.f}; asm volatile("" : "+v"(da[c]), "+v"(db[c])); continue; }
-            da[c] = *reinterpret_cast<const f32x4*>(xb + poff + ra * XROW + c * RS);
-            db[c] = *reinterpret_cast<const f32x4*>(xb + poff + rb * XROW + c * RS);
-        }
-    };
-    auto produce_store = [&](float* vb, int xi, const f32x4 (&da)[4], const f32x4 (&db)[4]) __attribute__((always_inline)) {
-        f32x4 t[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) t[c] = xi == 1 ? da[c] + db[c] : da[c] - db[c];
-        f32x4 v0, v1;
-        if (pr == 0) { v0 = t[0] - t[2]; v1 = t[1] + t[2]; }       // nu = 0, 1   (wave-uniform branch)
-        else { v0 = t[2] - t[1]; v1 = t[1] - t[3]; }               // nu = 2, 3
-        *reinterpret_cast<f32x4*>(vb + (2 * pr) * 32 * CK + vst) = v0;
-        *reinterpret_cast<f32x4*>(vb + (2 * pr + 1) * 32 * CK + vst) = v1;
-    };
-
-    // One stage: 32 MFMAs of this stage's transformed tile (vb) against its 4 weight positions (wb), and the production
-    // of the next stage's V (xb_n, xi_n -> vb_n; xb_n == nullptr: there is none).  Written as "all fragment reads, then
-    // the arithmetic" -- with one wave per SIMD nothing hides an LDS round trip but this wave's own MFMAs, and left to
-    // itself the compiler issues each read right before its use behind lgkmcnt(0).  The scheduling barriers keep the order.
-    auto stage = [&](const float* vb, const float* wb, int xi, const float* xb_n, float* vb_n, int xi_n) __attribute__((always_inline)) {
-        f32x4 vf[2][4], bf[2][4], da[4], db[4];
-#pragma unroll
-        for (int kg = 0; kg < 2; ++kg)
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu) {
-                vf[kg][nu] = *reinterpret_cast<const f32x4*>(vb + nu * 32 * CK + voff[kg]);
-                if (BMC_WINO_ABL & 32) { bf[kg][nu] = f32x4{1.f, 2.f, 3.f, 4.f}; asm volatile("" : "+v"(bf[kg][nu])); continue; }
-                bf[kg][nu] = *reinterpret_cast<const f32x4*>(wb + nu * BN * CK + woff[kg]);
-            }
-        if (xb_n) produce_load(xb_n, xi_n, da, db);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu) {
-                f32x16& d = acc[4 * xi + nu];
-                if (BMC_WINO_ABL & 1) { d[0] += bf[kg][nu][0] * vf[kg][nu][0] + bf[kg][nu][3] * vf[kg][nu][3]; continue; }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[kg][nu][j], vf[kg][nu][j], d, 0, 0, 0);
-            }
-            if (kg == 0 && xb_n) produce_store(vb_n, xi_n, da, db);     // under the second k-group's MFMAs
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // ---- epilogue: Y = A^T M A in place, then bias / residual / ReLU / mask / accumulate and the stores
-    auto epilogue = [&](const TileIt& it) __attribute__((always_inline)) {
-        pin_acc();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (BMC_WINO_ABL & 128) break;
-            float y[4];
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {     // output row a = h2: t_a[nu]
-                float ta[4];
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu)
-                    ta[nu] = h2 == 0 ? (acc[nu][r] + acc[4 + nu][r]) + acc[8 + nu][r] : (acc[4 + nu][r] - acc[8 + nu][r]) - acc[12 + nu][r];
-                y[2 * h2] = (ta[0] + ta[1]) + ta[2];
-                y[2 * h2 + 1] = (ta[1] - ta[2]) - ta[3];
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) acc[p][r] = y[p];
-            // one register column at a time: the 16 accumulator tiles are pinned to the accumulator half of the register file
-            // between columns (left alone, the compiler copies all 256 of them into the other half at once and spills)
-            pin_acc();
-        }
-        const int g = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
-        const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
-        float* const outb = a.out + (long long)it.b * a.out_batch_stride;
-        const float* const resb = a.residual.ptr ? src_batch_ptr(a.residual, it.b) : nullptr;
-        const float* const maskb = a.mask.ptr ? src_batch_ptr(a.mask, it.b) : nullptr;
-        const int co0 = it.nt * BN + 32 * wave + 4 * lh;         // + 8 rq
-        bool pok[4];
-        int pix[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int y = it.ty * TH + 2 * tr + (p >> 1), x = it.tx * TW + 2 * tc + (p & 1);
-            pok[p] = y < a.H && x < a.W;
-            pix[p] = y * a.W + x;
-        }
-        const bool simple = !resb && !maskb && !a.accumulate && (bias_pre || !biasg);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            if (simple) break;
-#pragma unroll
-            for (int hq = 0; hq < 2; ++hq) {        // two channel quads at a time: the register file is full of accumulators
-                f32x4 v[2];
-                bool ok[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int rq = 2 * hq + i;
-                    ok[i] = pok[p] && co0 + 8 * rq < a.Cout;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[i][k] = acc[p][4 * rq + k];
-                }
-                auto fetch = [&](const float* base, int off, f32x4 (&d)[2], float fill) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        d[i] = f32x4{fill, fill, fill, fill};
-                        if (ok[i]) d[i] = ldg16(base + off + co0 + 8 * (2 * hq + i));
-                    }
-                };
-                if (biasg && !bias_pre) {
-                    f32x4 d[2];
-                    fetch(biasg, 0, d, 0.f);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) v[i] += d[i];
-                }
-                if (resb) {
-                    f32x4 d[2];
-                    fetch(resb, pix[p] * a.residual.pix_stride, d, 0.f);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) v[i] += d[i];
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[i][k] = fmaxf(v[i][k], 0.f);
-                }
-                if (maskb) {
-                    f32x4 d[2];
-                    fetch(maskb, pix[p] * a.mask.pix_stride, d, 1.f);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[i][k] = d[i][k] > 0.f ? v[i][k] : 0.f;
-                }
-                if (a.accumulate) {
-                    f32x4 d[2];
-                    fetch(outb, pix[p] * a.out_pix_stride, d, 0.f);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) v[i] += d[i];
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[p][4 * (2 * hq + i) + k] = v[i][k];
-                pin_acc4();
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int co = co0 + 8 * rq;
-                if ((BMC_WINO_ABL & 8) && acc[p][4 * rq] != 12345.678f) continue;
-                if (pok[p] && co < a.Cout) {
-                    f32x4 v;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = acc[p][4 * rq + k];
-                    if (simple && a.relu) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-                    }
-                    *reinterpret_cast<f32x4*>(outb + pix[p] * a.out_pix_stride + co) = v;
-                }
-            }
-        init_acc();
-    };
-
-    // ---- prologue: first halo tile, first DW weight stages
-    xl_setup();
-    wl_setup();
-    load_x(0);
-    for (int k = 0; k < DW && wl_cnt < total_stages; ++k) issue_w();
-    dma_wait<0>();
-    __syncthreads();
-    {       // V of the very first stage
-        f32x4 da[4], db[4];
-        produce_load(Xb, 0, da, db);
-        produce_store(Vb, 0, da, db);
-    }
-    __syncthreads();
-    init_acc();
-
-    int gs = 0, gc = 0;           // global stage / chunk counters of this workgroup
-    for (int tile = t_first; tile < t_hi; tile += t_stride) {
-        for (int c = 0; c < nchunks; ++c, ++gc) {
-            const float* const xb = Xb + (gc & 1) * XBUFA;
-            const bool more_x = gc + 1 < total_chunks;
-#pragma unroll
-            for (int xi = 0; xi < 4; ++xi, ++gs) {
-                // stage gs + DW -> the slot stage gs - 1 was read from (every wave is past the barrier that ended it)
-                const bool issued = wl_cnt < total_stages;
-                if (issued) issue_w();
-                // the next chunk's halo -> the X buffer chunk gc - 1 was read from: three more stages to land from HBM
-                if (xi == 0 && more_x) load_x((gc + 1) & 1);
-                // the next stage's V comes from this chunk's halo, or (xi == 3) from the next chunk's: landed and published by the
-                // waits and barriers of stages xi = 2 / 3 of this chunk
-                const bool has_next = gs + 1 < total_stages;
-                const float* const xb_n = !has_next ? nullptr : (xi == 3 ? Xb + ((gc + 1) & 1) * XBUFA : xb);
-                stage(Vb + (gs & 1) * VSTAGE, Wb + (gs % NWR) * WSTAGE, xi, xb_n, Vb + ((gs + 1) & 1) * VSTAGE, (xi + 1) & 3);
-                // stage gs + 1 must have landed before the barrier publishes it: everything but what was issued after it
-                // (this stage's 8 DMA instructions, and at xi = 0 / 1 the 4 halo instructions issued behind stage gs + 1's
-                // DMA); at xi = 2 / 3 the halo is older than stage gs + 1 and lands with it, in time for the next chunk
-                if (!issued) dma_wait<0>();
-                else if (xi <= 1 && more_x) dma_wait<8 + NXD>();
-                else dma_wait<8>();
-                if (BMC_WINO_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else ring_publish();
-            }
-        }
-        epilogue(decode(tile));
-    }
-}
-
-// 4 KB linear copy global -> LDS by this wave (4 LDS-DMA instructions; see dma8k)
+// 4 KB linear copy global -> LDS by this wave (4 LDS-DMA instructions, one asm block: the base pointer reaches its SGPR pair once, the instruction's immediate offset advances the global AND the LDS address alike)
 __device__ __forceinline__ void dma4k(const void* gbase, unsigned lane_off, unsigned lds_addr) {
     const unsigned long long pv = reinterpret_cast<unsigned long long>(gbase);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pv), hi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
@@ -481,9 +76,9 @@ __device__ __forceinline__ void dma4k(const void* gbase, unsigned lane_off, unsi
         ::"v"(lane_off), "s"(b0), "s"(la) : "memory");
 }
 
-// ---- second machine mapping of the same algorithm: TWO waves per SIMD.
-// The first kernel above keeps all 16 transform positions of 32 tiles x 32 channels in one wave (256 accumulator registers):
-// one wave per SIMD, and every instruction that is not an MFMA -- fragment reads, DMA issue, waits, barriers, the output
+// ---- machine mapping: TWO waves per SIMD.
+// Round 3's first kernel (removed in round 4) kept all 16 transform positions of 32 tiles x 32 channels in one wave (256 accumulator
+// registers): one wave per SIMD, and every instruction that is not an MFMA -- fragment reads, DMA issue, waits, barriers, the output
 // transform -- is time the matrix pipe idles (ablation: MFMAs alone 0.39 ms of the kernel's 0.60).  Here a workgroup has 8
 // waves of v_mfma_f32_16x16x4_f32: wave w = output channels [16 w, 16 w + 16) x all 32 tiles (two 16-tile column blocks) x
 // all 16 positions = 32 accumulator quads = 128 registers, so two waves share a SIMD and cover each other's stalls.
@@ -983,11 +578,17 @@ int bmc_conv_wino_launch(ConvK k, int cus, hipStream_t st) {
     const long long ntiles = (long long)k.B * k.tiles_x * k.tiles_y * k.ntn;
     if (ntiles >= (1ll << 31)) { bmc_set_error("bmc_conv (winograd): too many tiles"); return -1; }
     k.ntiles = (int)ntiles;
-    // one workgroup per CU either way (148 KB of LDS): 4 waves x 256 accumulators, or 8 waves x 128 (BMC_WINO_V=1 / 2: A/B runs)
-    static const int version = getenv("BMC_WINO_V") ? atoi(getenv("BMC_WINO_V")) : 2;
+    // one workgroup per CU (148 KB of LDS), 8 waves x 128 accumulators.  (Round 3's first mapping -- 4 waves x 256 accumulators
+    // on v_mfma_f32_32x32x2_f32, one wave per SIMD, 0.59 ms against this kernel's 0.45 -- was removed in round 4: git history.)
+    // 32-bit per-lane DMA offsets: the launch must keep H * W * pix_stride * 4 below 2^31
+    long long max_stride = 0;
+    for (int i = 0; i < k.nsrc; ++i) max_stride = k.src[i].pix_stride > max_stride ? k.src[i].pix_stride : max_stride;
+    if ((long long)k.H * k.W * max_stride * 4 >= (1ll << 31)) {
+        bmc_set_error("bmc_conv (winograd): image too large for 32-bit offsets (H*W*pix_stride*4 must stay below 2^31)");
+        return -1;
+    }
     dim3 grid((unsigned)(ntiles < cus ? ntiles : cus));
-    if (version == 1) hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL(wino2_conv_kernel, grid, dim3(512), 0, st, k);
+    hipLaunchKernelGGL(wino2_conv_kernel, grid, dim3(512), 0, st, k);
     return 0;
 }
 

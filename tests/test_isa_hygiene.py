@@ -18,7 +18,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "bmcnet-esr_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
-FILES = ["conv", "conv_bf", "pgemm", "pgemm_bf", "chain", "conv1", "conv1p", "wino", "wino_wgrad"]
+FILES = ["conv", "conv_bf", "pgemm", "pgemm_bf", "chain", "conv1", "conv1p", "wino", "wino4", "wino_wgrad"]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 
@@ -30,13 +30,14 @@ def _kernels(path):
         m = re.match(r"^(_Z\w+):", ln)
         if m:
             cur = m.group(1)
-            body = out[cur] = {"flat": 0, "m0": 0, "scratch_in_loop": 0}
+            body = out[cur] = {"flat": 0, "m0": 0, "scratch_in_loop": 0, "max_mfma_per_block": 0, "_mfma": 0}
             in_asm = in_loop = False
             continue
         if body is None:
             continue
         if re.match(r"^\.LBB\d+_\d+:", ln):            # the compiler annotates the blocks of a loop ("in Loop: Header=..." / "Loop Header")
             in_loop = "Loop" in ln
+            body["_mfma"] = 0
         elif ln.lstrip().startswith(";") and "Loop" in ln and ("Header" in ln):
             in_loop = True
         if in_loop and re.search(r"\bscratch_(load|store)", ln.split(";")[0]):
@@ -46,6 +47,9 @@ def _kernels(path):
         elif "#ASMEND" in ln:
             in_asm = False
         code = ln.split(";")[0]
+        if "v_mfma" in code:
+            body["_mfma"] += 1
+            body["max_mfma_per_block"] = max(body["max_mfma_per_block"], body["_mfma"])
         if re.search(r"\bflat_(load|store|atomic)", code):
             body["flat"] += 1
         if not in_asm and re.search(r"\bm0\b", code):
@@ -118,7 +122,7 @@ def test_m0_only_inside_handwritten_asm(isa):
     ("conv1_kernelILi8E", 2),
     ("conv_bf_kernelILi9ELi128ELi8ELi3E", 2), ("pgemm_bf9x3_kernel", 3),
     ("wino2_conv_kernel", 2),                   # 8 waves x (128 accumulators + <= 128 others): two waves per SIMD is the point of it
-    ("wino_conv_kernel", 1),                    # 4 waves x 256 accumulators
+    ("wino4_conv_kernel", 2),                   # 8 waves x (144 accumulators + <= 112 others), weights streamed into registers
     ("wino_wgrad_kernel", 2),                   # 8 waves x (128 accumulators + <= 128 others)
     ("conv1p_kernelILi8ELi1E", 4),              # K = 128: two 8-wave workgroups per CU
     ("conv1p_kernelILi16ELi1E", 2),             # K = 256: 64 weight registers, one workgroup per CU
@@ -129,3 +133,14 @@ def test_occupancy_budgets(isa, frag, min_occ):
     for n, k in hits:
         assert k["Occupancy"] >= min_occ, (n, k)
         assert k["ScratchSize"] <= 8 or "wino_wgrad" in n, (n, k)
+
+
+def test_wino4_pair_loop_is_expanded_at_compile_time(isa):
+    """The 18 pairs of a chunk (144 MFMAs per wave) must be straight-line code: as a run-time loop the accumulators are indexed
+    dynamically and live in scratch memory (seen in a round-4 experiment: `#pragma unroll` is a request, and the kernel silently
+    became 20 % slower).  The producer variant's chunk is one basic block."""
+    hits = [(n, k) for _, n, k in _all(isa) if "wino4_conv_kernel" in n]
+    assert hits
+    for n, k in hits:
+        assert k["max_mfma_per_block"] == 144, (n, k["max_mfma_per_block"])
+        assert k["ScratchSize"] == 0 and k["scratch_in_loop"] == 0, (n, k)

@@ -8,7 +8,7 @@ import sys
 lines = open(sys.argv[1]).read().split("\n")
 name = sys.argv[2]
 start = next(i for i, l in enumerate(lines) if re.match(r"^\S*%s\S*:" % re.escape(name), l))
-end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))      # (a kernel may hold several s_endpgm)
 blk, order, stats = "entry", ["entry"], {"entry": dict(n=0, mfma=0, scratch=0, lane=0, bar=0, gload=0, vm0=0, line=start)}
 for i in range(start + 1, end + 1):
     l = lines[i].strip()
