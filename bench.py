@@ -457,6 +457,18 @@ def main():
 
     dt, loss = timed(wl.step, args.warmup, args.steps, use_dist, dev)
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2**30
+    lockstep = None
+    if use_dist:
+        # the ranks must be in lock step: identical parameters on every rank after the timed steps (a rank that missed an
+        # all-reduce, or reduced a stale bucket, shows up here and FAILS the run instead of producing a number)
+        with torch.no_grad():
+            ck = torch.stack([torch.cat([p.detach().double().reshape(-1) for p in wl.model.parameters()]).sum(),
+                              torch.cat([p.detach().double().abs().reshape(-1) for p in wl.model.parameters()]).sum()])
+        allck = [torch.zeros_like(ck) for _ in range(dist.get_world_size())]
+        dist.all_gather(allck, ck)
+        lockstep = all(torch.equal(allck[0], c) for c in allck)
+        if not lockstep:
+            raise SystemExit("bench.py: parameters differ between ranks after %d steps: %s" % (args.steps + args.warmup, [c.tolist() for c in allck]))
 
     # the instrumented extra step contains the gradient all-reduce: every rank has to take part in it
     iso = isolated_conv(dev, B, H, W, n_c) if rank == 0 else None
@@ -488,6 +500,7 @@ def main():
             "config": {"workload": workload_string(n_c, n_b, H, W, B, L, args.math, dist_on=use_dist, recompute=args.recompute, graph=args.graph),
                        "global_batch": world * B, "frames_per_step": frames_per_step,
                        "parallelism": "dp%d" % world, "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                       "ranks_in_lock_step": lockstep,
                        "peak_mem_GiB": round(peak_mem, 1),
                        "final_loss": round(float(loss), 6)},
             "roofline": roof,

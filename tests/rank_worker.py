@@ -19,7 +19,7 @@ sys.path[:0] = [os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "bmcn
 
 def problem(dev):
     import torch
-    scale, n_c, n_b, B, L, H, W = 4, 16, 1, 4, 3, 12, 20
+    scale, n_c, n_b, B, L, H, W = 4, 16, 1, int(os.environ.get("BMC_RANK_TEST_B", 4)), 3, 12, 20
     from models.BMCNet import BMCNet
     torch.manual_seed(6)
     m = BMCNet(scale, n_c, n_b).to(dev)

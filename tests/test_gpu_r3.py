@@ -25,12 +25,12 @@ def _free_port():
     return port
 
 
-def _run_ranks(tmp_path, tag, world, backend, devices, accum):
+def _run_ranks(tmp_path, tag, world, backend, devices, accum, batch=4):
     port = _free_port()
     procs, outs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   BMC_ACCUM_GRADS=accum, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   BMC_ACCUM_GRADS=accum, HSA_ENABLE_IPC_MODE_LEGACY="0", BMC_RANK_TEST_B=str(batch))
         out = str(tmp_path / ("%s_rank%d.npz" % (tag, r)))
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "rank_worker.py"), out, backend, str(devices[r])],
@@ -86,6 +86,28 @@ def test_two_ranks_on_one_gpu_hip_step_matches_full_batch(tmp_path, accum):
         assert int(res[0]["hook_launches"]) >= max(1, int(res[0]["nbuckets"]) - 2)
     else:
         assert int(res[0]["hook_launches"]) <= 1
+
+
+@pytest.mark.parametrize("world,accum", [(4, "1"), (4, "0"), (8, "1")])
+def test_four_and_eight_ranks_on_one_gpu_hip_step_matches_full_batch(tmp_path, world, accum):
+    """The same at world = 4 (both gradient routes) and world = 8 (the route the bench uses): 4 / 8 fresh processes on the one
+    GPU, gloo transport, 8 sequences sharded 2 / 1 per rank -- the world sizes of the 1 / 2 / 4 / 8-GPU scaling runs, which no
+    8-GPU node has been available to execute."""
+    dev = _gpu()
+    os.environ["BMC_RANK_TEST_B"] = "8"
+    try:
+        res = _run_ranks(tmp_path, "gloo%d_%s" % (world, accum), world, "gloo", [0] * world, accum, batch=8)
+        loss, grads = _full_batch_reference(dev)
+    finally:
+        os.environ.pop("BMC_RANK_TEST_B", None)
+    assert abs(sum(float(r["loss"]) for r in res) / world - loss) < 1e-5 * abs(loss)
+    worst = max(rel_l2(r["g%03d" % i], g) for r in res for i, g in enumerate(grads))
+    print("%d ranks / 1 GPU, BMC_ACCUM_GRADS=%s: worst gradient rel-L2 vs full batch %.2e, buckets %d, launched from hooks %d"
+          % (world, accum, worst, int(res[0]["nbuckets"]), int(res[0]["hook_launches"])))
+    assert worst < 1e-4
+    for r in res[1:]:
+        for i in range(len(grads)):
+            assert np.array_equal(res[0]["g%03d" % i], r["g%03d" % i])
 
 
 def test_two_ranks_rccl_hip_step_matches_full_batch(tmp_path):
