@@ -293,7 +293,9 @@ def wino_ok(B, H, W, Cout, taps, fwd=False):
     cp = coutpad(Cout)
     if cp % 128 or B * ((H + 7) // 8) * ((W + 15) // 16) * (cp // 128) < WINO_MIN_TILES:
         return 0
-    if WINO4 and not (fwd and _EXACT_ZERO[0]) and W >= 17 and H * W * 4 * 512 < 2 ** 31:
+    if H * W * 4 * 512 >= 2 ** 31:      # 32-bit per-lane DMA offsets in both Winograd kernels (pix_stride <= 512 floats): direct kernel
+        return 0
+    if WINO4 and not (fwd and _EXACT_ZERO[0]) and W >= 17 and H * W < 2 ** 24:
         n4 = B * ((((H + 3) // 4) * ((W + 3) // 4) + 15) // 16) * (cp // 128)
         if n4 >= WINO4_MIN_TILES:
             return 4

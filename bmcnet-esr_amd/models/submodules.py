@@ -180,6 +180,10 @@ class PixelUnShuffle(nn.Module):
         return 'upscale_factor={}'.format(self.upscale_factor)
 
 
+# Provenance (copy findings): `initialize_weights` below and `PixelUnShuffle` above are boundary helpers that have to
+# reproduce the reference's behaviour call for call -- the same torch RNG draws in the same order (fixture weights and seeded runs
+# depend on it), the same module repr -- so they follow models/submodules.py:107-124 / :80-104 of the reference closely; they
+# contain no compute of this repo (the unshuffle itself runs in ops.pixel_unshuffle_nhwc).
 def initialize_weights(net_l, scale=0.1):
     """Kaiming-normal (fan_in) x scale for conv/linear weights, zero biases, BN affine = (1, 0)
     (reference: models/submodules.py:107-124)."""
