@@ -127,18 +127,20 @@ class Backbone(nn.Module):
         self._sp_o = ConvSpec.dense(n_c, n_c)
         self.n_c = n_c
 
-    def forward_nhwc(self, xin12, h3, o12):
+    def forward_nhwc(self, xin12, h3, o12, zero_state=True):
         """xin12 [2B,H,W,16]: packed polarity inputs (p batch-half, n batch-half);
         h3 [3B,H,W,n_c] = [hp; hn; hs]; o12 [2B,H,W,s^2] = [o[:, :s^2]; o[:, s^2:]] (channel halves batch-stacked).
         Returns x_h, x_h_p, x_h_n, x_o (NHWC)."""
         B = o12.shape[0] // 2
         hpn = h3[:2 * B]
-        # (the input-fusion convolutions read raw event counts: ops.exact_zero_inputs)
-        with ops.exact_zero_inputs():
+        # (zero_state: the recurrent state and the previous prediction may be all zero -- the first window of a sequence, where
+        #  the input-fusion convolutions see nothing but sparse event counts: ops.exact_zero_inputs.  From the second window on
+        #  every 3x3 field holds 128 channels of a dense state, and no pre-activation is exactly zero.)
+        with (ops.exact_zero_inputs() if zero_state else contextlib.nullcontext()):
             st12, s12, sst12, xs = self._input_fusion(xin12, h3, hpn, o12, B)
         n_layers = len(self.para_reschunk)
         for i, layer in enumerate(self.para_reschunk):      # x*_st of the last block is never read: skip what only feeds it
-            s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12, need_st=i + 1 < n_layers, first=i == 0)
+            s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12, need_st=i + 1 < n_layers, first=zero_state and i == 0)
         return self._tail(s12, xs, sst12, B)
 
     def _input_fusion(self, xin12, h3, hpn, o12, B):
@@ -219,7 +221,7 @@ class BMCNet(nn.Module):
         # the reference passes (x_h, x_h_p, x_h_n) positionally into Backbone.forward(xs, hp, hn, hs, o)
         # (models/BMCNet.py:115,118 vs :57): x_h acts as hp, x_h_p as hn, x_h_n as hs.
         h3 = ops.stack_states([x_h, x_h_p, x_h_n])
-        n_h, n_hp, n_hn, o = self.neuro.forward_nhwc(xin12, h3, o12)
+        n_h, n_hp, n_hn, o = self.neuro.forward_nhwc(xin12, h3, o12, zero_state=bool(init))
         if _gt is not None:
             pred, mse = ops.head_mse(o, x[:, :, 1], _gt, self.scale)
             return to_nchw(n_h), to_nchw(n_hp), to_nchw(n_hn), pred, mse

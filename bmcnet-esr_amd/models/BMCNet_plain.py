@@ -3,6 +3,8 @@
 import torch.nn.functional as F
 
 from .submodules import *  # noqa: F401,F403
+import contextlib
+
 from .submodules import BIE, PixelUnShuffle, initialize_weights, to_nchw, to_nhwc
 from bmc_hip import ops
 from bmc_hip.ops import ConvSpec, View
@@ -36,16 +38,16 @@ class Backbone(nn.Module):
         self._sp_h = ConvSpec.dense(n_c)
         self._sp_o = ConvSpec.dense(n_c, n_c)
 
-    def forward_nhwc(self, xin12, h, o12):
+    def forward_nhwc(self, xin12, h, o12, zero_state=True):
         B = h.shape[0]
-        # (the input-fusion convolutions and the first BIE's residual blocks: ops.exact_zero_inputs)
-        with ops.exact_zero_inputs():
+        # (the input-fusion convolutions and the first BIE's residual blocks on a possibly all-zero state: ops.exact_zero_inputs)
+        with (ops.exact_zero_inputs() if zero_state else contextlib.nullcontext()):
             x12 = ops.conv([View(xin12), View(h, mod=B), View(o12)], self.conv_f1.weight, self.conv_f1.bias, self._sp_f1,
                            B=2 * B, relu=True)
             xs = ops.conv([View(xin12, b0=0), View(xin12, b0=B), View(h), View(o12, b0=0), View(o12, b0=B)],
                           self.conv_fs.weight, self.conv_fs.bias, self._sp_fs, B=B, relu=True)
         for i, layer in enumerate(self.para_reschunk):
-            if i == 0:
+            if i == 0 and zero_state:
                 with ops.exact_zero_inputs():
                     x12, xs = layer.forward_twin(x12, xs)
                 continue
@@ -97,7 +99,7 @@ class BMCNet_plain(nn.Module):
         else:
             o12 = ops.pixel_unshuffle_nhwc(x_o, self.scale, split=2)
         o12 = self.neuro.pad_o(o12)
-        n_h, o = self.neuro.forward_nhwc(xin12, to_nhwc(x_h), o12)
+        n_h, o = self.neuro.forward_nhwc(xin12, to_nhwc(x_h), o12, zero_state=bool(init))
         if _gt is not None:
             pred, mse = ops.head_mse(o, x[:, :, 1], _gt, self.scale)
             return to_nchw(n_h), pred, mse
