@@ -33,6 +33,11 @@ for step in "$@"; do
              echo "abl $n: $(python3 $R/tools/pmc_agg.py $(find /tmp/w4pmc_$n -name '*.db' | head -1) wino4_conv)"
            done > $O/${TAG}_abl4pmc.log 2>&1; cat $O/${TAG}_abl4pmc.log; cd $R ;;
     stamp4) for n in ${W4_ABLS:-0 254}; do echo "== abl $n"; BMC_HIP_LIB=$R/bmcnet-esr_amd/csrc/libbmc_hip_w4stamp$n.so timeout 120 python tools/w4_stamps.py ${W4_SHAPE:-8 180 240} 2>&1 | grep -v amdgpu.ids; done > $O/${TAG}_stamp4.log 2>&1; cat $O/${TAG}_stamp4.log ;;
+    c3trace) cd /tmp; for g in "" "--graph"; do
+             rocprofv3 --kernel-trace --output-format csv -d /tmp/c3t$g -o t -- python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-bf16x6 --also none --height 31 --width 56 --math ${C3_MATH:-bf16} $g > $O/${TAG}_c3trace$g.log 2>&1
+             echo "config3 ${C3_MATH:-bf16} $g: $(grep -o '"ms_per_step": [0-9.]*' $O/${TAG}_c3trace$g.log | head -1)"
+             python3 $R/tools/gpu_timeline.py $(find /tmp/c3t$g -name '*kernel_trace.csv' | head -1) 3
+           done > $O/${TAG}_c3trace.log 2>&1; cat $O/${TAG}_c3trace.log; cd $R ;;
     bench) timeout 1500 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; head -c 600 $O/${TAG}_bench.json ;;
     benchq) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16x6 --also none > $O/${TAG}_benchq.json 2> $O/${TAG}_benchq.err; head -c 700 $O/${TAG}_benchq.json ;;
     stats) cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-bf16x6 --also none > $O/${TAG}_stats.log 2>&1
