@@ -269,7 +269,7 @@ WINO4_MIN_TILES = int(os.environ.get("BMC_WINO4_MIN_TILES", 300))    # workgroup
 # gives EXACTLY 0 wherever a pixel's receptive field holds no event, and relu'(0) = 0 gates the gradient there.  F(2x2)
 # preserves that (every output of its minimal algorithm is a combination of products of ITS OWN 3x3 field only); F(4x4) computes
 # such a pixel from a 6x6 patch through rounded transformed weights: +-1e-8 instead of 0, a coin flip of the ReLU mask that the
-# bias gradients of the first layers see (tools/wino_numerics.py, profiles/r04_wino_numerics.txt: conv_fps.bias 1.8e-1 off).
+# bias gradients of the first layers see (tests/wino_numerics.py, profiles/r04_wino_numerics.txt: conv_fps.bias 1.8e-1 off).
 # The model marks the FORWARD launches whose input can hold whole empty receptive fields -- the input-fusion convolutions on
 # the raw event counts and the residual blocks in front of the first BIE -- with this context; they keep F(2x2).
 _EXACT_ZERO = [0]

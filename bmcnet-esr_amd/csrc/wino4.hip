@@ -4,7 +4,7 @@
 //
 // 36 multiplies per 4x4 output tile and (ci, co) pair instead of 144 (direct) or 64 (F(2x2), wino.hip): 1.78x fewer MFMA
 // cycles than wino.hip's kernel, which ran the matrix pipes at 0.64-0.66 and was 45 % of the training step.
-// Numerics (tools/wino_numerics.py, profiles/r04_wino_numerics.txt): one convolution 1.9e-6 rel-L2 against float64 (direct
+// Numerics (tests/wino_numerics.py, profiles/r04_wino_numerics.txt): one convolution 1.9e-6 rel-L2 against float64 (direct
 // fp32 1.6e-7, F(2x2) 3.1e-7); two recurrent windows of the full network at 180x240 SR 1.0e-7 / 1.5e-7 (direct 4e-8 / 7e-8),
 // whole gradient 9.7e-6 (direct 8.6e-6) -- inside the parity budget (1e-4 / 1e-3 contract, 2e-5 / 2e-4 regression bars).
 // One restriction found by that experiment and enforced by the caller (bmc_hip/ops.py: `exact_zero`): convolutions whose

@@ -8,9 +8,9 @@ transposed weights) and the weight gradient (dU = sum_tiles (A dY A^T)(B^T d B),
 convolution of the oracle's network is replaced by that emulation and compared with the float64 oracle, beside the
 direct float32 convolution and F(2x2,3x3) (what round 3 ships).
 
-    python tools/wino_numerics.py conv                  # one 128->128 convolution, fwd / dgrad / wgrad
-    python tools/wino_numerics.py c2    [--gain 2.0]     # test_c2_full_size_window_forward_backward_vs_oracle's problem
-    python tools/wino_numerics.py rec   [--windows 8]    # 45x80 recurrence, 8 windows, forward + gradients
+    python tests/wino_numerics.py conv                  # one 128->128 convolution, fwd / dgrad / wgrad
+    python tests/wino_numerics.py c2    [--gain 2.0]     # test_c2_full_size_window_forward_backward_vs_oracle's problem
+    python tests/wino_numerics.py rec   [--windows 8]    # 45x80 recurrence, 8 windows, forward + gradients
 """
 import argparse
 import os
@@ -21,10 +21,10 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # (lives under tests/: it uses the oracle as its checker)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "bmcnet-esr_amd"))
-from oracle import bmc_oracle as O  # noqa: E402  (tools/ is not the product: a numerics experiment may use the oracle)
+from oracle import bmc_oracle as O  # noqa: E402  (test infrastructure: this file lives under tests/, the only place beside smoke() and the bench cpu_baseline leg that may touch oracle/)
 
 
 def cook_toom(points, m, r=3):
