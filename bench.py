@@ -38,6 +38,7 @@ FLOP_PER_LRPX_FWD_BWD = 118_121_472      # BMCNet(4,128,5) one window forward+ba
 FLOP_PER_LRPX_FWD = 41_574_912           # ... forward only (inference)
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.6           # 16 x the fp32 rate (v_mfma_f32_32x32x16_bf16, dense, 2.4 GHz)
+HBM_PEAK_GBPS = 8000.0                   # MI355X_MICROARCH.md: HBM3E spec peak (~6.3 TB/s achievable)
 # peak of the dominant kernel per arithmetic mode, in algorithmic (fp32-equivalent) FLOP/s: the bf16x6 split spends six
 # bf16 MFMAs per algorithmic product
 KERNEL_PEAK = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16": PEAK_BF16_MFMA_TFLOPS}
@@ -184,22 +185,46 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
     utilisation of the dense MFMA peak, never above 1; `achieved_algorithmic` / `frac_algorithmic` stand beside them.
     avg_launch_ms is directly comparable with rocprofv3 --stats' average for the kernel."""
     from bmc_hip import ops
-    ops.PROFILE = []
-    step_fn()
-    torch.cuda.synchronize()
-    rec, ops.PROFILE = ops.PROFILE, None
-    agg = {}
-    for kind, flops, e0, e1 in rec:
-        a = agg.setdefault(kind, [0, 0.0, 0.0])
-        a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1)
+
+    def profiled_step():
+        ops.PROFILE = []
+        step_fn()
+        torch.cuda.synchronize()
+        rec, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for kind, flops, e0, e1, nbytes in rec:
+            a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1); a[3] += nbytes
+        return agg
+
+    # As the timed region runs it: in the fp32 mode the weight-gradient kernels run on a second stream beside the data-gradient
+    # chain (ops.wgrad_side), so a kernel's in-situ duration includes the CUs it shares with them -- these are the durations
+    # rocprofv3 --kernel-trace --stats of this command reports.  `alone` (below): the same step once more with everything on one
+    # stream, i.e. every kernel with the chip to itself.
+    agg = profiled_step()
+    concurrent = ops.WGRAD_SIDE != "0" and math == "fp32"
+    agg_alone = None
+    if concurrent:
+        side, ops.WGRAD_SIDE = ops.WGRAD_SIDE, "0"
+        try:
+            agg_alone = profiled_step()
+        finally:
+            ops.WGRAD_SIDE = side
     peak = KERNEL_PEAK[math]
     total_ms = sum(v[2] for v in agg.values())
 
-    def row(kind):
-        n, fl, ms = agg[kind]
+    def row(kind, agg=agg):
+        n, fl, ms, nb = agg[kind]
+        total_ms = sum(v[2] for v in agg.values())
         alg = fl / (ms * 1e-3) / 1e12 if fl else None
         ex = alg * EXECUTED.get(kind, 1.0) if alg else None
-        return {"kernel": kind, "launches": n, "avg_launch_ms": round(ms / n, 4), "ms_per_step": round(ms, 2),
+        hbm = nb / (ms * 1e-3) / 1e9 if nb else None          # algorithmic bytes (operands once, output once) over the in-situ time
+        alone = {}
+        if agg is not agg_alone and agg_alone is not None and kind in agg_alone:
+            ra = row(kind, agg_alone)
+            alone = {"avg_launch_ms_alone": ra["avg_launch_ms"], "frac_alone": ra["frac"], "hbm_frac_alone": ra["hbm_frac"]}
+        return {"kernel": kind, **alone, "hbm_algorithmic_GBps": round(hbm, 1) if hbm else None,
+                "hbm_frac": round(hbm / HBM_PEAK_GBPS, 4) if hbm else None, "launches": n, "avg_launch_ms": round(ms / n, 4), "ms_per_step": round(ms, 2),
                 "share_of_profiled_kernel_time": round(ms / total_ms, 4),
                 "achieved_algorithmic_tflops": round(alg, 2) if alg else None, "frac_algorithmic": round(alg / peak, 4) if alg else None,
                 "executed_tflops": round(ex, 2) if ex else None, "frac": round(ex / peak, 4) if ex else None,
@@ -207,7 +232,7 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
 
     mfma_kinds = [k for k, v in agg.items() if v[1] > 0]
     dom = max(mfma_kinds, key=lambda k: agg[k][2])
-    n, fl, ms = agg[dom]
+    n, fl, ms, _ = agg[dom]
     d = row(dom)
     # HBM bytes per launch and the PMC figures: from the committed rocprofv3 PMC passes over one bench step (the AVERAGE in-step
     # launch of this kernel, FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py) --
@@ -224,15 +249,30 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
     out = {"bound": "mfma", "kernel": "%s (3x3 convolution fwd + dgrad, %d launches of one step)" % (KERNEL_LABEL.get(dom, KERNEL_NAME[math] if dom.startswith("conv_kernel<9") else dom), n),
            "achieved": d["executed_tflops"], "peak": round(peak, 1), "unit": "TFLOP/s", "frac": d["frac"],
            "achieved_algorithmic": d["achieved_algorithmic_tflops"], "frac_algorithmic": d["frac_algorithmic"],
+           "hbm_algorithmic_GBps": d["hbm_algorithmic_GBps"], "hbm_frac": d["hbm_frac"],
            "note": "achieved / frac: EXECUTED matrix FLOPs of the kernel (algorithmic x %.4f) over its in-situ time, against the dense "
                    "fp32 MFMA peak -- a utilisation; the algorithmic rate (2 x 9 x Cin x Cout FLOP per pixel, what the metric counts) is "
-                   "achieved_algorithmic" % EXECUTED.get(dom, 1.0),
+                   "achieved_algorithmic.%s" % (EXECUTED.get(dom, 1.0),
+                   "  In the timed step the weight-gradient kernels run CONCURRENTLY on a second stream, so the in-situ duration of a "
+                   "launch (these figures, and rocprofv3 --stats of this command) contains CUs shared with them and the kernel times "
+                   "add up to more than the step: `alone` is the kernel by itself, `step_frac_executed` the whole step as one "
+                   "utilisation (all executed matrix FLOPs over the step time)." if concurrent else ""),
            "traffic": traffic, "traffic_static": traffic is not None,
            "avg_launch_ms": d["avg_launch_ms"], "flop_per_launch": fl / n, "launches_per_step": n,
            "isolated_2B_128to128": iso, "pmc": pmc,
+           "streams": "weight-gradient kernels on a second stream beside the data-gradient chain (ops.wgrad_side): in-situ durations include shared CUs" if concurrent else "one stream",
+           "alone": None if agg_alone is None else dict(
+               {k: row(dom, agg_alone)[k] for k in ("avg_launch_ms", "ms_per_step", "executed_tflops", "frac", "achieved_algorithmic_tflops")},
+               note="the same step with every kernel on ONE stream (BMC_WGRAD_STREAM=0): the kernel with the chip to itself; "
+                    "rocprofv3 --stats of that command: profiles/r04_bench_fp32_onestream_kernel_stats.csv"),
            # every kernel kind with >= 4 % of the profiled kernel time, the same two rates each
            "kernels": [row(k) for k in sorted(agg, key=lambda k: -agg[k][2]) if agg[k][2] >= 0.04 * total_ms],
            "profiled_kernel_ms_per_step": round(total_ms, 1)}
+    if step_ms:
+        # the whole step as a utilisation: executed matrix FLOPs of all profiled kernels over the step time
+        ex_flops = sum(v[1] * EXECUTED.get(k, 1.0) for k, v in agg.items())
+        out["step_executed_tflops_per_gpu"] = round(ex_flops / (step_ms * 1e-3) / 1e12, 2)
+        out["step_frac_executed"] = round(ex_flops / (step_ms * 1e-3) / 1e12 / peak, 4)
     return out
 
 
@@ -472,14 +512,14 @@ def main():
 
     # the instrumented extra step contains the gradient all-reduce: every rank has to take part in it
     iso = isolated_conv(dev, B, H, W, n_c) if rank == 0 else None
-    roof = dominant_kernel_roofline(wl.eager_step, iso, args.math, wl.shape_key())
+    roof = dominant_kernel_roofline(wl.eager_step, iso, args.math, wl.shape_key(), step_ms=dt / args.steps * 1e3)
     # second arithmetic mode of the same step (every rank takes part): the fp32-equivalent bf16x6 split -- reported
     # beside the headline number, never as it
     split = None
     if args.math == "fp32" and not args.no_bf16x6 and not args.graph:
         ops.set_math("bf16x6")
         dt6, loss6 = timed(wl.eager_step, 1, args.steps, use_dist, dev)
-        roof6 = dominant_kernel_roofline(wl.eager_step, None, "bf16x6", wl.shape_key())
+        roof6 = dominant_kernel_roofline(wl.eager_step, None, "bf16x6", wl.shape_key(), step_ms=dt6 / args.steps * 1e3)
         ops.set_math("fp32")
         split = (dt6, float(loss6), roof6)
     step_flops = wl.step_flops()

@@ -89,7 +89,7 @@ def chain_fwd(s0, s1, wf, bf, gamma, beta, wc, bc, eps, B, H, W, Cn, dev):
     a.B, a.C, a.H, a.W = B, Cn, H, W
     e0 = ops._prof_begin()
     lib.call(lib._chain_fwd, "bmc_chain_fwd", C.byref(a), _stream())
-    ops._prof_end(e0, "chain_kernel<fwd>", 2.0 * B * H * W * Cn * 3 * Cn)
+    ops._prof_end(e0, "chain_kernel<fwd>", 2.0 * B * H * W * Cn * 3 * Cn, B * H * W * (16.0 * Cn + 4))
     return yhat, rstd, centre
 
 
@@ -110,7 +110,7 @@ def chain_bwd(dc, yhat, rstd, gamma, wf, wc, add, n, H, W, Cn, dev, ds1=None):
     a.n, a.C, a.H, a.W = n, Cn, H, W
     e0 = ops._prof_begin()
     lib.call(lib._chain_bwd, "bmc_chain_bwd", C.byref(a), _stream())
-    ops._prof_end(e0, "chain_kernel<bwd>", 2.0 * 2 * n * H * W * Cn * 3 * Cn)
+    ops._prof_end(e0, "chain_kernel<bwd>", 2.0 * 2 * n * H * W * Cn * 3 * Cn, 2 * n * H * W * (20.0 * Cn + 4))
     return dz, ds1, ds0
 
 
@@ -153,7 +153,8 @@ def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, w_param, b_param, G=1,
     (ops.reduce_wgrad).  G > 1 (stacked per-group weights): w_param None, result [G, ...]."""
     # keep: the operand tensors behind a_src / x_srcs (ops.wgrad_side: small launches run on the side stream)
     if ops.wino_wgrad_ok(a_src, x_srcs, spec, taps, Cout, G) and w_param is not None:
-        return ops.wgrad_wino(a_src, x_srcs[0], B, H, W, spec, dev, w_param, b_param, w_shape if w_shape is not None else w_param.shape)
+        return ops.wgrad_wino(a_src, x_srcs[0], B, H, W, spec, dev, w_param, b_param, w_shape if w_shape is not None else w_param.shape,
+                              keep=keep)
     with ops.wgrad_side(B * H * W, ops._flat_params(w_param, b_param), keep):
         slabs, nsplit, _, bsl = pgemm_raw(a_src, x_srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
                                           flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)

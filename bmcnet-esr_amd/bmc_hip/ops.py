@@ -20,7 +20,8 @@ CK = 16
 _cur_dev = torch._C._cuda_getDevice      # torch.cuda.current_device() without its Python-level lazy-init wrapper
 
 
-_STREAM_OVERRIDE = None      # raw handle of the side stream while a weight-gradient launch is being issued there (wgrad_side)
+_STREAM_OVERRIDE = None      # raw handle of the side stream while a weight-gradient launch is being issued there (wgrad_side),
+_STREAM_OVERRIDE_TS = None   # the same stream as a torch.cuda.Stream
 
 
 def _stream():
@@ -35,10 +36,9 @@ def _on_side(*tensors):
     """Workspaces torch allocated (on the launch stream's pool) for kernels that run on the side stream: the allocator must
     not hand their memory out again before the side stream is done with it."""
     if _STREAM_OVERRIDE is not None:
-        st = _SIDE[_cur_dev()].stream
         for t in tensors:
             if t is not None:
-                t.record_stream(st)
+                t.record_stream(_STREAM_OVERRIDE_TS)
 
 
 def _need_gpu(t: torch.Tensor):
@@ -145,7 +145,8 @@ class ConvSpec:
 
 
 # Optional in-situ kernel timing (bench.py): when PROFILE is a list, every conv / pgemm launch appends
-# (kernel kind, algorithmic FLOPs, start event, end event) recorded on the launch stream.
+# (kernel kind, algorithmic FLOPs, start event, end event, algorithmic HBM bytes) recorded on the launch stream.  The bytes are
+# every operand read once and the output written once (DESIGN.md's per-pixel figures x the launch's pixels).
 PROFILE = None
 PROFILE_WINO = [0, 0]       # while PROFILE is a list: conv launches that took the Winograd kernel / the direct kernels
 
@@ -153,7 +154,7 @@ PROFILE_WINO = [0, 0]       # while PROFILE is a list: conv launches that took t
 def _prof_record(e):
     # on the stream the launch really goes to (torch's current stream, or the side stream of wgrad_side)
     if _STREAM_OVERRIDE is not None:
-        e.record(_SIDE[_cur_dev()].stream)
+        e.record(_STREAM_OVERRIDE_TS)
     else:
         e.record()
 
@@ -166,11 +167,11 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, kind, flops):
+def _prof_end(e0, kind, flops, nbytes=0.0):
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         _prof_record(e1)
-        PROFILE.append((kind, flops, e0, e1))
+        PROFILE.append((kind, flops, e0, e1, nbytes))
 
 
 # Arithmetic of the convolution kernels (include/bmc_hip.h BMC_MATH_*): 0 = native fp32 MFMA (default, the headline
@@ -410,7 +411,8 @@ def conv_raw(srcs: List[lib.Src], wpacked, w_group_stride, bias, bias_group_stri
     e0 = _prof_begin()
     lib.call(lib._conv, "bmc_conv", C.byref(a), _stream())
     _prof_end(e0, ("wino4_conv<9,128>" if wino == 4 else "wino_conv<9,128>") if wino else
-              "conv_kernel<%d,%d>" % (taps, 32 if a.Coutpad == 32 else 128), flops)
+              "conv_kernel<%d,%d>" % (taps, 32 if a.Coutpad == 32 else 128), flops,
+              4.0 * B * H * W * (sum(x.nch for x in srcs) + Cout * (1 + (residual is not None) + (mask is not None) + bool(accumulate))))
     if PROFILE is not None and e0 is not None:
         PROFILE_WINO[0 if wino else 1] += 1
 
@@ -474,7 +476,7 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
     _on_side(slabs, bslabs)
     e0 = _prof_begin()
     lib.call(lib._pgemm, "bmc_pgemm", C.byref(p), _stream())
-    _prof_end(e0, "pgemm_kernel<%d>" % taps, flops)
+    _prof_end(e0, "pgemm_kernel<%d>" % taps, flops, 4.0 * B * H * W * (a_src.nch + sum(x.nch for x in srcs)) + 4.0 * slabs.numel())
     if want_bias:
         return slabs, nsplit, G, bslabs
     return slabs, nsplit, G
@@ -498,10 +500,15 @@ def wino_wgrad_ok(a_src, x_srcs, spec, taps, Cout, G):
     return k0 >= 0 and spec.kmap_host == list(range(k0, k0 + 128))
 
 
-def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias=True, k0=None, full=None):
+def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias=True, k0=None, full=None, keep=()):
     """(dW, db) of a convolution wino_wgrad_ok() accepted, with reduce_wgrad's conventions: None where the sums went straight
     into a leaf parameter's .grad.  k0 / full: the launch covers only the weight columns [k0, k0 + 128) of a wider convolution
     (one 128-channel source of a multi-source launch: split_wgrad_ok)."""
+    with (wgrad_side(B * H * W, [w_param, b_param] if want_bias else [w_param], keep) if w_param is not None else _NOCTX):
+        return _wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias, k0, full)
+
+
+def _wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias, k0, full):
     nsplit = lib._ww_nsplit(B, H, W)
     part = torch.empty(nsplit * 16 * 128 * 128, device=dev, dtype=torch.float32)
     bpart = torch.empty(nsplit * 128, device=dev, dtype=torch.float32) if want_bias else None
@@ -509,7 +516,7 @@ def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want
     e0 = _prof_begin()
     lib.call(lib._ww, "bmc_wgrad_wino", C.byref(a_src), C.byref(x_src), B, H, W, nsplit, part.data_ptr(),
              bpart.data_ptr() if want_bias else None, _stream())
-    _prof_end(e0, "wgrad_wino<9>", 2.0 * B * H * W * 128 * 9 * 128)
+    _prof_end(e0, "wgrad_wino<9>", 2.0 * B * H * W * 128 * 9 * 128, 4.0 * B * H * W * 256 + 4.0 * part.numel())
     k0 = spec.kmap_host[0] if k0 is None else k0
     full = spec.covers_all if full is None else full
     sg = sink_group([w_param, b_param] if want_bias else [w_param], full) if w_param is not None else None
@@ -636,21 +643,29 @@ def sink_group(params, full=True):
 
 
 # --------------------------------------------------------------------------
-# weight gradients beside the data-gradient chain (small frames)
+# weight gradients beside the data-gradient chain
 # --------------------------------------------------------------------------
-# Nothing in backward waits for a weight gradient: it only has to be in .grad when the optimizer steps.  At the frame sizes
-# of BASELINE configs[3] (31x56) and of the reference's own NFS config (45x80) every launch is a single wave of small
-# tiles that cannot fill the chip, and the step is a chain of ~4 700 of them: there the pixel-reduction GEMMs and their
-# slab reductions (a third of the step) run on a SIDE stream beside the convolutions of the data-gradient chain instead
-# of between them.  (At 180x240 every kernel fills all 256 CUs by itself: measured neutral in round 2, and the operands
-# kept alive until the join would cost memory -- off there.)  Protocol: the side stream waits for the launch stream before
-# every weight-gradient launch (its operands were just produced there); operand tensors are kept referenced until the
-# join; the join -- launch stream waits for the side stream -- is an autograd-engine callback at the end of the backward
-# pass that armed it, i.e. before anything (optimizer, GradAllReducer.finish) reads a .grad.  Only for gradients that go
-# straight into leaf parameters' .grad (sink route): a gradient handed back to autograd stays on the launch stream.
-# Accumulation order into a .grad = issue order on the one side stream = backward's order: deterministic as before.
-WGRAD_SIDE = os.environ.get("BMC_WGRAD_STREAM", "0")             # "0" never (default, see below), "1" always, "auto" small fp32 problems
-WGRAD_SIDE_MAX_PIXELS = int(os.environ.get("BMC_WGRAD_STREAM_MAX_PIXELS", 1 << 17))
+# Nothing in backward waits for a weight gradient: it only has to be in .grad when the optimizer steps.  So the weight-gradient
+# kernels (pixel-reduction GEMMs, the Winograd weight gradient, their reductions: a quarter to a third of the step) run on a
+# SIDE stream beside the convolutions of the data-gradient chain instead of between them.  Two regimes gain from it:
+#   * small frames (BASELINE configs[3] 31x56, the reference's own NFS config 45x80): every launch is a single wave of small
+#     tiles that cannot fill the chip, and the step is a chain of ~4 700 of them -- 87.9 -> 82.6 ms, 87.2 -> 80.4 ms;
+#   * large frames (180x240), since round 4: every kernel fills the 256 CUs, but in ROUNDS of one tile per CU -- the F(4x4)
+#     convolution's 1 352 workgroup tiles of a 2B launch are 5.28 rounds, so 186 CUs idle through the sixth -- and the other
+#     stream's workgroups take exactly those CUs: 765 -> 747 ms at C2, 251.6 -> 234.6 ms at 90x120 (round 2 measured it neutral:
+#     the direct kernels' many small tiles left no such tails).
+# Not in the bf16 mode (31x56: 72.0 -> 83.4 ms, the bf16 pixel-reduction kernel and the convolutions then fight for LDS) and
+# not in bf16x6 (neutral, 910.5 vs 908.5 ms at C2).  `tools/side_stream_matrix.sh` is the measurement.
+# Protocol: the side stream waits for the launch stream before every weight-gradient launch (its operands were just produced
+# there); the operand tensors are kept referenced until the join (small problems) or handed to the caching allocator with
+# record_stream (large ones: keeping every window's operands until the end of an 8-window backward would not fit); the join
+# -- launch stream waits for the side stream -- is an autograd-engine callback at the end of the backward pass that armed it,
+# i.e. before anything (optimizer, GradAllReducer.finish) reads a .grad.  Only for gradients that go straight into leaf
+# parameters' .grad (sink route): a gradient handed back to autograd stays on the launch stream.
+# Accumulation order into a .grad = issue order on the one side stream = backward's order: deterministic as before, and
+# bit-identical to the single-stream run (tests/test_gpu_r3.py, tests/test_gpu_r4.py).
+WGRAD_SIDE = os.environ.get("BMC_WGRAD_STREAM", "auto")          # "0" never, "1" always, "auto" (default) in the fp32 mode
+WGRAD_SIDE_MAX_PIXELS = int(os.environ.get("BMC_WGRAD_STREAM_MAX_PIXELS", 1 << 17))     # operands kept (<=) or record_stream'ed (>)
 
 
 class _SideState:
@@ -687,14 +702,14 @@ class _SideCtx:
         self.st = st
 
     def __enter__(self):
-        global _STREAM_OVERRIDE
+        global _STREAM_OVERRIDE, _STREAM_OVERRIDE_TS
         self.st.follow_main()
-        _STREAM_OVERRIDE = self.st.raw
+        _STREAM_OVERRIDE, _STREAM_OVERRIDE_TS = self.st.raw, self.st.stream
         return self.st
 
     def __exit__(self, *exc):
-        global _STREAM_OVERRIDE
-        _STREAM_OVERRIDE = None
+        global _STREAM_OVERRIDE, _STREAM_OVERRIDE_TS
+        _STREAM_OVERRIDE = _STREAM_OVERRIDE_TS = None
         return False
 
 
@@ -709,8 +724,9 @@ class _NoCtx:
 _NOCTX = _NoCtx()
 
 
+
 def wgrad_side(npx, params, keep=()):
-    """Context for one weight-gradient launch (+ its reduction): the side stream when the launch is small, all its
+    """Context for one weight-gradient launch (+ its reduction): the side stream when the mode has it (above), all its
     destinations are sink parameters and an autograd backward pass is running (the join hangs on its end), else nothing.
     keep: the operand tensors of the launch (referenced until the join)."""
     if WGRAD_SIDE == "0" or torch._C._current_graph_task_id() < 0:
@@ -723,7 +739,7 @@ def wgrad_side(npx, params, keep=()):
         # the FIRST weight-gradient launch of a backward pass decides for the whole pass: one parameter's gradient is
         # accumulated by launches of different batch sizes (conv_fs: B and 3B), and its read-modify-writes must not be
         # split over two streams
-        st.side = WGRAD_SIDE == "1" or (npx <= WGRAD_SIDE_MAX_PIXELS and MATH == 0)
+        st.side = WGRAD_SIDE == "1" or MATH == 0
         torch.autograd.Variable._execution_engine.queue_callback(st.join)
         st.armed = True
     if not st.side:
@@ -731,7 +747,11 @@ def wgrad_side(npx, params, keep=()):
     ps = [p for p in params if p is not None]
     if not ps or not all(is_sink(p) for p in ps):
         return _NOCTX
-    st.keep.extend(keep)
+    if npx <= WGRAD_SIDE_MAX_PIXELS:
+        st.keep.extend(keep)
+    else:                       # large operands: not kept until the join -- the allocator defers their reuse to the side stream's progress
+        for t in keep:
+            t.record_stream(st.stream)
     return _SideCtx(st)
 
 
@@ -872,7 +892,7 @@ class ConvFn(torch.autograd.Function):
                 big, rest, sub = sp
                 for n, (i, k0) in enumerate(big):
                     wgrad_wino(a_src, srcs[i], B, H, W, spec, dev, wp_, bp_ if (wb and n == 0) else None, weight.shape,
-                               want_bias=wb and n == 0, k0=k0, full=False)
+                               want_bias=wb and n == 0, k0=k0, full=False, keep=(g, src_ts[i]))
                 if rest:
                     with wgrad_side(B * H * W, [wp_], (g, *src_ts)):
                         r_pg = pgemm_raw(a_src, [srcs[i] for i in rest], B, H, W, taps, B, Cout, sub.kpad, dev,
@@ -880,7 +900,8 @@ class ConvFn(torch.autograd.Function):
                         reduce_wgrad(r_pg[0], r_pg[1], 1, taps, Cout, sub, dev, None, wp_, None, weight.shape)
                 dw = db = None
             elif wino_wgrad_ok(a_src, srcs, spec, taps, Cout, G) and not isinstance(wp_, (tuple, list)):
-                dw, db = wgrad_wino(a_src, srcs[0], B, H, W, spec, dev, wp_, bp_ if wb else None, weight.shape, want_bias=wb)
+                dw, db = wgrad_wino(a_src, srcs[0], B, H, W, spec, dev, wp_, bp_ if wb else None, weight.shape, want_bias=wb,
+                                    keep=(g, src_ts[0]))
             elif (ngp and 1 < G <= 4 and len(wp_) == G and wino_wgrad_ok(a_src, srcs, spec, taps, Cout, 1) and v0[2] == 0
                   and v0[3] is None):
                 # grouped launch over separate parameters (conv_hp / conv_hn): one Winograd weight gradient per group, on the
@@ -890,7 +911,8 @@ class ConvFn(torch.autograd.Function):
                 for gi in range(G):
                     a_g = _src(g, 0, Cout, 0, None, gi * bpg, bpg)
                     x_g = _src(src_ts[0], v0[0], v0[1], 0, None, v0[4] + gi * bpg, bpg)
-                    outs.append(wgrad_wino(a_g, x_g, bpg, H, W, spec, dev, wp_[gi], bp_[gi] if wb else None, wp_[gi].shape, want_bias=wb))
+                    outs.append(wgrad_wino(a_g, x_g, bpg, H, W, spec, dev, wp_[gi], bp_[gi] if wb else None, wp_[gi].shape, want_bias=wb,
+                                           keep=(g, src_ts[0])))
                 dw = None if all(o[0] is None for o in outs) else torch.stack([
                     o[0] if o[0] is not None else torch.zeros_like(wp_[i]) for i, o in enumerate(outs)])
                 db = None if (not wb or all(o[1] is None for o in outs)) else torch.stack([
@@ -1045,7 +1067,7 @@ def _wgrad_plain(g, x, spec, w_param, b_param, taps):
     dev = g.device
     a_src, x_src = _src(g, 0, Cout, 0, None, 0, B), _src(x, 0, x.shape[3], 0, None, 0, B)
     if wino_wgrad_ok(a_src, [x_src], spec, taps, Cout, 1):
-        return wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_param.shape)
+        return wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_param.shape, keep=(g, x))
     with wgrad_side(B * H * W, [w_param, b_param], (g, x)):
         slabs, nsplit, _, bsl = pgemm_raw(a_src, [x_src], B, H, W, taps,
                                           B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)

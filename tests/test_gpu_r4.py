@@ -162,3 +162,54 @@ def test_exact_zero_rule_keeps_reference_relu_gates(force_wino4):
     assert torch.count_nonzero(y_safe[empty]) == 0
     assert rel_l2(y_f4, y_safe) < 1e-5
     print("F(4x4) residue on empty receptive fields: %d of %d outputs non-zero" % (torch.count_nonzero(y_f4[empty]), int(empty.sum())))
+
+
+# ------------------------------------------------------------------ weight gradients on the side stream at every size (fp32 default)
+@pytest.mark.parametrize("keep_limit", [0, 1 << 30])
+def test_side_stream_weight_gradients_bit_identical_with_winograd_kernels(force_wino4, keep_limit):
+    """Round 4: in the fp32 mode the weight-gradient kernels (pixel-reduction GEMM AND the Winograd weight gradient, with their
+    reductions) run on a second stream by default, at every frame size (bmc_hip.ops.wgrad_side).  The whole step -- loss, every
+    parameter gradient, the parameters after three Adam steps -- must be bit-identical to the one-stream run, repeatedly, both
+    when the operands are kept referenced until the join (keep_limit large) and when they are handed to the caching allocator
+    with record_stream (keep_limit 0: the route of the large frames, where a use-after-reuse would show up here)."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from models.BMCNet import BMCNet
+    from train_step import bptt_step
+    ops.set_math("fp32")
+    scale, n_c, n_b, B, L, H, W = 4, 128, 1, 2, 4, 72, 96         # (force_wino4: the F(4x4) kernel runs at this size too)
+    g = torch.Generator().manual_seed(191)
+    inp = torch.poisson(torch.full((B, L, 2, H, W), 0.5), generator=g).to(dev)
+    gt = torch.poisson(torch.full((B, L, 2, scale * H, scale * W), 0.5), generator=g).to(dev)
+
+    def run(mode):
+        old, old_lim = ops.WGRAD_SIDE, ops.WGRAD_SIDE_MAX_PIXELS
+        ops.WGRAD_SIDE, ops.WGRAD_SIDE_MAX_PIXELS = mode, keep_limit
+        try:
+            torch.manual_seed(192)
+            m = BMCNet(scale, n_c, n_b).to(dev)
+            scaled_init(m, 2.0)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-5, amsgrad=True)
+            losses = []
+            ops.PROFILE, ops.PROFILE_WINO[:] = [], [0, 0]
+            for _ in range(3):
+                loss, _ = bptt_step(m, opt, inp, gt, n_c, scale)
+                losses.append(loss.item())
+            torch.cuda.synchronize()
+            kinds = {r[0] for r in ops.PROFILE}
+            ops.PROFILE = None
+            return losses, [p.grad.clone() for p in m.parameters() if p.grad is not None], [p.detach().clone() for p in m.parameters()], kinds
+        finally:
+            ops.WGRAD_SIDE, ops.WGRAD_SIDE_MAX_PIXELS = old, old_lim
+            ops.PROFILE = None
+
+    assert ops.WGRAD_SIDE == "auto"                  # the shipped default
+    l0, g0, p0, kinds = run("0")
+    assert {"wino4_conv<9,128>", "wgrad_wino<9>", "pgemm_kernel<1>"} <= kinds, kinds
+    for rep in range(2):
+        l1, g1, p1, _ = run("auto")
+        assert l0 == l1
+        assert len(g0) == len(g1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+        assert all(torch.equal(a, b) for a, b in zip(p0, p1))
+    st = next(iter(ops._SIDE.values()))
+    assert st.side and not st.armed and not st.keep

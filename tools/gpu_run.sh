@@ -3,7 +3,7 @@
 # from the repo root, every log under gpurun_out/<tag>_*.  usage: bash tools/gpu_run.sh <tag> <step> [<step> ...]
 #   steps:  t4 (tests/test_gpu_r4.py)  tall (all -m gpu tests)  time4 (isolated F(4x4) / F(2x2) / direct launch)
 #           abl4 (ablation ladder of the F(4x4) kernel: make -C bmcnet-esr_amd/csrc libbmc_hip_w4ablN.so first)
-#           bench (default bench line)  benchq (bench without side runs)  stats (rocprofv3 --kernel-trace --stats of benchq)
+#           bench (default bench line)  benchq (bench without side runs)  stats (rocprofv3 --kernel-trace --stats of benchq)  stats1 (the same with BMC_WGRAD_STREAM=0: every kernel alone on one stream)
 #           pmc (the three PMC passes of tools/pmc_summary.py)
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
@@ -42,6 +42,8 @@ for step in "$@"; do
     benchq) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16x6 --also none > $O/${TAG}_benchq.json 2> $O/${TAG}_benchq.err; head -c 700 $O/${TAG}_benchq.json ;;
     stats) cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-bf16x6 --also none > $O/${TAG}_stats.log 2>&1
            find /tmp/prof_$TAG -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats.csv \; ; head -12 $O/${TAG}_kernel_stats.csv; cd $R ;;
+    stats1) cd /tmp; export BMC_WGRAD_STREAM=0; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1_$TAG -o p -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-bf16x6 --also none > $O/${TAG}_stats1.log 2>&1
+           unset BMC_WGRAD_STREAM; find /tmp/prof1_$TAG -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_onestream_kernel_stats.csv \; ; head -6 $O/${TAG}_onestream_kernel_stats.csv; cd $R ;;
     pmc)   cd /tmp
            for p in "sq:SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
              rocprofv3 --kernel-trace --pmc ${p#*:} -d /tmp/pmcw_$TAG/pmc_fp32_${p%%:*} -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-bf16x6 --also none > $O/${TAG}_pmc_${p%%:*}.log 2>&1

@@ -37,7 +37,7 @@ for mode in ("winograd", "direct"):
     ops.PROFILE = []
     run(10)
     torch.cuda.synchronize()
-    ks = [e0.elapsed_time(e1) for _, _, e0, e1 in ops.PROFILE]
+    ks = [e0.elapsed_time(e1) for _, _, e0, e1, _ in ops.PROFILE]
     ops.PROFILE = None
     print("   main kernel alone: %.3f ms" % (sum(ks) / len(ks)))
     print("%-9s B%d %dx%d: %.3f ms per weight gradient (kernel + reduction) = %.1f algorithmic TFLOP/s" % (mode, B, H, W, ms, flops / ms / 1e9))
