@@ -47,6 +47,10 @@ typedef struct bmc_src {
 /* ---- library ---- */
 int bmc_version(void);
 const char* bmc_last_error(void);
+/* A new stream of the device's lowest priority (hipDeviceGetStreamPriorityRange), never destroyed by the library.  The training
+ * step issues its weight-gradient kernels there (the reference has no counterpart: autograd runs train.py:233's backward on
+ * one stream): they fill the CUs the data-gradient chain leaves idle without delaying it. */
+int bmc_stream_create_low_priority(bmc_stream_t* out);
 
 /* ---- event -> count image: dataloader/encodings.py:241-269,290-305 -------
  * events_to_channels() for `nframes` frames in one launch.  Frame f owns events
