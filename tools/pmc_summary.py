@@ -47,7 +47,10 @@ def short(name):
     return sym.replace(" ", "")
 
 
-def main(root, tag, steps=3):      # bench.py --steps 1 --warmup 1 runs 3 steps: warm-up, timed, instrumented (roofline block)
+def main(root, tag, steps=None):
+    # bench.py --steps 1 --warmup 1 runs warm-up, timed and instrumented (roofline block) steps: 3, and in the fp32 mode a fourth
+    # (the instrumented step once more on one stream: roofline.alone)
+    steps_of = {"fp32": steps or 4, "bf16x6": steps or 3}
     out = {"_comment": __doc__.split("\n\n")[0] + " Counters: rocprofv3 --pmc, one pass per counter group; "
            "FETCH_SIZE doubled (gfx950), KiB -> bytes; clock = GRBM_GUI_ACTIVE / 8 / duration.",
            # the workload the passes ran (bench.py defaults): bench.py attaches these numbers to a run of THIS workload only
@@ -77,7 +80,7 @@ def main(root, tag, steps=3):      # bench.py --steps 1 --warmup 1 runs 3 steps:
             w = {k: a[0] / a[1] for k, a in m["_w"].items() if a[1]}
             if "avg_us" not in w or m["launches"] < 2:
                 continue
-            e = {"launches_per_step": round(m["launches"] / steps, 1), "avg_launch_us": round(w["avg_us"], 2)}
+            e = {"launches_per_step": round(m["launches"] / steps_of[mode], 1), "avg_launch_us": round(w["avg_us"], 2)}
             if "GRBM_GUI_ACTIVE" in w:
                 cyc = w["GRBM_GUI_ACTIVE"] / 8.0
                 e["in_kernel_clock_GHz"] = round(cyc / w["avg_us"] / 1e3, 3)
@@ -103,4 +106,4 @@ def main(root, tag, steps=3):      # bench.py --steps 1 --warmup 1 runs 3 steps:
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r02", int(sys.argv[3]) if len(sys.argv) > 3 else 3)
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r02", int(sys.argv[3]) if len(sys.argv) > 3 else None)
