@@ -457,8 +457,9 @@ class Unstack2Fn(torch.autograd.Function):
     slice backward would zero-fill and add two full-size tensors)."""
 
     @staticmethod
-    def forward(ctx, t):
-        n = t.shape[0] // 2
+    def forward(ctx, t, n=None):
+        # (n: split point, default the middle -- models/BMCNet.py's [xs_p_st; xs_n_st | xs] is a 2B / B split)
+        n = t.shape[0] // 2 if n is None else n
         ctx.n = n
         ctx.shape = t.shape
         return t[:n], t[n:]
@@ -485,9 +486,9 @@ class Unstack2Fn(torch.autograd.Function):
             pair = getattr(ctx, "pair", None)
             if pair is not None:
                 pair.buf = None          # `out` owns the storage from here on
-            return out
+            return out, None
         pair = getattr(ctx, "pair", None)
         if pair is not None:
             pair.buf = None
-        z = lambda: torch.zeros((ctx.n,) + tuple(ctx.shape[1:]), device=(g1 if g1 is not None else g2).device)
-        return torch.cat([g1 if g1 is not None else z(), g2 if g2 is not None else z()], 0)
+        z = lambda k: torch.zeros((k,) + tuple(ctx.shape[1:]), device=(g1 if g1 is not None else g2).device)
+        return torch.cat([g1 if g1 is not None else z(ctx.n), g2 if g2 is not None else z(ctx.shape[0] - ctx.n)], 0), None

@@ -747,7 +747,9 @@ def wgrad_side(npx, params, keep=()):
         # the FIRST weight-gradient launch of a backward pass decides for the whole pass: one parameter's gradient is
         # accumulated by launches of different batch sizes (conv_fs: B and 3B), and its read-modify-writes must not be
         # split over two streams
-        st.side = WGRAD_SIDE == "1" or MATH == 0
+        # (not while a HIP graph is being captured: replaying the two-stream graph serialises badly -- 31x56: 174.9 ms against
+        #  82.3 ms eager and 88 ms for the one-stream graph; "1" forces it)
+        st.side = WGRAD_SIDE == "1" or (MATH == 0 and not torch.cuda.is_current_stream_capturing())
         torch.autograd.Variable._execution_engine.queue_callback(st.join)
         st.armed = True
     if not st.side:

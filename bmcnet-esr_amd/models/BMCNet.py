@@ -154,7 +154,8 @@ class Backbone(nn.Module):
                           self.conv_fs.bias, self._sp_fs_shared, B=B)      # input channels of xp_st, xn_st, o (+ the bias)
         fs3 = ops.conv([View(h3)], wfs, None, self._sp_fs_h, B=3 * B, relu=True,
                        residual=View(shared, mod=B))                       # + those of h*: [xs_p_st; xs_n_st; xs]
-        return st12, s12, fs3[:2 * B], fs3[2 * B:]
+        sst12, xs = bie.Unstack2Fn.apply(fs3, 2 * B)       # (one concatenation in backward instead of two zero-filled slice gradients + add)
+        return st12, s12, sst12, xs
 
     def _tail(self, s12, xs, sst12, B):
         # the three new states go into ONE buffer [x_h; x_h_p; x_h_n]: the next window reads them as h3 without a copy
