@@ -254,28 +254,49 @@ __device__ __forceinline__ float split_sum(const float* p, long long slab, int n
 // conv_hp / conv_hn): group g is written to gd.dw[g] / gd.db[g] instead of dw + g * M*Cin*taps / db + g * M.
 struct GroupDst { float* dw[4]; float* db[4]; int n; };
 
+// Bias gradient db[g][m] = sum over the nsplit * 4 column-sum partials the GEMM's workgroups left in bias_slabs (partial
+// i = split * 4 + part lives at ((split * G + g) * 4 + part) * Mpad + m).  One block = BIAS_OUT outputs x 64 parts: a thread
+// adds every 64th partial (eight loads in flight), the 64 part sums of an output meet in LDS and are added in part order -- a
+// fixed order whatever the launch.  (32 outputs x 8 parts, the first form, left each thread with nsplit / 2 dependent rounds of
+// loads: with 224-256 splits these few blocks ran 14-37 us and were the whole duration of a reduction whose weight part takes
+// 5 us -- 715 launches per small-frame step.)
+constexpr int BIAS_OUT = 4;
+__device__ __forceinline__ void bias_block_sum(const float* bias_slabs, int nsplit, int G, int M, int Mpad, float* db,
+                                               int accumulate, int block, const GroupDst& gd, float* red /* [256] */) {
+    const long long total = (long long)G * M;
+    const long long idx = (long long)block * BIAS_OUT + (threadIdx.x & (BIAS_OUT - 1));
+    const bool live = idx < total;
+    const int g = live ? (int)(idx / M) : 0, m = live ? (int)(idx % M) : 0;
+    const int part = threadIdx.x / BIAS_OUT, nparts = 256 / BIAS_OUT, n4 = nsplit * 4;
+    float s = 0.f;
+    if (live) {
+        auto at = [&](int i) { return ldg4(bias_slabs + (((long long)(i >> 2) * G + g) * 4 + (i & 3)) * Mpad + m); };
+        int i = part;
+        for (; i + 7 * nparts < n4; i += 8 * nparts) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = at(i + k * nparts);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; i < n4; i += nparts) s += at(i);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < BIAS_OUT && live) {
+        float t = 0.f;
+        for (int k = 0; k < nparts; ++k) t += red[k * BIAS_OUT + threadIdx.x];
+        float* o = gd.n ? gd.db[g] + m : db + idx;
+        *o = accumulate ? *o + t : t;
+    }
+}
+
 __global__ void reduce_weight_kernel(const float* slabs, int nsplit, int G, int taps, int M, int N, int Mpad, int Npad,
                                      const int* kmap, int Cin, float* dw, int accumulate, const float* bias_slabs,
                                      float* db, int wblocks, const GroupDst gd) {
     __shared__ float red[256];
-    if ((int)blockIdx.x >= wblocks) {    // trailing blocks: bias gradient db[g][m] = sum over (split, part) partials
-        const long long total = (long long)G * M;
-        const long long idx = (long long)(blockIdx.x - wblocks) * 32 + (threadIdx.x & 31);
-        const int g = idx < total ? (int)(idx / M) : 0, m = idx < total ? (int)(idx % M) : 0;
-        // partial p = split * 4 + part lives at ((split*G + g)*4 + part)*Mpad + m
-        const int part = threadIdx.x >> 5;
-        float s = 0.f;
-        if (idx < total)
-            for (int i = part; i < nsplit * 4; i += 8) s += bias_slabs[(((long long)(i >> 2) * G + g) * 4 + (i & 3)) * Mpad + m];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        if (threadIdx.x < 32 && idx < total) {
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t += red[k * 32 + threadIdx.x];
-            float* o = gd.n ? gd.db[g] + m : db + idx;
-            *o = accumulate ? *o + t : t;
-        }
+    if ((int)blockIdx.x >= wblocks) {    // trailing blocks: bias gradient
+        bias_block_sum(bias_slabs, nsplit, G, M, Mpad, db, accumulate, (int)blockIdx.x - wblocks, gd, red);
         return;
     }
     const long long total = (long long)G * taps * M * N;
@@ -312,22 +333,7 @@ __global__ void reduce_weight4_kernel(const float* slabs, int nsplit, int G, int
     __shared__ f32x4 red4[256];
     __shared__ float red[256];
     if ((int)blockIdx.x >= wblocks) {    // trailing blocks: bias gradient (as in reduce_weight_kernel)
-        const long long total = (long long)G * M;
-        const long long idx = (long long)(blockIdx.x - wblocks) * 32 + (threadIdx.x & 31);
-        const int g = idx < total ? (int)(idx / M) : 0, m = idx < total ? (int)(idx % M) : 0;
-        const int part = threadIdx.x >> 5;
-        float s = 0.f;
-        if (idx < total)
-            for (int i = part; i < nsplit * 4; i += 8) s += bias_slabs[(((long long)(i >> 2) * G + g) * 4 + (i & 3)) * Mpad + m];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        if (threadIdx.x < 32 && idx < total) {
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t += red[k * 32 + threadIdx.x];
-            float* o = gd.n ? gd.db[g] + m : db + idx;
-            *o = accumulate ? *o + t : t;
-        }
+        bias_block_sum(bias_slabs, nsplit, G, M, Mpad, db, accumulate, (int)blockIdx.x - wblocks, gd, red);
         return;
     }
     const int per = 256 / P, ol = threadIdx.x % per, part = threadIdx.x / per;
@@ -486,7 +492,7 @@ extern "C" int bmc_pgemm_reduce_weight(const float* slabs, int nsplit, int G, in
     BMC_CHECK_ARG((bias_slabs == nullptr) == (db == nullptr), "bmc_pgemm_reduce_weight: bias_slabs and db go together");
     const long long total = (long long)G * taps * M * N;
     const int wblocks = (int)((total + 31) / 32 > 8192 ? 8192 : (total + 31) / 32);
-    const int bblocks = bias_slabs ? (int)(((long long)G * M + 31) / 32) : 0;
+    const int bblocks = bias_slabs ? (int)(((long long)G * M + BIAS_OUT - 1) / BIAS_OUT) : 0;
     GroupDst gd = {};
     if (N % 4 == 0) {
         const int P = reduce_parts(nsplit), per = 256 / P;
@@ -516,7 +522,7 @@ extern "C" int bmc_pgemm_reduce_weight_groups(const float* slabs, int nsplit, in
     }
     const long long total = (long long)G * taps * M * N;
     const int wblocks = (int)((total + 31) / 32 > 8192 ? 8192 : (total + 31) / 32);
-    const int bblocks = bias_slabs ? (int)(((long long)G * M + 31) / 32) : 0;
+    const int bblocks = bias_slabs ? (int)(((long long)G * M + BIAS_OUT - 1) / BIAS_OUT) : 0;
     if (N % 4 == 0) {
         const int P = reduce_parts(nsplit), per = 256 / P;
         const long long nchunk = ((long long)G * taps * M * (N / 4) + per - 1) / per;
