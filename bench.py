@@ -202,7 +202,7 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
     # rocprofv3 --kernel-trace --stats of this command reports.  `alone` (below): the same step once more with everything on one
     # stream, i.e. every kernel with the chip to itself.
     agg = profiled_step()
-    concurrent = ops.WGRAD_SIDE != "0" and math == "fp32"
+    concurrent = any(st.side for st in ops._SIDE.values())      # did that step's backward use the second stream?
     agg_alone = None
     if concurrent:
         side, ops.WGRAD_SIDE = ops.WGRAD_SIDE, "0"

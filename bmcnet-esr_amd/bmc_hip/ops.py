@@ -647,15 +647,17 @@ def sink_group(params, full=True):
 # --------------------------------------------------------------------------
 # Nothing in backward waits for a weight gradient: it only has to be in .grad when the optimizer steps.  So the weight-gradient
 # kernels (pixel-reduction GEMMs, the Winograd weight gradient, their reductions: a quarter to a third of the step) run on a
-# SIDE stream beside the convolutions of the data-gradient chain instead of between them.  Two regimes gain from it:
-#   * small frames (BASELINE configs[3] 31x56, the reference's own NFS config 45x80): every launch is a single wave of small
-#     tiles that cannot fill the chip, and the step is a chain of ~4 700 of them -- 87.9 -> 82.6 ms, 87.2 -> 80.4 ms;
-#   * large frames (180x240), since round 4: every kernel fills the 256 CUs, but in ROUNDS of one tile per CU -- the F(4x4)
-#     convolution's 1 352 workgroup tiles of a 2B launch are 5.28 rounds, so 186 CUs idle through the sixth -- and the other
-#     stream's workgroups take exactly those CUs: 765 -> 747 ms at C2, 251.6 -> 234.6 ms at 90x120 (round 2 measured it neutral:
-#     the direct kernels' many small tiles left no such tails).
-# Not in the bf16 mode (31x56: 72.0 -> 83.4 ms, the bf16 pixel-reduction kernel and the convolutions then fight for LDS) and
-# not in bf16x6 (neutral, 910.5 vs 908.5 ms at C2).  `tools/side_stream_matrix.sh` is the measurement.
+# SIDE stream beside the convolutions of the data-gradient chain instead of between them.  Every kernel fills the 256 CUs,
+# but in ROUNDS of one tile per CU -- the F(4x4) convolution's 1 352 workgroup tiles of a 2B launch at 180x240 are 5.28 rounds,
+# so 186 CUs idle through the sixth, and every dependent launch has its drain and ramp -- and the other stream's workgroups take
+# exactly those CUs: 759 -> 742 ms at C2, 245.5 -> 231.0 ms at 90x120, 163.8 -> 152.7 ms at 64x96 (alternating runs on one box;
+# round 2 measured it neutral: the direct kernels' many small tiles left no such tails).  The stream has the device's lowest
+# priority (the data-gradient chain is the critical path: 745.5 vs 750.2 ms at the default priority).
+# Not below 2^14 pixels per launch: at 31x56 bs 4 and 45x80 bs 2 it is neutral on average and bimodal from run to run
+# (79.3 ... 86.8 ms against 82.2 / 82.7 ms on one stream; what it gained there in an earlier state, 87.9 -> 82.6 ms, was the
+# overlap of slab reductions that have since become 3x shorter).  Not in the bf16 mode (31x56: 66.3 -> 83.6 ms, the bf16
+# pixel-reduction kernel and the convolutions then fight for LDS), not in bf16x6 (neutral, 910.5 vs 908.5 ms at C2), and not
+# while a HIP graph is captured.  `tools/side_stream_matrix.sh` is the measurement.
 # Protocol: the side stream waits for the launch stream before every weight-gradient launch (its operands were just produced
 # there); the operand tensors are kept referenced until the join (small problems) or handed to the caching allocator with
 # record_stream (large ones: keeping every window's operands until the end of an 8-window backward would not fit); the join
@@ -664,7 +666,8 @@ def sink_group(params, full=True):
 # parameters' .grad (sink route): a gradient handed back to autograd stays on the launch stream.
 # Accumulation order into a .grad = issue order on the one side stream = backward's order: deterministic as before, and
 # bit-identical to the single-stream run (tests/test_gpu_r3.py, tests/test_gpu_r4.py).
-WGRAD_SIDE = os.environ.get("BMC_WGRAD_STREAM", "auto")          # "0" never, "1" always, "auto" (default) in the fp32 mode
+WGRAD_SIDE = os.environ.get("BMC_WGRAD_STREAM", "auto")          # "0" never, "1" always, "auto" (default): fp32 mode, launches of
+WGRAD_SIDE_MIN_PIXELS = int(os.environ.get("BMC_WGRAD_STREAM_MIN_PIXELS", 1 << 14))     # at least this many pixels (see above)
 WGRAD_SIDE_MAX_PIXELS = int(os.environ.get("BMC_WGRAD_STREAM_MAX_PIXELS", 1 << 17))     # operands kept (<=) or record_stream'ed (>)
 
 
@@ -749,7 +752,7 @@ def wgrad_side(npx, params, keep=()):
         # split over two streams
         # (not while a HIP graph is being captured: replaying the two-stream graph serialises badly -- 31x56: 174.9 ms against
         #  82.3 ms eager and 88 ms for the one-stream graph; "1" forces it)
-        st.side = WGRAD_SIDE == "1" or (MATH == 0 and not torch.cuda.is_current_stream_capturing())
+        st.side = WGRAD_SIDE == "1" or (MATH == 0 and npx >= WGRAD_SIDE_MIN_PIXELS and not torch.cuda.is_current_stream_capturing())
         torch.autograd.Variable._execution_engine.queue_callback(st.join)
         st.armed = True
     if not st.side:

@@ -548,7 +548,7 @@ def test_side_stream_weight_gradients_are_bit_identical(math):
         assert l0 == l1
         assert len(g0) == len(g1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
         assert all(torch.equal(a, b) for a, b in zip(p0, p1))
-    la, ga, pa = run("auto")         # 31x56: the automatic choice is the side stream
+    la, ga, pa = run("auto")         # (31x56: the automatic choice is one stream since round 4)
     assert la == l0 and all(torch.equal(a, b) for a, b in zip(ga, g0))
     assert ops._SIDE and not next(iter(ops._SIDE.values())).armed and not next(iter(ops._SIDE.values())).keep
 

@@ -168,7 +168,7 @@ def test_exact_zero_rule_keeps_reference_relu_gates(force_wino4):
 @pytest.mark.parametrize("keep_limit", [0, 1 << 30])
 def test_side_stream_weight_gradients_bit_identical_with_winograd_kernels(force_wino4, keep_limit):
     """Round 4: in the fp32 mode the weight-gradient kernels (pixel-reduction GEMM AND the Winograd weight gradient, with their
-    reductions) run on a second stream by default, at every frame size (bmc_hip.ops.wgrad_side).  The whole step -- loss, every
+    reductions) run on a second stream by default (bmc_hip.ops.wgrad_side; from 2^14 pixels per launch -- forced here).  The whole step -- loss, every
     parameter gradient, the parameters after three Adam steps -- must be bit-identical to the one-stream run, repeatedly, both
     when the operands are kept referenced until the join (keep_limit large) and when they are handed to the caching allocator
     with record_stream (keep_limit 0: the route of the large frames, where a use-after-reuse would show up here)."""
@@ -183,8 +183,8 @@ def test_side_stream_weight_gradients_bit_identical_with_winograd_kernels(force_
     gt = torch.poisson(torch.full((B, L, 2, scale * H, scale * W), 0.5), generator=g).to(dev)
 
     def run(mode):
-        old, old_lim = ops.WGRAD_SIDE, ops.WGRAD_SIDE_MAX_PIXELS
-        ops.WGRAD_SIDE, ops.WGRAD_SIDE_MAX_PIXELS = mode, keep_limit
+        old, old_lim, old_min = ops.WGRAD_SIDE, ops.WGRAD_SIDE_MAX_PIXELS, ops.WGRAD_SIDE_MIN_PIXELS
+        ops.WGRAD_SIDE, ops.WGRAD_SIDE_MAX_PIXELS, ops.WGRAD_SIDE_MIN_PIXELS = mode, keep_limit, 0     # (auto: at this test's size too)
         try:
             torch.manual_seed(192)
             m = BMCNet(scale, n_c, n_b).to(dev)
@@ -200,7 +200,7 @@ def test_side_stream_weight_gradients_bit_identical_with_winograd_kernels(force_
             ops.PROFILE = None
             return losses, [p.grad.clone() for p in m.parameters() if p.grad is not None], [p.detach().clone() for p in m.parameters()], kinds
         finally:
-            ops.WGRAD_SIDE, ops.WGRAD_SIDE_MAX_PIXELS = old, old_lim
+            ops.WGRAD_SIDE, ops.WGRAD_SIDE_MAX_PIXELS, ops.WGRAD_SIDE_MIN_PIXELS = old, old_lim, old_min
             ops.PROFILE = None
 
     assert ops.WGRAD_SIDE == "auto"                  # the shipped default
