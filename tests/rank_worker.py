@@ -56,6 +56,7 @@ def main():
     loss, _ = bptt_step(m, opt, si, sg, n_c, scale)
     torch.cuda.synchronize()
     np.savez(out, loss=float(loss), accum=int(ops.ACCUM_PARAM_GRADS), hook_launches=in_finish[0], nbuckets=len(red.buckets),
+             side_stream=int(any(st.side for st in ops._SIDE.values())),
              **{"g%03d" % i: (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().numpy()       # (None: a parameter
                 for i, p in enumerate(m.parameters())})                                                         #  the loss does not reach)
     dist.barrier()

@@ -25,12 +25,12 @@ def _free_port():
     return port
 
 
-def _run_ranks(tmp_path, tag, world, backend, devices, accum, batch=4):
+def _run_ranks(tmp_path, tag, world, backend, devices, accum, batch=4, side="auto"):
     port = _free_port()
     procs, outs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   BMC_ACCUM_GRADS=accum, HSA_ENABLE_IPC_MODE_LEGACY="0", BMC_RANK_TEST_B=str(batch))
+                   BMC_ACCUM_GRADS=accum, HSA_ENABLE_IPC_MODE_LEGACY="0", BMC_RANK_TEST_B=str(batch), BMC_WGRAD_STREAM=side)
         out = str(tmp_path / ("%s_rank%d.npz" % (tag, r)))
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "rank_worker.py"), out, backend, str(devices[r])],
@@ -57,15 +57,18 @@ def _full_batch_reference(dev):
     return loss.item(), [(p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().numpy() for p in m.parameters()]
 
 
-@pytest.mark.parametrize("accum", ["1", "0"])
-def test_two_ranks_on_one_gpu_hip_step_matches_full_batch(tmp_path, accum):
+@pytest.mark.parametrize("accum,side", [("1", "auto"), ("0", "auto"), ("1", "1")])
+def test_two_ranks_on_one_gpu_hip_step_matches_full_batch(tmp_path, accum, side):
     """world = 2 on the ONE GPU of the test box: two fresh processes on cuda:0, backend gloo (RCCL refuses two ranks on one
     device; the reducer moves its buckets through host memory for gloo), each running the real sharded step on the HIP
     kernels.  Everything of the N > 1 path except the RCCL transport: sequence sharding, kernel-side .grad accumulation
     (BMC_ACCUM_GRADS=1: no hook fires, finish() stages every bucket) or hook-driven buckets launched during backward
-    (BMC_ACCUM_GRADS=0), averaging, .grad views.  == the single-process full batch to 1e-4; ranks bit-equal."""
+    (BMC_ACCUM_GRADS=0), averaging, .grad views.  == the single-process full batch to 1e-4; ranks bit-equal.
+    side = "1": the weight-gradient kernels on the second stream (what large frames do by default; forced at this tiny size) --
+    the reducer must see the gradients only after the streams have joined."""
     dev = _gpu()
-    res = _run_ranks(tmp_path, "gloo%s" % accum, 2, "gloo", [0, 0], accum)
+    res = _run_ranks(tmp_path, "gloo%s%s" % (accum, side), 2, "gloo", [0, 0], accum, side=side)
+    assert all(bool(r["side_stream"]) == (side == "1") for r in res)
     loss, grads = _full_batch_reference(dev)
     assert all(int(r["accum"]) == int(accum) for r in res)
     assert abs(0.5 * (float(res[0]["loss"]) + float(res[1]["loss"])) - loss) < 1e-5 * abs(loss)
