@@ -35,6 +35,61 @@ CHAIN_IN_BF16X6 = os.environ.get("BMC_CHAIN_BF16X6", "1") != "0"
 FUSE_FIRST = os.environ.get("BMC_FUSE_FIRST", "1") != "0"      # BIEFirstFn for the last block's local BIE
 
 
+# Attention without the value tensor (fp32 arithmetic modes).  v = W_v x + b_v enters the BIE twice -- the Gram matrix
+# att = scale * c^T v and the product out = softmax(att) v -- and both are linear in v, so with G0 = c^T x (the same
+# pixel-reduction GEMM, on x instead of v) and s = the column sums of c (its bias slabs):
+#     att = scale * (G0 W_v^T + s b_v^T),        out = (P W_v) x + P b_v           (P = softmax(att), per sample)
+# i.e. v is never formed: the forward loses the value convolution, the backward loses its data-gradient convolution and its
+# weight-gradient GEMM (dW_v = P^T dM + da^T G0 from C x C matrices, dM = g_out^T x taking the place of g_out^T v), three of
+# the BIE's thirteen full-size 1x1 launches -- against a handful of C x C x C products per sample.  Same mathematics, another
+# order of summation (the parity bars of tests/parity_bars.py hold it); BMC_BIE_VFREE=0 restores the explicit form, which the
+# bf16 mode keeps (its operand-rounding oracle rounds v).
+VFREE = os.environ.get("BMC_BIE_VFREE", "1") != "0"
+
+
+def vfree_supported():
+    return VFREE and ops.MATH in (0, 3)
+
+
+def _gram_on_x(c_src, x_src, B, H, W, Cn, dev):
+    """-> (G0 [B,C,C], s [B,C]): G0_b = sum_px c_b[px,:]^T x_b[px,:], s_b = sum_px c_b[px,:] (one pixel-reduction launch per
+    sample group + its reduction; c_src / x_src: lib.Src over B launch batches)."""
+    slabs, nsplit, G, bsl = pgemm_raw(c_src, [x_src], B, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * B * H * W * Cn * Cn, want_bias=True)
+    G0 = torch.empty((B, Cn, Cn), device=dev, dtype=torch.float32)
+    sc = torch.empty((B, Cn), device=dev, dtype=torch.float32)
+    lib.call(lib._red_w, "bmc_pgemm_reduce_weight", slabs.data_ptr(), nsplit, G, 1, Cn, Cn, None, Cn, G0.data_ptr(), 0,
+             bsl.data_ptr(), sc.data_ptr(), _stream())
+    return G0, sc
+
+
+def _times_wt(m, vec, wg, bg, bpg, alpha, out):
+    """out[b] = alpha (m[b] W_g^T + vec[b] b_g^T)  (m [B,C,C], vec [B,C]; wg [G,C(j),C(k)], bg [G,C]; g = b // bpg): the Gram
+    matrix of the attention from G0 = center^T x, and dP from dM = g_out^T x."""
+    B, Cn, _ = m.shape
+    ops.small_mm([((m, Cn * Cn, 0, Cn, 1), (wg, 0, Cn * Cn, 1, Cn), None)], B, bpg, Cn, Cn, Cn, c=(out, Cn * Cn, 0, Cn, 1),
+                 alpha=alpha, uv=((vec, Cn, 0), (bg, 0, Cn)))
+    return out
+
+
+def _times_w(m, wg, bg, bpg, out, out_strides, vec=None):
+    """out[b][i][k] = sum_j m[b][i][j] W_g[j][k] (written with out_strides = (batch, i, k) strides: plain, into a column block
+    of a wider matrix, or transposed), vec[b][i] = sum_j m[b][i][j] b_g[j]."""
+    B, Cn, _ = m.shape
+    ops.small_mm([((m, Cn * Cn, 0, Cn, 1), (wg, 0, Cn * Cn, Cn, 1), (bg, 0, Cn, 1) if vec is not None else None)], B, bpg, Cn, Cn, Cn,
+                 c=(out, out_strides[0], 0, out_strides[1], out_strides[2]), vec_out=(vec, Cn, 0) if vec is not None else None)
+
+
+def _value_param_grads(p, dM, tg, da, G0, sc, groups):
+    """dW_v[g] = sum over the group's samples of P^T dM + da^T G0, db_v[g] = sum of P^T t + da^T s  ->  ([groups,C,C], [groups,C])."""
+    B, Cn, _ = p.shape
+    dw = torch.empty((B, Cn, Cn), device=p.device, dtype=torch.float32)
+    db = torch.empty((B, Cn), device=p.device, dtype=torch.float32)
+    cc = Cn * Cn
+    ops.small_mm([((p, cc, 0, 1, Cn), (dM, cc, 0, Cn, 1), (tg, Cn, 0, 1)), ((da, cc, 0, 1, Cn), (G0, cc, 0, Cn, 1), (sc, Cn, 0, 1))],
+                 B, 1, Cn, Cn, Cn, c=(dw, cc, 0, Cn, 1), vec_out=(db, Cn, 0))
+    return dw.view(groups, B // groups, Cn, Cn).sum(1), db.view(groups, B // groups, Cn).sum(1)
+
+
 def chain_supported(Cn):
     return FUSE_CHAIN and (ops.MATH == 0 or (ops.MATH == 3 and CHAIN_IN_BF16X6)) and Cn in (32, 64, 128)
 
@@ -196,22 +251,36 @@ class BIETwinFn(torch.autograd.Function):
                      y12.data_ptr(), stats.data_ptr(), _stream())
             _conv([X(y12)], d(wc).reshape(1, Cn, Cn, 1), s1, wc, d(bc), c12, B2)
         # values: v1 on the first half, v2 on the second (two weight groups)
-        v12 = new(B2)
         wv = ops.stacked((wv1, wv2), lambda: torch.stack([d(wv1).reshape(Cn, Cn, 1), d(wv2).reshape(Cn, Cn, 1)]), "v1x1")
         bv = ops.stacked((bv1, bv2), lambda: torch.stack([d(bv1), d(bv2)]), "stack")
-        _conv([X(x12)], wv, s1, wv, bv, v12, B2, bpg=n)
-        # channel attention per sample
-        slabs, nsplit, G = pgemm_raw(X(c12), [X(v12)], B2, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * B2 * H * W * Cn * Cn)
-        att = torch.empty((B2, Cn, Cn), device=dev, dtype=torch.float32)
-        lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, scale, att.data_ptr(), _stream())
-        p = torch.empty_like(att)
-        lib.call(lib._sm_fwd, "bmc_softmax_fwd", att.data_ptr(), B2 * Cn, Cn, p.data_ptr(), _stream())
+        vfree = vfree_supported()
         o12 = new(B2)
-        _conv([X(v12)], p.view(B2, Cn, Cn, 1), s1, None, None, o12, B2, residual=X(r12, shift=n, mod=B2), bpg=1)
+        if vfree:       # attention without v (above): att = scale (G0 W_v^T + s b_v^T), out = (P W_v) x + P b_v
+            G0, sc = _gram_on_x(X(c12), X(x12), B2, H, W, Cn, dev)
+            wg, v12 = wv.view(2, Cn, Cn), None
+            att = _times_wt(G0, sc, wg, bv, n, scale, torch.empty_like(G0))
+            p = torch.empty_like(att)
+            lib.call(lib._sm_fwd, "bmc_softmax_fwd", att.data_ptr(), B2 * Cn, Cn, p.data_ptr(), _stream())
+            pw, pb = torch.empty_like(p), torch.empty_like(sc)                                 # P W_v [b, i, k],  P b_v [b, i]
+            _times_w(p, wg, bv, n, pw, (Cn * Cn, Cn, 1), vec=pb)
+            _conv([X(x12)], pw.view(B2, Cn, Cn, 1), s1, None, pb, o12, B2, residual=X(r12, shift=n, mod=B2), bpg=1)
+        else:
+            G0 = sc = None
+            v12 = new(B2)
+            _conv([X(x12)], wv, s1, wv, bv, v12, B2, bpg=n)
+            # channel attention per sample
+            slabs, nsplit, G = pgemm_raw(X(c12), [X(v12)], B2, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * B2 * H * W * Cn * Cn)
+            att = torch.empty((B2, Cn, Cn), device=dev, dtype=torch.float32)
+            lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, scale, att.data_ptr(), _stream())
+            p = torch.empty_like(att)
+            lib.call(lib._sm_fwd, "bmc_softmax_fwd", att.data_ptr(), B2 * Cn, Cn, p.data_ptr(), _stream())
+            _conv([X(v12)], p.view(B2, Cn, Cn, 1), s1, None, None, o12, B2, residual=X(r12, shift=n, mod=B2), bpg=1)
         # shared stream: unclustering(cat[c1, c2]) + xs
         xs_new = new(n)
         _conv([X(c12, b0=0, B=n), X(c12, b0=n, B=n)], d(wu).reshape(1, Cn, 2 * Cn, 1), s2, wu, d(bu), xs_new, n, residual=X(xs))
-        ctx.save_for_backward(x12, xs, t12, z12, stats, y12, c12, v12, p, rw1, rw2, wf, gamma, wc, wu, wv1, wv2, beta)
+        ctx.save_for_backward(x12, xs, t12, z12, stats, y12, c12, v12 if not vfree else G0, p, rw1, rw2, wf, gamma, wc, wu, wv1, wv2, beta,
+                              *((sc, bv1, bv2) if vfree else ()))
+        ctx.vfree = vfree
         ctx.owners = (rw1, rw2, wf, wc, wu)
         ctx.params = (rw1, rb1, rw2, rb2, wf, bf, gamma, beta, wc, bc, wu, bu)     # the caller's objects (gradient sinks)
         ctx.vparams = (wv1, wv2, bv1, bv2)
@@ -222,7 +291,11 @@ class BIETwinFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, do12, dxs_new):
-        x12, xs, t12, z12, stats, y12, c12, v12, p, rw1, rw2, wf, gamma, wc, wu, wv1, wv2, beta = ctx.saved_tensors
+        saved = ctx.saved_tensors           # (once: a second access breaks torch.utils.checkpoint's unpack bookkeeping)
+        x12, xs, t12, z12, stats, y12, c12, v12, p, rw1, rw2, wf, gamma, wc, wu, wv1, wv2, beta = saved[:18]
+        vfree = ctx.vfree
+        if vfree:
+            G0, (sc, bv1, bv2) = v12, saved[18:]
         o_rw1, o_rw2, o_wf, o_wc, o_wu = ctx.owners
         p_rw1, p_rb1, p_rw2, p_rb2, p_wf, p_bf, p_gamma, p_beta, p_wc, p_bc, p_wu, p_bu = ctx.params
         B2, H, W, Cn = x12.shape
@@ -239,27 +312,52 @@ class BIETwinFn(torch.autograd.Function):
         w_v = ops.stacked(ctx.vparams[:2], lambda: torch.stack([wv1.detach().reshape(Cn, Cn, 1), wv2.detach().reshape(Cn, Cn, 1)]), "v1x1")
 
         # ---- out = P v (+ rotated residual): dP, dv
-        slabs, nsplit, G = pgemm_raw(X(g_o), [X(v12)], B2, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * B2 * H * W * Cn * Cn)
-        dp = torch.empty_like(p)
-        lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, 1.0, dp.data_ptr(), _stream())
+        if vfree:       # dM = g_o^T x, t = column sums of g_o;  dP = dM W_v^T + t b_v^T
+            wg = w_v.view(2, Cn, Cn)
+            bg = ops.stacked(ctx.vparams[2:], lambda: torch.stack([bv1.detach(), bv2.detach()]), "stack")
+            dM, tg = _gram_on_x(X(g_o), X(x12), B2, H, W, Cn, dev)
+            dp = _times_wt(dM, tg, wg, bg, n, 1.0, torch.empty_like(dM))
+        else:
+            slabs, nsplit, G = pgemm_raw(X(g_o), [X(v12)], B2, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * B2 * H * W * Cn * Cn)
+            dp = torch.empty_like(p)
+            lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, 1.0, dp.data_ptr(), _stream())
         # ---- softmax, Gram (att = scale * center v^T)
         da = torch.empty_like(p)
         lib.call(lib._sm_bwd, "bmc_softmax_bwd", p.data_ptr(), dp.data_ptr(), B2 * Cn, Cn, ctx.scale, da.data_ptr(), _stream())
+        if vfree:
+            # value-convolution parameters: dW_v = P^T dM + da^T G0, db_v = P^T t + da^T s (summed over the group's samples)
+            dwv, dbv = _value_param_grads(p, dM, tg, da, G0, sc, 2)
         # Each of dv and d center has two contributions that are 1x1 products with per-sample / per-half matrices: ONE
         # two-source launch each (K = 2C, the matrices side by side) instead of a launch + accumulating launches --
         #   dv[b]      = P_b^T g_o[b] + da_b^T center[b]
         #   dcenter[b] = da_b  v[b]   + W_u[:, half(b)]^T g_x[b mod n]            (unclustering reads cat[c1, c2])
-        dv12, dc12 = new(B2), new(B2)
-        w_dv = torch.cat([p.transpose(1, 2), da.transpose(1, 2)], 2).view(B2, Cn, 2 * Cn, 1)
-        _conv([X(g_o), X(c12)], w_dv, s2, None, None, dv12, B2, bpg=1)
+        dc12 = new(B2)
         w_ut = wu.detach().view(Cn, 2, Cn).permute(1, 2, 0).repeat_interleave(n, 0)           # [B2, C (c_i), C (co)]
-        w_dc = torch.cat([da, w_ut], 2).view(B2, Cn, 2 * Cn, 1)
-        _conv([X(v12), X(g_x, mod=n, B=B2)], w_dc, s2, None, None, dc12, B2, bpg=1)
+        if vfree:
+            # without v:  dx12 (+)= (P W_v)^T g_o + (da W_v)^T center  (below, once dx12 exists);
+            #             dcenter = (da W_v) x + da b_v + W_u[:, half]^T g_x
+            # the per-sample matrices are written straight into the two-source weight layouts [b][cout][cin of source 0 | 1]
+            w_dx = torch.empty((B2, Cn, 2 * Cn, 1), device=dev, dtype=torch.float32)
+            w_dc = torch.empty((B2, Cn, 2 * Cn, 1), device=dev, dtype=torch.float32)
+            w_dc.view(B2, Cn, 2 * Cn)[:, :, Cn:] = w_ut
+            ds = torch.empty((B2, Cn), device=dev, dtype=torch.float32)
+            cc2 = 2 * Cn * Cn
+            _times_w(da, wg, bg, n, w_dc, (cc2, 2 * Cn, 1), vec=ds)                            # [da W_v | .],  da b_v
+            _times_w(da, wg, bg, n, w_dx[:, :, Cn:], (cc2, 1, 2 * Cn))                         # [. | (da W_v)^T]
+            _times_w(p, wg, bg, n, w_dx, (cc2, 1, 2 * Cn))                                     # [(P W_v)^T | .]
+            _conv([X(x12), X(g_x, mod=n, B=B2)], w_dc, s2, None, ds, dc12, B2, bpg=1)
+        else:
+            dv12 = new(B2)
+            w_dv = torch.cat([p.transpose(1, 2), da.transpose(1, 2)], 2).view(B2, Cn, 2 * Cn, 1)
+            _conv([X(g_o), X(c12)], w_dv, s2, None, None, dv12, B2, bpg=1)
+            w_dc = torch.cat([da, w_ut], 2).view(B2, Cn, 2 * Cn, 1)
+            _conv([X(v12), X(g_x, mod=n, B=B2)], w_dc, s2, None, None, dc12, B2, bpg=1)
         # ---- unclustering(cat[c1, c2]) + xs: weight gradient
         dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu, keep=(g_x, c12))
         # ---- value convs (two weight groups)
-        dwv, dbv = _wgrad(X(dv12), [X(x12)], s1, B2, H, W, 1, Cn, dev, ctx.vparams[:2], ctx.vparams[2:], G=2,
-                          w_shape=(2, Cn, Cn, 1, 1), keep=(dv12, x12))
+        if not vfree:
+            dwv, dbv = _wgrad(X(dv12), [X(x12)], s1, B2, H, W, 1, Cn, dev, ctx.vparams[:2], ctx.vparams[2:], G=2,
+                              w_shape=(2, Cn, Cn, 1, 1), keep=(dv12, x12))
         if ctx.fused:
             # ---- clustering, LayerNorm, convf: ONE data-gradient launch (csrc/chain.hip); y12 holds yhat, stats rstd.
             # dx12 = conv_f^T (second half of its inputs), dxs = skip + conv_f^T (first half) summed over both halves.
@@ -281,10 +379,16 @@ class BIETwinFn(torch.autograd.Function):
                      o_b.data_ptr() if o_b is not None else None, o_g.data_ptr(), o_bt.data_ptr(), acc, _stream())
             dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf,
                               keep=(dz12, xs, x12))
-            _dgrad(X(dv12), w_v, s1, 0, w_v, dx12, B2, bpg=n, accumulate=True)                          # dx12 += value convs
+            if vfree:
+                _conv([X(g_o), X(c12)], w_dx, s2, None, None, dx12, B2, bpg=1, accumulate=True)         # dx12 += attention
+            else:
+                _dgrad(X(dv12), w_v, s1, 0, w_v, dx12, B2, bpg=n, accumulate=True)                      # dx12 += value convs
         else:
             dx12 = ops.grad_slot(ctx.gslot, x12)
-            _dgrad(X(dv12), w_v, s1, 0, w_v, dx12, B2, bpg=n)                                           # dx12  =
+            if vfree:
+                _conv([X(g_o), X(c12)], w_dx, s2, None, None, dx12, B2, bpg=1)
+            else:
+                _dgrad(X(dv12), w_v, s1, 0, w_v, dx12, B2, bpg=n)                                       # dx12  =
             # ---- clustering, LayerNorm, convf
             dwc, dbc = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev, p_wc, p_bc, keep=(dc12, y12))
             dy12 = new(B2)
@@ -343,18 +447,32 @@ class BIEFirstFn(torch.autograd.Function):
         _conv([X(t2)], d(rw2).reshape(1, Cn, Cn, 9), s1, rw2, d(rb2), r2, n, residual=second)
         yhat, rstd, c12 = chain_fwd(X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2), wf, d(bf), d(gamma), d(beta), wc, d(bc), eps,
                                     B2, H, W, Cn, dev)
-        v1 = new(n)
-        _conv([X(x12, b0=0, B=n)], d(wv1).reshape(1, Cn, Cn, 1), s1, wv1, d(bv1), v1, n)
-        slabs, nsplit, G = pgemm_raw(X(c12, b0=0, B=n), [X(v1)], n, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * n * H * W * Cn * Cn)
-        att = torch.empty((n, Cn, Cn), device=dev, dtype=torch.float32)
-        lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, scale, att.data_ptr(), _stream())
-        p = torch.empty_like(att)
-        lib.call(lib._sm_fwd, "bmc_softmax_fwd", att.data_ptr(), n * Cn, Cn, p.data_ptr(), _stream())
+        vfree = vfree_supported()
         o1 = new(n)
-        _conv([X(v1)], p.view(n, Cn, Cn, 1), s1, None, None, o1, n, residual=X(r2), bpg=1)
+        if vfree:       # attention without v (top of this file)
+            G0, sc = _gram_on_x(X(c12, b0=0, B=n), X(x12, b0=0, B=n), n, H, W, Cn, dev)
+            wg, bg, v1 = d(wv1).reshape(1, Cn, Cn), d(bv1).reshape(1, Cn), None
+            att = _times_wt(G0, sc, wg, bg, n, scale, torch.empty_like(G0))
+            p = torch.empty_like(att)
+            lib.call(lib._sm_fwd, "bmc_softmax_fwd", att.data_ptr(), n * Cn, Cn, p.data_ptr(), _stream())
+            pw, pb = torch.empty_like(p), torch.empty_like(sc)
+            _times_w(p, wg, bg, n, pw, (Cn * Cn, Cn, 1), vec=pb)
+            _conv([X(x12, b0=0, B=n)], pw.view(n, Cn, Cn, 1), s1, None, pb, o1, n, residual=X(r2), bpg=1)
+        else:
+            G0 = sc = None
+            v1 = new(n)
+            _conv([X(x12, b0=0, B=n)], d(wv1).reshape(1, Cn, Cn, 1), s1, wv1, d(bv1), v1, n)
+            slabs, nsplit, G = pgemm_raw(X(c12, b0=0, B=n), [X(v1)], n, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * n * H * W * Cn * Cn)
+            att = torch.empty((n, Cn, Cn), device=dev, dtype=torch.float32)
+            lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, scale, att.data_ptr(), _stream())
+            p = torch.empty_like(att)
+            lib.call(lib._sm_fwd, "bmc_softmax_fwd", att.data_ptr(), n * Cn, Cn, p.data_ptr(), _stream())
+            _conv([X(v1)], p.view(n, Cn, Cn, 1), s1, None, None, o1, n, residual=X(r2), bpg=1)
         xs_new = new(n)
         _conv([X(c12, b0=0, B=n), X(c12, b0=n, B=n)], d(wu).reshape(1, Cn, 2 * Cn, 1), s2, wu, d(bu), xs_new, n, residual=X(xs))
-        ctx.save_for_backward(x12, xs, t2, yhat, rstd, c12, v1, p, rw1, rw2, wf, gamma, wc, wu, wv1, beta)
+        ctx.save_for_backward(x12, xs, t2, yhat, rstd, c12, v1 if not vfree else G0, p, rw1, rw2, wf, gamma, wc, wu, wv1, beta,
+                              *((sc, bv1) if vfree else ()))
+        ctx.vfree = vfree
         ctx.owners = (rw1, rw2, wf, wc, wu, wv1)
         ctx.params = (rw1, rb1, rw2, rb2, wf, bf, gamma, beta, wc, bc, wu, bu, wv1, bv1)     # the caller's objects (gradient sinks)
         ctx.scale = scale
@@ -362,7 +480,11 @@ class BIEFirstFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, do1, dxs_new):
-        x12, xs, t2, yhat, rstd, c12, v1, p, rw1, rw2, wf, gamma, wc, wu, wv1, beta = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        x12, xs, t2, yhat, rstd, c12, v1, p, rw1, rw2, wf, gamma, wc, wu, wv1, beta = saved[:16]
+        vfree = ctx.vfree
+        if vfree:
+            G0, (sc, bv1) = v1, saved[16:]
         o_rw1, o_rw2, o_wf, o_wc, o_wu, o_wv1 = ctx.owners
         p_rw1, p_rb1, p_rw2, p_rb2, p_wf, p_bf, p_gamma, p_beta, p_wc, p_bc, p_wu, p_bu, p_wv1, p_bv1 = ctx.params
         B2, H, W, Cn = x12.shape
@@ -371,26 +493,47 @@ class BIEFirstFn(torch.autograd.Function):
         s1, s2 = _dense_spec(Cn), _spec2(Cn)
         new = lambda b: torch.empty((b, H, W, Cn), device=dev, dtype=torch.float32)
         X = lambda t, **k: _src(t, 0, Cn, k.get("shift", 0), k.get("mod"), k.get("b0", 0), k.get("B", t.shape[0]))
-        g_o = do1.contiguous() if do1 is not None else torch.zeros_like(v1)
+        g_o = do1.contiguous() if do1 is not None else torch.zeros_like(t2)
         g_x = dxs_new.contiguous() if dxs_new is not None else torch.zeros_like(xs)
         w_r1, w_r2 = rw1.detach().reshape(1, Cn, Cn, 9), rw2.detach().reshape(1, Cn, Cn, 9)
         w_v1 = wv1.detach().reshape(1, Cn, Cn, 1)
         # ---- o1 = P v1 + r2: dP, softmax, Gram
-        slabs, nsplit, G = pgemm_raw(X(g_o), [X(v1)], n, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * n * H * W * Cn * Cn)
-        dp = torch.empty_like(p)
-        lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, 1.0, dp.data_ptr(), _stream())
+        if vfree:
+            wg, bg = wv1.detach().reshape(1, Cn, Cn), bv1.detach().reshape(1, Cn)
+            dM, tg = _gram_on_x(X(g_o), X(x12, b0=0, B=n), n, H, W, Cn, dev)
+            dp = _times_wt(dM, tg, wg, bg, n, 1.0, torch.empty_like(dM))
+        else:
+            slabs, nsplit, G = pgemm_raw(X(g_o), [X(v1)], n, H, W, 1, 1, Cn, Cn, dev, flops=2.0 * n * H * W * Cn * Cn)
+            dp = torch.empty_like(p)
+            lib.call(lib._red_p, "bmc_pgemm_reduce_plain", slabs.data_ptr(), nsplit, G, Cn, Cn, 1.0, dp.data_ptr(), _stream())
         da = torch.empty_like(p)
         lib.call(lib._sm_bwd, "bmc_softmax_bwd", p.data_ptr(), dp.data_ptr(), n * Cn, Cn, ctx.scale, da.data_ptr(), _stream())
+        if vfree:
+            dwv1, dbv1 = _value_param_grads(p, dM, tg, da, G0, sc, 1)
+            dwv1, dbv1 = dwv1.view(wv1.shape), dbv1.view(Cn)
         #   dv1[b]     = P_b^T g_o[b] + da_b^T c1[b]
         #   dcentre[b] = (b < n: da_b v1[b]) + W_u[:, half(b)]^T g_x[b mod n]     (the second half has no attention term: a zero matrix)
-        dv1, dc12 = new(n), new(B2)
-        w_dv = torch.cat([p.transpose(1, 2), da.transpose(1, 2)], 2).view(n, Cn, 2 * Cn, 1)
-        _conv([X(g_o), X(c12, b0=0, B=n)], w_dv, s2, None, None, dv1, n, bpg=1)
+        dc12 = new(B2)
         w_ut = wu.detach().view(Cn, 2, Cn).permute(1, 2, 0).repeat_interleave(n, 0)           # [B2, C (c_i), C (co)]
-        w_dc = torch.cat([torch.cat([da, torch.zeros_like(da)], 0), w_ut], 2).view(B2, Cn, 2 * Cn, 1)
-        _conv([X(v1, mod=n, B=B2), X(g_x, mod=n, B=B2)], w_dc, s2, None, None, dc12, B2, bpg=1)
+        if vfree:       # (as in BIETwinFn; the second half has no attention term: zero matrix, zero bias)
+            w_dx = torch.empty((n, Cn, 2 * Cn, 1), device=dev, dtype=torch.float32)
+            w_dc = torch.zeros((B2, Cn, 2 * Cn, 1), device=dev, dtype=torch.float32)
+            w_dc.view(B2, Cn, 2 * Cn)[:, :, Cn:] = w_ut
+            ds = torch.zeros((B2, Cn), device=dev, dtype=torch.float32)
+            cc2 = 2 * Cn * Cn
+            _times_w(da, wg, bg, n, w_dc, (cc2, 2 * Cn, 1), vec=ds)                            # (first n samples; the rest stay zero)
+            _times_w(da, wg, bg, n, w_dx[:, :, Cn:], (cc2, 1, 2 * Cn))
+            _times_w(p, wg, bg, n, w_dx, (cc2, 1, 2 * Cn))
+            _conv([X(x12), X(g_x, mod=n, B=B2)], w_dc, s2, None, ds, dc12, B2, bpg=1)
+        else:
+            dv1 = new(n)
+            w_dv = torch.cat([p.transpose(1, 2), da.transpose(1, 2)], 2).view(n, Cn, 2 * Cn, 1)
+            _conv([X(g_o), X(c12, b0=0, B=n)], w_dv, s2, None, None, dv1, n, bpg=1)
+            w_dc = torch.cat([torch.cat([da, torch.zeros_like(da)], 0), w_ut], 2).view(B2, Cn, 2 * Cn, 1)
+            _conv([X(v1, mod=n, B=B2), X(g_x, mod=n, B=B2)], w_dc, s2, None, None, dc12, B2, bpg=1)
         dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu, keep=(g_x, c12))
-        dwv1, dbv1 = _wgrad(X(dv1), [X(x12, b0=0, B=n)], s1, n, H, W, 1, Cn, dev, p_wv1, p_bv1, keep=(dv1, x12))
+        if not vfree:
+            dwv1, dbv1 = _wgrad(X(dv1), [X(x12, b0=0, B=n)], s1, n, H, W, 1, Cn, dev, p_wv1, p_bv1, keep=(dv1, x12))
         # ---- clustering, LayerNorm, convf (csrc/chain.hip), as in BIETwinFn
         dz12, dx12, dxs = chain_bwd(X(dc12), yhat, rstd, gamma.detach(), wf, wc, X(g_x), n, H, W, Cn, dev)
         Gm, dbc_t = _wgrad(X(dc12), [X(yhat)], s1, B2, H, W, 1, Cn, dev, None, None, w_shape=(Cn, Cn))
@@ -408,7 +551,10 @@ class BIEFirstFn(torch.autograd.Function):
                  o_b.data_ptr() if o_b is not None else None, o_g.data_ptr(), o_bt.data_ptr(), acc, _stream())
         dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf,
                           keep=(dz12, xs, x12))
-        _dgrad(X(dv1), w_v1, s1, 0, o_wv1, dx12, n, accumulate=True)                                     # dx12[first] += value conv
+        if vfree:
+            _conv([X(g_o), X(c12, b0=0, B=n)], w_dx, s2, None, None, dx12, n, bpg=1, accumulate=True)    # dx12[first] += attention
+        else:
+            _dgrad(X(dv1), w_v1, s1, 0, o_wv1, dx12, n, accumulate=True)                                 # dx12[first] += value conv
         # ---- residual block (second half), upstream gradient = g_o
         dw2, db2 = _wgrad(X(g_o), [X(t2)], s1, n, H, W, 9, Cn, dev, p_rw2, p_rb2, keep=(g_o, t2))
         dt = new(n)

@@ -59,6 +59,21 @@ class ChainBwdArgs(C.Structure):
                 ("H", C.c_int), ("W", C.c_int)]
 
 
+class MmTerm(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("a_sb", C.c_longlong), ("a_sg", C.c_longlong), ("a_si", C.c_int), ("a_sk", C.c_int),
+                ("b", C.c_void_p), ("b_sb", C.c_longlong), ("b_sg", C.c_longlong), ("b_sk", C.c_int), ("b_sj", C.c_int),
+                ("w", C.c_void_p), ("w_sb", C.c_longlong), ("w_sg", C.c_longlong), ("w_sk", C.c_int)]
+
+
+class SmallMmArgs(C.Structure):
+    _fields_ = [("nterms", C.c_int), ("t", MmTerm * 2), ("nbatch", C.c_int), ("batch_per_group", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("alpha", C.c_float),
+                ("u", C.c_void_p), ("u_sb", C.c_longlong), ("u_sg", C.c_longlong),
+                ("v", C.c_void_p), ("v_sb", C.c_longlong), ("v_sg", C.c_longlong),
+                ("c", C.c_void_p), ("c_sb", C.c_longlong), ("c_sg", C.c_longlong), ("c_si", C.c_int), ("c_sj", C.c_int),
+                ("vec_out", C.c_void_p), ("vo_sb", C.c_longlong), ("vo_sg", C.c_longlong), ("accumulate", C.c_int)]
+
+
 def _sig(name, argtypes, restype=C.c_int):
     fn = getattr(_lib, name)
     fn.argtypes = argtypes
@@ -88,6 +103,7 @@ _pack_wino = _sig("bmc_pack_weight_wino", [_p, _p, _i, _i, _i, _i, _i, _i, _i, _
 _pack_wino4 = _sig("bmc_pack_weight_wino4", [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p])
 _ww_nsplit = _sig("bmc_wgrad_wino_nsplit", [_i, _i, _i])
 _stream_low = _sig("bmc_stream_create_low_priority", [C.POINTER(C.c_void_p)])
+_small_mm = _sig("bmc_small_mm", [C.POINTER(SmallMmArgs), _p])
 _ww = _sig("bmc_wgrad_wino", [C.POINTER(Src), C.POINTER(Src), _i, _i, _i, _i, _p, _p, _p])
 _ww_red = _sig("bmc_wgrad_wino_reduce", [_p, _i, _p, _i, _i, _i, _p, _p, _p])
 _split_w = _sig("bmc_split_weight", [_p, _p, _ll, _i, _i, _p])
@@ -123,7 +139,7 @@ EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_event
            "bmc_pgemm_reduce_weight_groups", "bmc_events_binned_ws_bytes", "bmc_events_to_channels_binned",
            "bmc_encode_raw_events_binned", "bmc_pack_weight_wino", "bmc_pack_weight_wino4", "bmc_wgrad_wino_nsplit", "bmc_wgrad_wino",
            "bmc_wgrad_wino_reduce", "bmc_events_torch_ws_ints", "bmc_events_to_image_torch",
-           "bmc_events_to_voxel_torch", "bmc_stream_create_low_priority"]
+           "bmc_events_to_voxel_torch", "bmc_stream_create_low_priority", "bmc_small_mm"]
 
 
 def check(rc, what):

@@ -643,6 +643,35 @@ def sink_group(params, full=True):
 
 
 # --------------------------------------------------------------------------
+# batched C x C products (csrc/smallmm.hip): the BIE's attention without the value tensor (bie.py)
+# --------------------------------------------------------------------------
+def small_mm(terms, nbatch, bpg, M, N, K, c=None, alpha=1.0, uv=None, vec_out=None, accumulate=False):
+    """C[b][i][j] (=|+=) alpha (sum_t A_t[b] B_t[b] + u[b] v[b]^T), vec[b][i] (=|+=) alpha sum_t A_t[b] w_t[b]  (include/bmc_hip.h:
+    bmc_small_mm).  Operands are (tensor, batch stride, group stride, stride, stride) tuples in floats -- tensor may be a view, its
+    storage offset is honoured:
+        terms:   [(A, B, w or None), ...]   A = (t, sb, sg, s_i, s_k), B = (t, sb, sg, s_k, s_j), w = (t, sb, sg, s_k)
+        c:       (t, sb, sg, s_i, s_j) or None;   uv: ((u, sb, sg), (v, sb, sg)) or None;   vec_out: (t, sb, sg) or None"""
+    a = lib.SmallMmArgs()
+    a.nterms = len(terms)
+    for i, (A, B, w) in enumerate(terms):
+        t = a.t[i]
+        t.a, t.a_sb, t.a_sg, t.a_si, t.a_sk = A[0].data_ptr(), A[1], A[2], A[3], A[4]
+        t.b, t.b_sb, t.b_sg, t.b_sk, t.b_sj = B[0].data_ptr(), B[1], B[2], B[3], B[4]
+        if w is not None:
+            t.w, t.w_sb, t.w_sg, t.w_sk = w[0].data_ptr(), w[1], w[2], w[3]
+    a.nbatch, a.batch_per_group, a.M, a.N, a.K, a.alpha = nbatch, bpg, M, N, K, alpha
+    if uv is not None:
+        (u, usb, usg), (v, vsb, vsg) = uv
+        a.u, a.u_sb, a.u_sg, a.v, a.v_sb, a.v_sg = u.data_ptr(), usb, usg, v.data_ptr(), vsb, vsg
+    if c is not None:
+        a.c, a.c_sb, a.c_sg, a.c_si, a.c_sj = c[0].data_ptr(), c[1], c[2], c[3], c[4]
+    if vec_out is not None:
+        a.vec_out, a.vo_sb, a.vo_sg = vec_out[0].data_ptr(), vec_out[1], vec_out[2]
+    a.accumulate = int(accumulate)
+    lib.call(lib._small_mm, "bmc_small_mm", C.byref(a), _stream())
+
+
+# --------------------------------------------------------------------------
 # weight gradients beside the data-gradient chain
 # --------------------------------------------------------------------------
 # Nothing in backward waits for a weight gradient: it only has to be in .grad when the optimizer steps.  So the weight-gradient

@@ -1,0 +1,109 @@
+// Batched products of the BIE's C x C matrices (include/bmc_hip.h: bmc_small_mm).
+//
+// The attention of a BIE (reference models/submodules.py:66-73) is evaluated without the value tensor (bmc_hip/bie.py): what
+// remains of the value convolution are products of per-sample C x C matrices with the C x C weight matrix of the sample's
+// weight group -- att = scale (G0 W^T + s b^T), P W, da W, P^T dM + da^T G0, ... -- 16 samples of 128^3 multiply-adds each: work
+// for microseconds, where the cost is the NUMBER of launches (eight library GEMMs, their bias / outer-product updates and the
+// transposes and concatenations around them were ~25 launches per BIE and 17 ms per step).  One kernel with strided operands
+// covers them all:
+//     C[b][i][j]  (=|+=) alpha * ( sum_t sum_k A_t[b][i][k] B_t[b][k][j]  +  u[b][i] v[b][j] )
+//     vec[b][i]   (=|+=) alpha *   sum_t sum_k A_t[b][i][k] w_t[b][k]
+// t = 1 or 2 terms; every operand is addressed as base + b * batch_stride + (b / batch_per_group) * group_stride + row and
+// column strides, so transposes, per-group weights, and writes into a column range of a wider matrix (the concatenated
+// per-sample weights of the following 1x1 launch) cost nothing.
+// One workgroup = one 32 x 32 tile of one batch, 256 threads x (2 x 2) outputs, K in steps of 32 through LDS; plain fp32 FMAs in
+// a fixed order (deterministic; no matrix cores: 4 MFLOP per tile).
+#include "bmc_common.h"
+
+namespace {
+
+struct MmK { bmc_small_mm_args_t a; };
+
+constexpr int T = 32;
+
+__device__ __forceinline__ const float* opbase(const float* p, long long sb, long long sg, int b, int g) {
+    return p + (long long)b * sb + (long long)g * sg;
+}
+
+__global__ __launch_bounds__(256) void small_mm_kernel(const MmK k) {
+    const bmc_small_mm_args_t& a = k.a;
+    __shared__ float As[T][T + 1], Bs[T][T + 1], ws[T];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int b = blockIdx.z, g = b / a.batch_per_group;
+    const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, vacc[2] = {0.f, 0.f};
+    const bool want_vec = a.vec_out != nullptr && blockIdx.x == 0;
+    for (int t = 0; t < a.nterms; ++t) {
+        const bmc_mm_term_t& m = a.t[t];
+        const float* A = opbase(m.a, m.a_sb, m.a_sg, b, g);
+        const float* B = opbase(m.b, m.b_sb, m.b_sg, b, g);
+        const float* Wv = m.w ? opbase(m.w, m.w_sb, m.w_sg, b, g) : nullptr;
+        for (int k0 = 0; k0 < a.K; k0 += T) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = tid + 256 * q, hi = e >> 5, lo = e & 31;
+                // the unit-stride index runs fastest over the lanes
+                const int ai = m.a_sk == 1 ? hi : lo, ak = m.a_sk == 1 ? lo : hi;
+                As[ai][ak] = (i0 + ai < a.M && k0 + ak < a.K) ? ldg4(A + (long long)(i0 + ai) * m.a_si + (long long)(k0 + ak) * m.a_sk) : 0.f;
+                const int bk = m.b_sj == 1 ? hi : lo, bj = m.b_sj == 1 ? lo : hi;
+                Bs[bk][bj] = (k0 + bk < a.K && j0 + bj < a.N) ? ldg4(B + (long long)(k0 + bk) * m.b_sk + (long long)(j0 + bj) * m.b_sj) : 0.f;
+            }
+            if (want_vec && Wv && tid < T) ws[tid] = k0 + tid < a.K ? ldg4(Wv + (long long)(k0 + tid) * m.w_sk) : 0.f;
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < T; ++kk) {
+                const float a0 = As[2 * ty][kk], a1 = As[2 * ty + 1][kk];
+                const float b0 = Bs[kk][2 * tx], b1 = Bs[kk][2 * tx + 1];
+                acc[0][0] += a0 * b0; acc[0][1] += a0 * b1;
+                acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+                if (want_vec && Wv) { vacc[0] += a0 * ws[kk]; vacc[1] += a1 * ws[kk]; }
+            }
+            __syncthreads();
+        }
+    }
+    const float* u = a.u ? a.u + (long long)b * a.u_sb + (long long)g * a.u_sg : nullptr;
+    const float* v = a.v ? a.v + (long long)b * a.v_sb + (long long)g * a.v_sg : nullptr;
+    float* C = a.c ? a.c + (long long)b * a.c_sb + (long long)g * a.c_sg : nullptr;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = i0 + 2 * ty + r;
+        if (i >= a.M) continue;
+        if (C) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int j = j0 + 2 * tx + c;
+                if (j >= a.N) continue;
+                float val = acc[r][c];
+                if (u) val += ldg4(u + i) * ldg4(v + j);
+                val *= a.alpha;
+                float* o = C + (long long)i * a.c_si + (long long)j * a.c_sj;
+                *o = a.accumulate ? *o + val : val;
+            }
+        }
+        if (want_vec && tx == 0) {
+            float* o = a.vec_out + (long long)b * a.vo_sb + (long long)g * a.vo_sg + i;
+            const float val = a.alpha * vacc[r];
+            *o = a.accumulate ? *o + val : val;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int bmc_small_mm(const bmc_small_mm_args_t* host_args, bmc_stream_t stream) {
+    BMC_CHECK_ARG(host_args, "bmc_small_mm: null arguments");
+    const bmc_small_mm_args_t& a = *host_args;
+    BMC_CHECK_ARG(a.nterms >= 1 && a.nterms <= 2 && a.nbatch >= 1 && a.batch_per_group >= 1 && a.M >= 1 && a.N >= 1 && a.K >= 1,
+                  "bmc_small_mm: bad sizes (terms %d, batch %d / %d, M %d N %d K %d)", a.nterms, a.nbatch, a.batch_per_group, a.M, a.N, a.K);
+    BMC_CHECK_ARG(a.c || a.vec_out, "bmc_small_mm: no output");
+    BMC_CHECK_ARG((a.u == nullptr) == (a.v == nullptr), "bmc_small_mm: u and v go together");
+    for (int t = 0; t < a.nterms; ++t)
+        BMC_CHECK_ARG(a.t[t].a && a.t[t].b && (!a.vec_out || a.t[t].w), "bmc_small_mm: term %d: null operand (vec_out needs w in every term)", t);
+    BMC_CHECK_ARG(a.nbatch <= 65535, "bmc_small_mm: more than 65535 batches");
+    MmK k;
+    k.a = a;
+    dim3 grid((unsigned)((a.N + T - 1) / T), (unsigned)((a.M + T - 1) / T), (unsigned)a.nbatch);
+    hipLaunchKernelGGL(small_mm_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
+    BMC_CHECK_LAUNCH("bmc_small_mm");
+    return 0;
+}

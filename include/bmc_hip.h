@@ -369,6 +369,38 @@ int bmc_chain_bwd(const bmc_chain_bwd_args_t* host_args, bmc_stream_t s);
 int bmc_chain_affine_grads(const float* G, const float* dbc, const float* Wc, const float* gamma, const float* beta, int C,
                            float* dwc, float* dbc_out, float* dgamma, float* dbeta, int accumulate, bmc_stream_t s);
 
+/* ---- batched products of C x C matrices: the BIE's attention without the value tensor --------------------------------
+ * models/submodules.py:63-73 computes v = conv1x1(x) and uses it twice, att = scale * bmm(center, v^T) and
+ * out = bmm(softmax(att), v).  Both are linear in v = W_v x + b_v, so with G0 = center^T x and s = the column sums of center
+ * (one bmc_pgemm launch with bias slabs on x instead of v)
+ *     att = scale * (G0 W_v^T + s b_v^T),     out = (P W_v) x + P b_v
+ * and v is never formed (bmc_hip/bie.py); the backward likewise needs only C x C matrices.  This entry point evaluates
+ * those products for all samples in one launch:
+ *     C[b][i][j]  (=|+=) alpha * ( sum_t sum_k A_t[b][i][k] B_t[b][k][j]  +  u[b][i] v[b][j] )
+ *     vec[b][i]   (=|+=) alpha *   sum_t sum_k A_t[b][i][k] w_t[b][k]
+ * for b < nbatch, i < M, j < N, k < K; t < nterms (1 or 2).  Every operand X of batch b (weight group g = b / batch_per_group)
+ * starts at X.ptr + b * X_sb + g * X_sg (floats) and is indexed with its own row / column strides: transposed and per-group
+ * operands, and results written into a column range of a wider matrix, need no copies.  u / v (together) and vec_out (with a w
+ * in every term) are optional; c may be NULL when only vec_out is wanted.  fp32 FMAs in a fixed order. */
+typedef struct {
+    const float* a; long long a_sb, a_sg; int a_si, a_sk;   /* A[b][i][k] */
+    const float* b; long long b_sb, b_sg; int b_sk, b_sj;   /* B[b][k][j] */
+    const float* w; long long w_sb, w_sg; int w_sk;         /* optional w[b][k] */
+} bmc_mm_term_t;
+typedef struct {
+    int nterms;
+    bmc_mm_term_t t[2];
+    int nbatch, batch_per_group;
+    int M, N, K;
+    float alpha;
+    const float* u; long long u_sb, u_sg;                   /* optional u[b][i] (unit stride) */
+    const float* v; long long v_sb, v_sg;                   /*          v[b][j] (unit stride) */
+    float* c; long long c_sb, c_sg; int c_si, c_sj;         /* C[b][i][j] */
+    float* vec_out; long long vo_sb, vo_sg;                 /* vec[b][i] (unit stride) */
+    int accumulate;
+} bmc_small_mm_args_t;
+int bmc_small_mm(const bmc_small_mm_args_t* host_args, bmc_stream_t s);
+
 /* ---- loss-side resize ------------------------------------------------------
  * F.interpolate(prediction, size=gt.size()[-2:], mode='bicubic', align_corners=False): train.py:227-231,
  * infer_BMCNet.py:77-78 (taken when scale * round(sensor / scale) != sensor, dataloader/h5dataset.py:88-100; EventZoom:

@@ -213,3 +213,74 @@ def test_side_stream_weight_gradients_bit_identical_with_winograd_kernels(force_
         assert all(torch.equal(a, b) for a, b in zip(p0, p1))
     st = next(iter(ops._SIDE.values()))
     assert st.side and not st.armed and not st.keep
+
+
+# ------------------------------------------------------------------ batched C x C products (csrc/smallmm.hip)
+@pytest.mark.parametrize("M,N,K,nb,bpg", [(128, 128, 128, 16, 8), (48, 80, 40, 6, 2), (16, 16, 16, 3, 1), (33, 65, 17, 4, 4)])
+def test_small_mm_vs_float64(M, N, K, nb, bpg):
+    """bmc_small_mm: two terms, per-batch and per-group operands, transposed operands, the rank-1 term, the vector result, alpha,
+    accumulate, and a result written transposed into a column block of a wider matrix -- against float64 einsums."""
+    dev = _gpu()
+    from bmc_hip import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    ng = nb // bpg
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    A1, B1g, w1g = r(nb, M, K), r(ng, N, K), r(ng, K)          # term 1: A1[b] (B1[g])^T, w1[g]
+    A2t, B2, w2 = r(nb, K, M), r(nb, K, N), r(nb, K)           # term 2: (A2t[b])^T B2[b], w2[b]
+    u, v = r(nb, M), r(ng, N)
+    gi = torch.arange(nb, device=dev) // bpg
+    d = lambda t: t.double()
+    ref = torch.einsum("bik,bjk->bij", d(A1), d(B1g)[gi]) + torch.einsum("bki,bkj->bij", d(A2t), d(B2)) + d(u)[:, :, None] * d(v)[gi][:, None, :]
+    refv = torch.einsum("bik,bk->bi", d(A1), d(w1g)[gi]) + torch.einsum("bki,bk->bi", d(A2t), d(w2))
+    alpha = 0.37
+    terms = [((A1, M * K, 0, K, 1), (B1g, 0, N * K, 1, K), (w1g, 0, K, 1)), ((A2t, K * M, 0, 1, M), (B2, K * N, 0, N, 1), (w2, K, 0, 1))]
+    # (1) plain result + vector
+    c, vec = torch.empty(nb, M, N, device=dev), torch.empty(nb, M, device=dev)
+    ops.small_mm(terms, nb, bpg, M, N, K, c=(c, M * N, 0, N, 1), alpha=alpha, uv=((u, M, 0), (v, 0, N)), vec_out=(vec, M, 0))
+    assert rel_l2(c, alpha * ref) < 2e-6 and rel_l2(vec, alpha * refv) < 2e-6
+    # (2) accumulate on top of it
+    ops.small_mm(terms, nb, bpg, M, N, K, c=(c, M * N, 0, N, 1), alpha=alpha, uv=((u, M, 0), (v, 0, N)), vec_out=(vec, M, 0), accumulate=True)
+    assert rel_l2(c, 2 * alpha * ref) < 2e-6 and rel_l2(vec, 2 * alpha * refv) < 2e-6
+    # (3) transposed into columns [5, 5 + M) of a wider matrix [nb, N, M + 9]; the rest stays untouched
+    wide = torch.full((nb, N, M + 9), 7.0, device=dev)
+    ops.small_mm(terms[:1], nb, bpg, M, N, K, c=(wide[:, :, 5:], N * (M + 9), 0, 1, M + 9))
+    ref1 = torch.einsum("bik,bjk->bij", d(A1), d(B1g)[gi])
+    assert rel_l2(wide[:, :, 5:5 + M], ref1.transpose(1, 2)) < 2e-6
+    assert bool((wide[:, :, :5] == 7).all()) and bool((wide[:, :, 5 + M:] == 7).all())
+
+
+def test_attention_without_value_tensor_matches_explicit_form():
+    """BIETwinFn / BIEFirstFn with and without the value tensor (bie.VFREE): the same function, another order of summation --
+    outputs and every gradient agree to fp32 rounding."""
+    dev = _gpu()
+    from bmc_hip import bie, ops
+    from models.submodules import BIE
+    ops.set_math("fp32")
+    torch.manual_seed(5)
+    Cn, n, H, W = 128, 2, 24, 40
+    m = BIE(Cn).to(dev)
+    scaled_init(m, 3.0)
+    x12 = torch.randn(2 * n, H, W, Cn, device=dev)
+    xs = torch.randn(n, H, W, Cn, device=dev)
+    go, gx = torch.randn(2 * n, H, W, Cn, device=dev), torch.randn(n, H, W, Cn, device=dev)
+
+    def run(fn, vfree, nout):
+        old, oldacc = bie.VFREE, ops.ACCUM_PARAM_GRADS
+        bie.VFREE = vfree
+        ops.ACCUM_PARAM_GRADS = False                 # every gradient through autograd: comparable tensors
+        try:
+            for p_ in m.parameters():
+                p_.grad = None
+            a, b = x12.clone().requires_grad_(), xs.clone().requires_grad_()
+            o, xn = fn(m, a, b)
+            torch.autograd.backward([o, xn], [go[:nout], gx])
+            return [o.detach(), xn.detach(), a.grad, b.grad] + [p_.grad.clone() for p_ in m.parameters() if p_.grad is not None]
+        finally:
+            bie.VFREE, ops.ACCUM_PARAM_GRADS = old, oldacc
+
+    for fn, nout in ((bie.bie_twin, 2 * n), (bie.bie_first, n)):
+        ref, new = run(fn, False, nout), run(fn, True, nout)
+        assert len(ref) == len(new)
+        worst = max(rel_l2(a, b) for a, b in zip(new, ref))
+        print("%s: worst rel-L2 between the two forms %.2e" % (fn.__name__, worst))
+        assert worst < 5e-6
