@@ -79,15 +79,33 @@ def _times_w(m, wg, bg, bpg, out, out_strides, vec=None):
                  c=(out, out_strides[0], 0, out_strides[1], out_strides[2]), vec_out=(vec, Cn, 0) if vec is not None else None)
 
 
-def _value_param_grads(p, dM, tg, da, G0, sc, groups):
-    """dW_v[g] = sum over the group's samples of P^T dM + da^T G0, db_v[g] = sum of P^T t + da^T s  ->  ([groups,C,C], [groups,C])."""
+def _value_param_grads(p, dM, tg, da, G0, sc, w_params, b_params, npx):
+    """dW_v[g] = sum over the group's samples of P^T dM + da^T G0, db_v[g] = sum of P^T t + da^T s: one launch per weight group,
+    the group's (sample, row) pairs as its K dimension.  -> (dw [G,C,C], db [G,C]) for autograd, or (None, None) when the sums
+    went straight into the parameters' .grad (ops.sink_group; on the weight-gradient stream when there is one)."""
+    groups = len(w_params)
     B, Cn, _ = p.shape
-    dw = torch.empty((B, Cn, Cn), device=p.device, dtype=torch.float32)
-    db = torch.empty((B, Cn), device=p.device, dtype=torch.float32)
-    cc = Cn * Cn
-    ops.small_mm([((p, cc, 0, 1, Cn), (dM, cc, 0, Cn, 1), (tg, Cn, 0, 1)), ((da, cc, 0, 1, Cn), (G0, cc, 0, Cn, 1), (sc, Cn, 0, 1))],
-                 B, 1, Cn, Cn, Cn, c=(dw, cc, 0, Cn, 1), vec_out=(db, Cn, 0))
-    return dw.view(groups, B // groups, Cn, Cn).sum(1), db.view(groups, B // groups, Cn).sum(1)
+    n = B // groups
+    cc, K = Cn * Cn, n * Cn
+
+    def launch(g0, ng, dw, db, acc):
+        s_ = slice(g0 * n, (g0 + ng) * n)
+        ops.small_mm([((p[s_], n * cc, 0, 1, Cn), (dM[s_], n * cc, 0, Cn, 1), (tg[s_], K, 0, 1)),
+                      ((da[s_], n * cc, 0, 1, Cn), (G0[s_], n * cc, 0, Cn, 1), (sc[s_], K, 0, 1))],
+                     ng, 1, Cn, Cn, K, c=(dw, cc, 0, Cn, 1), vec_out=(db, Cn, 0), accumulate=acc)
+
+    params = list(w_params) + list(b_params)
+    with ops.wgrad_side(npx, params, (p, dM, tg, da, G0, sc)):
+        sg = ops.sink_group(params)
+        if sg is not None:
+            grads, acc = sg
+            for g in range(groups):
+                launch(g, 1, grads[g], grads[groups + g], acc)
+            return None, None
+    dw = torch.empty((groups, Cn, Cn), device=p.device, dtype=torch.float32)
+    db = torch.empty((groups, Cn), device=p.device, dtype=torch.float32)
+    launch(0, groups, dw, db, False)
+    return dw, db
 
 
 def chain_supported(Cn):
@@ -326,7 +344,7 @@ class BIETwinFn(torch.autograd.Function):
         lib.call(lib._sm_bwd, "bmc_softmax_bwd", p.data_ptr(), dp.data_ptr(), B2 * Cn, Cn, ctx.scale, da.data_ptr(), _stream())
         if vfree:
             # value-convolution parameters: dW_v = P^T dM + da^T G0, db_v = P^T t + da^T s (summed over the group's samples)
-            dwv, dbv = _value_param_grads(p, dM, tg, da, G0, sc, 2)
+            dwv, dbv = _value_param_grads(p, dM, tg, da, G0, sc, ctx.vparams[:2], ctx.vparams[2:], B2 * H * W)
         # Each of dv and d center has two contributions that are 1x1 products with per-sample / per-half matrices: ONE
         # two-source launch each (K = 2C, the matrices side by side) instead of a launch + accumulating launches --
         #   dv[b]      = P_b^T g_o[b] + da_b^T center[b]
@@ -509,8 +527,9 @@ class BIEFirstFn(torch.autograd.Function):
         da = torch.empty_like(p)
         lib.call(lib._sm_bwd, "bmc_softmax_bwd", p.data_ptr(), dp.data_ptr(), n * Cn, Cn, ctx.scale, da.data_ptr(), _stream())
         if vfree:
-            dwv1, dbv1 = _value_param_grads(p, dM, tg, da, G0, sc, 1)
-            dwv1, dbv1 = dwv1.view(wv1.shape), dbv1.view(Cn)
+            dwv1, dbv1 = _value_param_grads(p, dM, tg, da, G0, sc, (p_wv1,), (p_bv1,), n * H * W)
+            if dwv1 is not None:
+                dwv1, dbv1 = dwv1.view(wv1.shape), dbv1.view(Cn)
         #   dv1[b]     = P_b^T g_o[b] + da_b^T c1[b]
         #   dcentre[b] = (b < n: da_b v1[b]) + W_u[:, half(b)]^T g_x[b mod n]     (the second half has no attention term: a zero matrix)
         dc12 = new(B2)

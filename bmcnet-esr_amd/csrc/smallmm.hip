@@ -33,33 +33,47 @@ __global__ __launch_bounds__(256) void small_mm_kernel(const MmK k) {
     const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, vacc[2] = {0.f, 0.f};
     const bool want_vec = a.vec_out != nullptr && blockIdx.x == 0;
-    for (int t = 0; t < a.nterms; ++t) {
-        const bmc_mm_term_t& m = a.t[t];
+    // flattened (term, K step) iteration space, software-pipelined: the global loads of step s + 1 are in flight while step s
+    // is multiplied out of LDS (the kernel is a chain of load latencies otherwise: 17 us for 4 steps)
+    const int ksteps = (a.K + T - 1) / T, nsteps = a.nterms * ksteps;
+    float ra[4], rb[4], rw = 0.f;
+    auto fetch = [&](int s_) {
+        const bmc_mm_term_t& m = a.t[s_ / ksteps];
+        const int k0 = (s_ % ksteps) * T;
         const float* A = opbase(m.a, m.a_sb, m.a_sg, b, g);
         const float* B = opbase(m.b, m.b_sb, m.b_sg, b, g);
-        const float* Wv = m.w ? opbase(m.w, m.w_sb, m.w_sg, b, g) : nullptr;
-        for (int k0 = 0; k0 < a.K; k0 += T) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = tid + 256 * q, hi = e >> 5, lo = e & 31;
-                // the unit-stride index runs fastest over the lanes
-                const int ai = m.a_sk == 1 ? hi : lo, ak = m.a_sk == 1 ? lo : hi;
-                As[ai][ak] = (i0 + ai < a.M && k0 + ak < a.K) ? ldg4(A + (long long)(i0 + ai) * m.a_si + (long long)(k0 + ak) * m.a_sk) : 0.f;
-                const int bk = m.b_sj == 1 ? hi : lo, bj = m.b_sj == 1 ? lo : hi;
-                Bs[bk][bj] = (k0 + bk < a.K && j0 + bj < a.N) ? ldg4(B + (long long)(k0 + bk) * m.b_sk + (long long)(j0 + bj) * m.b_sj) : 0.f;
-            }
-            if (want_vec && Wv && tid < T) ws[tid] = k0 + tid < a.K ? ldg4(Wv + (long long)(k0 + tid) * m.w_sk) : 0.f;
-            __syncthreads();
-#pragma unroll
-            for (int kk = 0; kk < T; ++kk) {
-                const float a0 = As[2 * ty][kk], a1 = As[2 * ty + 1][kk];
-                const float b0 = Bs[kk][2 * tx], b1 = Bs[kk][2 * tx + 1];
-                acc[0][0] += a0 * b0; acc[0][1] += a0 * b1;
-                acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
-                if (want_vec && Wv) { vacc[0] += a0 * ws[kk]; vacc[1] += a1 * ws[kk]; }
-            }
-            __syncthreads();
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, hi = e >> 5, lo = e & 31;
+            // the unit-stride index runs fastest over the lanes
+            const int ai = m.a_sk == 1 ? hi : lo, ak = m.a_sk == 1 ? lo : hi;
+            ra[q] = (i0 + ai < a.M && k0 + ak < a.K) ? ldg4(A + (long long)(i0 + ai) * m.a_si + (long long)(k0 + ak) * m.a_sk) : 0.f;
+            const int bk = m.b_sj == 1 ? hi : lo, bj = m.b_sj == 1 ? lo : hi;
+            rb[q] = (k0 + bk < a.K && j0 + bj < a.N) ? ldg4(B + (long long)(k0 + bk) * m.b_sk + (long long)(j0 + bj) * m.b_sj) : 0.f;
         }
+        if (want_vec && tid < T) rw = k0 + tid < a.K ? ldg4(opbase(m.w, m.w_sb, m.w_sg, b, g) + (long long)(k0 + tid) * m.w_sk) : 0.f;
+    };
+    fetch(0);
+    for (int s_ = 0; s_ < nsteps; ++s_) {
+        const bmc_mm_term_t& m = a.t[s_ / ksteps];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, hi = e >> 5, lo = e & 31;
+            As[m.a_sk == 1 ? hi : lo][m.a_sk == 1 ? lo : hi] = ra[q];
+            Bs[m.b_sj == 1 ? hi : lo][m.b_sj == 1 ? lo : hi] = rb[q];
+        }
+        if (want_vec && tid < T) ws[tid] = rw;
+        __syncthreads();
+        if (s_ + 1 < nsteps) fetch(s_ + 1);
+#pragma unroll
+        for (int kk = 0; kk < T; ++kk) {
+            const float a0 = As[2 * ty][kk], a1 = As[2 * ty + 1][kk];
+            const float b0 = Bs[kk][2 * tx], b1 = Bs[kk][2 * tx + 1];
+            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1;
+            acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+            if (want_vec) { vacc[0] += a0 * ws[kk]; vacc[1] += a1 * ws[kk]; }
+        }
+        __syncthreads();
     }
     const float* u = a.u ? a.u + (long long)b * a.u_sb + (long long)g * a.u_sg : nullptr;
     const float* v = a.v ? a.v + (long long)b * a.v_sb + (long long)g * a.v_sg : nullptr;
