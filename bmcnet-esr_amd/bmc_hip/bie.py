@@ -44,11 +44,15 @@ FUSE_FIRST = os.environ.get("BMC_FUSE_FIRST", "1") != "0"      # BIEFirstFn for 
 # the BIE's thirteen full-size 1x1 launches -- against a handful of C x C x C products per sample.  Same mathematics, another
 # order of summation (the parity bars of tests/parity_bars.py hold it); BMC_BIE_VFREE=0 restores the explicit form, which the
 # bf16 mode keeps (its operand-rounding oracle rounds v).
+# Not for small launches: the three full-size launches it removes cost 12-15 us each at 31x56, the eight small ones it adds
+# 5-6 us each plus their weight packs (31x56: 82.3 -> 96.6 ms, 48x64: 111.5 -> 124.9 ms; break-even at 64x96, 154.2 vs 155.0 ms;
+# 90x120: 232.4 -> 228.3 ms; 180x240: 743 -> 710 ms) -- from 2^16 pixels per launch.
 VFREE = os.environ.get("BMC_BIE_VFREE", "1") != "0"
+VFREE_MIN_PIXELS = int(os.environ.get("BMC_BIE_VFREE_MIN_PIXELS", 1 << 16))
 
 
-def vfree_supported():
-    return VFREE and ops.MATH in (0, 3)
+def vfree_supported(npx):
+    return VFREE and ops.MATH in (0, 3) and npx >= VFREE_MIN_PIXELS
 
 
 def _gram_on_x(c_src, x_src, B, H, W, Cn, dev):
@@ -271,7 +275,7 @@ class BIETwinFn(torch.autograd.Function):
         # values: v1 on the first half, v2 on the second (two weight groups)
         wv = ops.stacked((wv1, wv2), lambda: torch.stack([d(wv1).reshape(Cn, Cn, 1), d(wv2).reshape(Cn, Cn, 1)]), "v1x1")
         bv = ops.stacked((bv1, bv2), lambda: torch.stack([d(bv1), d(bv2)]), "stack")
-        vfree = vfree_supported()
+        vfree = vfree_supported(B2 * H * W)
         o12 = new(B2)
         if vfree:       # attention without v (above): att = scale (G0 W_v^T + s b_v^T), out = (P W_v) x + P b_v
             G0, sc = _gram_on_x(X(c12), X(x12), B2, H, W, Cn, dev)
@@ -465,7 +469,7 @@ class BIEFirstFn(torch.autograd.Function):
         _conv([X(t2)], d(rw2).reshape(1, Cn, Cn, 9), s1, rw2, d(rb2), r2, n, residual=second)
         yhat, rstd, c12 = chain_fwd(X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2), wf, d(bf), d(gamma), d(beta), wc, d(bc), eps,
                                     B2, H, W, Cn, dev)
-        vfree = vfree_supported()
+        vfree = vfree_supported(B2 * H * W)
         o1 = new(n)
         if vfree:       # attention without v (top of this file)
             G0, sc = _gram_on_x(X(c12, b0=0, B=n), X(x12, b0=0, B=n), n, H, W, Cn, dev)

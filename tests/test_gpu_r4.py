@@ -265,8 +265,8 @@ def test_attention_without_value_tensor_matches_explicit_form():
     go, gx = torch.randn(2 * n, H, W, Cn, device=dev), torch.randn(n, H, W, Cn, device=dev)
 
     def run(fn, vfree, nout):
-        old, oldacc = bie.VFREE, ops.ACCUM_PARAM_GRADS
-        bie.VFREE = vfree
+        old, oldacc, oldmin = bie.VFREE, ops.ACCUM_PARAM_GRADS, bie.VFREE_MIN_PIXELS
+        bie.VFREE, bie.VFREE_MIN_PIXELS = vfree, 0    # (the form without v at this test's size too)
         ops.ACCUM_PARAM_GRADS = False                 # every gradient through autograd: comparable tensors
         try:
             for p_ in m.parameters():
@@ -276,7 +276,7 @@ def test_attention_without_value_tensor_matches_explicit_form():
             torch.autograd.backward([o, xn], [go[:nout], gx])
             return [o.detach(), xn.detach(), a.grad, b.grad] + [p_.grad.clone() for p_ in m.parameters() if p_.grad is not None]
         finally:
-            bie.VFREE, ops.ACCUM_PARAM_GRADS = old, oldacc
+            bie.VFREE, ops.ACCUM_PARAM_GRADS, bie.VFREE_MIN_PIXELS = old, oldacc, oldmin
 
     for fn, nout in ((bie.bie_twin, 2 * n), (bie.bie_first, n)):
         ref, new = run(fn, False, nout), run(fn, True, nout)
@@ -284,3 +284,28 @@ def test_attention_without_value_tensor_matches_explicit_form():
         worst = max(rel_l2(a, b) for a, b in zip(new, ref))
         print("%s: worst rel-L2 between the two forms %.2e" % (fn.__name__, worst))
         assert worst < 5e-6
+
+
+@pytest.fixture
+def force_vfree():
+    """The BIE attention without the value tensor at every launch size (default: from 2^16 pixels per launch)."""
+    from bmc_hip import bie
+    old = bie.VFREE, bie.VFREE_MIN_PIXELS
+    bie.VFREE, bie.VFREE_MIN_PIXELS = True, 0
+    yield bie
+    bie.VFREE, bie.VFREE_MIN_PIXELS = old
+
+
+def test_reference_goldens_with_attention_without_value_tensor(force_vfree):
+    """The reference's own golden vectors (BIE, ParallelBlk, the 3-window BPTT of the full models in both fp32-class modes) and
+    the quarter-frame oracle gradients, with the value-free attention forced at these small sizes (C = 16 / 32 / 128 matrices
+    through bmc_small_mm, value-parameter gradients straight into .grad): the same bars as the explicit form."""
+    import test_gpu_parity as tp
+    tp.test_bie_golden()
+    tp.test_parallel_blk_golden()
+    tp.test_full_model_bptt_golden("bmcnet_nc16", False, "fp32")
+    tp.test_full_model_bptt_golden("bmcnet_nc32", False, "bf16x6")
+    tp.test_full_model_bptt_golden("bmcnet_nc32", False, "fp32")
+    tp.test_quarter_frame_window_gradients_vs_oracle()
+    tp.test_fused_twin_bie_matches_unfused_autograd_path()
+    tp.test_fused_first_output_bie_matches_unfused_autograd_path()
