@@ -84,32 +84,26 @@ def _times_w(m, wg, bg, bpg, out, out_strides, vec=None):
 
 
 def _value_param_grads(p, dM, tg, da, G0, sc, w_params, b_params, npx):
-    """dW_v[g] = sum over the group's samples of P^T dM + da^T G0, db_v[g] = sum of P^T t + da^T s: one launch per weight group,
-    the group's (sample, row) pairs as its K dimension.  -> (dw [G,C,C], db [G,C]) for autograd, or (None, None) when the sums
-    went straight into the parameters' .grad (ops.sink_group; on the weight-gradient stream when there is one)."""
+    """dW_v[g] = sum over the group's samples of P^T dM + da^T G0, db_v[g] = sum of P^T t + da^T s.  The per-sample products are
+    written in the slab layout of the pixel-reduction GEMM (sample = split), so the sum over a group's samples, the routing
+    into the parameters' .grad (or back to autograd) and the weight-gradient stream are ops.reduce_wgrad's, as for every other
+    weight gradient.  -> (dw [G,C,C], db [G,C]) or (None, None)."""
     groups = len(w_params)
     B, Cn, _ = p.shape
-    n = B // groups
-    cc, K = Cn * Cn, n * Cn
-
-    def launch(g0, ng, dw, db, acc):
-        s_ = slice(g0 * n, (g0 + ng) * n)
-        ops.small_mm([((p[s_], n * cc, 0, 1, Cn), (dM[s_], n * cc, 0, Cn, 1), (tg[s_], K, 0, 1)),
-                      ((da[s_], n * cc, 0, 1, Cn), (G0[s_], n * cc, 0, Cn, 1), (sc[s_], K, 0, 1))],
-                     ng, 1, Cn, Cn, K, c=(dw, cc, 0, Cn, 1), vec_out=(db, Cn, 0), accumulate=acc)
-
+    n, cc, dev = B // groups, Cn * Cn, p.device
+    mp = round_up(Cn, 32)
+    slab, bslab = groups * mp * mp, groups * 4 * mp
+    slabs = torch.empty(n * slab, device=dev, dtype=torch.float32)       # [n][G][1][mp][mp]; the reduction reads rows / columns < C only
+    bsl = torch.zeros(n * bslab, device=dev, dtype=torch.float32)        # [n][G][4][mp]: part 0 written, parts 1-3 zero
     params = list(w_params) + list(b_params)
     with ops.wgrad_side(npx, params, (p, dM, tg, da, G0, sc)):
-        sg = ops.sink_group(params)
-        if sg is not None:
-            grads, acc = sg
-            for g in range(groups):
-                launch(g, 1, grads[g], grads[groups + g], acc)
-            return None, None
-    dw = torch.empty((groups, Cn, Cn), device=p.device, dtype=torch.float32)
-    db = torch.empty((groups, Cn), device=p.device, dtype=torch.float32)
-    launch(0, groups, dw, db, False)
-    return dw, db
+        ops._on_side(slabs, bsl)
+        # batch b = g * n + s  ->  slab s, group g
+        ops.small_mm([((p, cc, 0, 1, Cn), (dM, cc, 0, Cn, 1), (tg, Cn, 0, 1)), ((da, cc, 0, 1, Cn), (G0, cc, 0, Cn, 1), (sc, Cn, 0, 1))],
+                     B, n, Cn, Cn, Cn, c=(slabs, slab, mp * mp - n * slab, mp, 1), vec_out=(bsl, bslab, 4 * mp - n * bslab))
+        one = groups == 1
+        return ops.reduce_wgrad(slabs, n, groups, 1, Cn, _dense_spec(Cn), dev, bsl, w_params[0] if one else tuple(w_params),
+                                b_params[0] if one else tuple(b_params), (Cn, Cn) if one else (groups, Cn, Cn))
 
 
 def chain_supported(Cn):

@@ -20,6 +20,7 @@ namespace {
 struct MmK { bmc_small_mm_args_t a; };
 
 constexpr int T = 32;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ const float* opbase(const float* p, long long sb, long long sg, int b, int g) {
     return p + (long long)b * sb + (long long)g * sg;
@@ -27,7 +28,10 @@ __device__ __forceinline__ const float* opbase(const float* p, long long sb, lon
 
 __global__ __launch_bounds__(256) void small_mm_kernel(const MmK k) {
     const bmc_small_mm_args_t& a = k.a;
-    __shared__ float As[T][T + 1], Bs[T][T + 1], ws[T];
+    // rows of As are read four k at a time (16-byte aligned: 36 floats per row), rows of Bs two columns at a time (34)
+    __shared__ __attribute__((aligned(16))) float As[T][T + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[T][T + 2];
+    __shared__ __attribute__((aligned(16))) float ws[T];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int b = blockIdx.z, g = b / a.batch_per_group;
     const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
@@ -66,12 +70,16 @@ __global__ __launch_bounds__(256) void small_mm_kernel(const MmK k) {
         __syncthreads();
         if (s_ + 1 < nsteps) fetch(s_ + 1);
 #pragma unroll
-        for (int kk = 0; kk < T; ++kk) {
-            const float a0 = As[2 * ty][kk], a1 = As[2 * ty + 1][kk];
-            const float b0 = Bs[kk][2 * tx], b1 = Bs[kk][2 * tx + 1];
-            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1;
-            acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
-            if (want_vec) { vacc[0] += a0 * ws[kk]; vacc[1] += a1 * ws[kk]; }
+        for (int kk = 0; kk < T; kk += 4) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[2 * ty][kk]), a1 = *reinterpret_cast<const f32x4*>(&As[2 * ty + 1][kk]);
+            const f32x4 w4 = want_vec ? *reinterpret_cast<const f32x4*>(&ws[kk]) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 bq = *reinterpret_cast<const f32x2*>(&Bs[kk + q][2 * tx]);
+                acc[0][0] += a0[q] * bq[0]; acc[0][1] += a0[q] * bq[1];
+                acc[1][0] += a1[q] * bq[0]; acc[1][1] += a1[q] * bq[1];
+                vacc[0] += a0[q] * w4[q]; vacc[1] += a1[q] * w4[q];
+            }
         }
         __syncthreads();
     }
