@@ -600,12 +600,14 @@ def is_sink(p):
     """May a launch add its weight gradient straight into p.grad?  Only for contiguous leaf parameters, and only when nobody
     is listening on autograd for them: a parameter with tensor hooks or post-accumulate-grad hooks keeps the autograd
     route (the hooks fire only when autograd accumulates), unless the hook's owner declared that it stages sink gradients
-    itself (parallel.GradAllReducer sets p._bmc_sink_aware).  Not detectable from here, hence documented in INTEGRATION.md:
+    itself (parallel.GradAllReducer sets p._bmc_sink_aware = 1: exactly its one hook may be present -- a clipping or logging
+    hook registered beside it, before or after, sends the parameter back to the autograd route).  Not detectable from here, hence documented in INTEGRATION.md:
     torch DDP / FSDP (hooks on the AccumulateGrad nodes) and torch.autograd.grad(loss, params) need BMC_ACCUM_GRADS=0 /
     set_accumulate_param_grads(False)."""
     if not (ACCUM_PARAM_GRADS and p is not None and p.is_leaf and p.requires_grad and p.is_contiguous()):
         return False
-    if (p._post_accumulate_grad_hooks or p._backward_hooks) and not getattr(p, "_bmc_sink_aware", False):
+    nh = len(p._post_accumulate_grad_hooks or ()) + len(p._backward_hooks or ())
+    if nh and nh != getattr(p, "_bmc_sink_aware", 0):      # hooks other than the one sink-aware owner's
         return False
     return True
 
@@ -701,7 +703,7 @@ WGRAD_SIDE_MAX_PIXELS = int(os.environ.get("BMC_WGRAD_STREAM_MAX_PIXELS", 1 << 1
 
 
 class _SideState:
-    __slots__ = ("stream", "raw", "event", "keep", "armed", "side")
+    __slots__ = ("stream", "raw", "event", "keep", "armed", "side", "task")
 
     def __init__(self, dev):
         # the device's lowest stream priority: the data-gradient chain (critical path) gets the CUs first, the weight gradients
@@ -715,7 +717,7 @@ class _SideState:
             self.stream = torch.cuda.Stream(device=dev, priority=int(prio))
         self.raw = self.stream.cuda_stream
         self.event = torch.cuda.Event()
-        self.keep, self.armed, self.side = [], False, False
+        self.keep, self.armed, self.side, self.task = [], False, False, -1
 
     def follow_main(self):
         """Everything queued on the launch stream so far happens before what the side stream is given next."""
@@ -775,7 +777,13 @@ def wgrad_side(npx, params, keep=()):
     st = _SIDE.get(dev)
     if st is None:
         st = _SIDE[dev] = _SideState(dev)
+    task = torch._C._current_graph_task_id()
+    if st.armed and st.task != task:
+        # the backward pass that armed the join never ran its callback (it raised): join now, or this pass would queue no join
+        # of its own and the optimizer could read a .grad the side stream is still adding to
+        st.join()
     if not st.armed:
+        st.task = task
         # the FIRST weight-gradient launch of a backward pass decides for the whole pass: one parameter's gradient is
         # accumulated by launches of different batch sizes (conv_fs: B and 3B), and its read-modify-writes must not be
         # split over two streams

@@ -51,11 +51,24 @@ class GradAllReducer:
         # the bucket travels through host memory -- independent of whether this gloo build takes device tensors
         self.host_stage = self.cuda and dist.is_initialized() and dist.get_backend(group) == "gloo"
         for p in self.params:
-            p._bmc_sink_aware = True          # bmc_hip.ops.is_sink: our hooks do not need the autograd route (finish() stages)
+            # bmc_hip.ops.is_sink: OUR hook does not need the autograd route (finish() stages sink gradients) -- but somebody
+            # else's hook on the parameter (clipping, logging) does: such a parameter keeps the autograd route
+            p._bmc_sink_aware = 0 if (p._post_accumulate_grad_hooks or p._backward_hooks) else 1      # (the number of hooks is_sink accepts)
             p._bmc_sink_touched = False
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
-        if optimizer is not None:
-            optimizer.register_step_pre_hook(lambda *_: self.finish())
+        self._step_hook = optimizer.register_step_pre_hook(lambda *_: self.finish()) if optimizer is not None else None
+
+    def detach(self):
+        """Undo the constructor: hooks removed, the parameters no longer marked for the kernels' sink route on this reducer's
+        behalf (a model that outlives its reducer must not keep bypassing autograd for hooks registered later)."""
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+        if self._step_hook is not None:
+            self._step_hook.remove()
+            self._step_hook = None
+        for p in self.params:
+            p._bmc_sink_aware = 0
 
     # -- called by autograd once per parameter per backward, after all its uses have been accumulated
     def _on_grad(self, p):

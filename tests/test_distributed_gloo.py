@@ -379,8 +379,24 @@ def test_hooked_parameters_keep_the_autograd_route():
     net(torch.randn(4, 8)).sum().backward()
     assert "post" in fired and "tensor" in fired and net.c.grad is not None
     net2 = SinkNet()
-    GradAllReducer(net2)
+    red2 = GradAllReducer(net2)
     assert all(ops.is_sink(p) for p in net2.parameters())
     ops.set_accumulate_param_grads(False)
     assert not ops.is_sink(net2.a)
     ops.set_accumulate_param_grads(True)
+    # somebody else's hook registered BESIDE the reducer's (a clipping / logging hook added later): autograd route again
+    h = net2.a.register_post_accumulate_grad_hook(lambda p: None)
+    assert not ops.is_sink(net2.a) and ops.is_sink(net2.c)
+    h.remove()
+    assert ops.is_sink(net2.a)
+    # ... or BEFORE it: the reducer does not claim such a parameter
+    net3 = SinkNet()
+    net3.a.register_hook(lambda g: g)
+    red3 = GradAllReducer(net3)
+    assert not ops.is_sink(net3.a) and ops.is_sink(net3.c)
+    # detach(): the model outlives its reducer -- hooks gone, parameters plain again, later hooks are respected
+    red2.detach()
+    assert all(ops.is_sink(p) for p in net2.parameters())            # (no hooks at all: a sink by the basic rule)
+    net2.c.register_post_accumulate_grad_hook(lambda p: None)
+    assert not ops.is_sink(net2.c)
+    red3.detach()

@@ -309,3 +309,45 @@ def test_reference_goldens_with_attention_without_value_tensor(force_vfree):
     tp.test_quarter_frame_window_gradients_vs_oracle()
     tp.test_fused_twin_bie_matches_unfused_autograd_path()
     tp.test_fused_first_output_bie_matches_unfused_autograd_path()
+
+
+def test_weight_gradient_stream_recovers_from_a_backward_that_raised():
+    """A backward pass that raises after its first weight-gradient launch never runs the join callback it queued.  The next pass
+    must notice (another autograd graph task), join the stale work and queue a join of its own -- otherwise the optimizer could
+    read a .grad the side stream is still adding to."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from bmc_hip.ops import ConvSpec, View
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    torch.manual_seed(3)
+    w = (torch.randn(128, 128, 3, 3, device=dev) * 0.05).requires_grad_()
+    b = torch.zeros(128, device=dev, requires_grad=True)
+    x = torch.randn(2, 24, 32, 128, device=dev, requires_grad=True)
+    spec = ConvSpec.dense(128)
+    old = ops.WGRAD_SIDE
+    ops.WGRAD_SIDE = "1"
+    try:
+        with pytest.raises(RuntimeError, match="boom"):
+            ops.conv([View(Boom.apply(x))], w, b, spec).sum().backward()
+        st = ops._SIDE[torch.cuda.current_device()]
+        assert st.armed                                   # the callback of the failed pass never ran
+        w.grad = b.grad = None
+        ops.conv([View(x)], w, b, spec).sum().backward()
+        assert not st.armed and not st.keep               # this pass joined (its own callback ran)
+        torch.cuda.synchronize()
+        got = w.grad.clone()
+        ops.WGRAD_SIDE = "0"
+        w.grad = b.grad = None
+        ops.conv([View(x)], w, b, spec).sum().backward()
+        assert torch.equal(got, w.grad)
+    finally:
+        ops.WGRAD_SIDE = old
