@@ -437,8 +437,8 @@ def extra_infer(dev, windows=24):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)       # (two: the caching allocator still grows in the second step of a process)
     ap.add_argument("--batch", type=int, default=4, help="sequences per GPU")
     ap.add_argument("--height", type=int, default=180)
     ap.add_argument("--width", type=int, default=240)
