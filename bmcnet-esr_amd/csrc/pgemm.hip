@@ -194,6 +194,34 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
         if (wave_active) {
             const float* const ap = lds + cur * BUF + lh * 128 + 32 * mw + li;
             const float* const xp = lds + (2 + cur) * BUF + lh * XCH + 32 * NT * nw + li + (TG == TAPS ? 0 : tg * HWD * XCH);
+            if constexpr (TAPS == 1) {
+                // 1x1: two MFMAs per pair of operand reads.  Left to itself the compiler issues each read right in front of its
+                // MFMAs and waits for it (lgkmcnt(0) before every pair: an LDS round trip per 128 matrix-pipe cycles, 0.71 of the
+                // MFMA rate with nothing else going on).  Operands are read a batch of QB k-steps AHEAD into a second register
+                // set; the scheduling barriers keep "reads of batch b + 1, then the MFMAs of batch b" in that order.
+                constexpr int QB = 4, NBAT = PT / 2 / QB;
+                float av[2][QB], xv[2][QB][NT];
+                auto rd = [&](const int slot, const int q0) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) {
+                        av[slot][j] = ap[2 * (q0 + j) * 128];
+#pragma unroll
+                        for (int u = 0; u < NT; ++u) xv[slot][j][u] = xp[2 * (q0 + j) * XCH + 32 * u];
+                    }
+                };
+                rd(0, 0);
+#pragma unroll
+                for (int qb = 0; qb < NBAT; ++qb) {
+                    if (qb + 1 < NBAT) rd((qb + 1) & 1, (qb + 1) * QB);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < QB; ++j)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u)
+                            acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[qb & 1][j], xv[qb & 1][j][u], acc[u], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < PT / 2; ++q) {
                 const float av = ap[2 * q * 128];
