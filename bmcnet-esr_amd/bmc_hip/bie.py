@@ -348,7 +348,8 @@ class BIETwinFn(torch.autograd.Function):
         #   dv[b]      = P_b^T g_o[b] + da_b^T center[b]
         #   dcenter[b] = da_b  v[b]   + W_u[:, half(b)]^T g_x[b mod n]            (unclustering reads cat[c1, c2])
         dc12 = new(B2)
-        w_ut = wu.detach().view(Cn, 2, Cn).permute(1, 2, 0).repeat_interleave(n, 0)           # [B2, C (c_i), C (co)]
+        # [B2, C (c_i), C (co)], cached per version of the unclustering weight and batch size (it is the same in all 8 windows)
+        w_ut = ops.stacked((p_wu,), lambda: wu.detach().view(Cn, 2, Cn).permute(1, 2, 0).repeat_interleave(n, 0).contiguous(), "wut%d" % n)
         if vfree:
             # without v:  dx12 (+)= (P W_v)^T g_o + (da W_v)^T center  (below, once dx12 exists);
             #             dcenter = (da W_v) x + da b_v + W_u[:, half]^T g_x
@@ -531,7 +532,8 @@ class BIEFirstFn(torch.autograd.Function):
         #   dv1[b]     = P_b^T g_o[b] + da_b^T c1[b]
         #   dcentre[b] = (b < n: da_b v1[b]) + W_u[:, half(b)]^T g_x[b mod n]     (the second half has no attention term: a zero matrix)
         dc12 = new(B2)
-        w_ut = wu.detach().view(Cn, 2, Cn).permute(1, 2, 0).repeat_interleave(n, 0)           # [B2, C (c_i), C (co)]
+        # [B2, C (c_i), C (co)], cached per version of the unclustering weight and batch size (it is the same in all 8 windows)
+        w_ut = ops.stacked((p_wu,), lambda: wu.detach().view(Cn, 2, Cn).permute(1, 2, 0).repeat_interleave(n, 0).contiguous(), "wut%d" % n)
         if vfree:       # (as in BIETwinFn; the second half has no attention term: zero matrix, zero bias)
             w_dx = torch.empty((n, Cn, 2 * Cn, 1), device=dev, dtype=torch.float32)
             w_dc = torch.zeros((B2, Cn, 2 * Cn, 1), device=dev, dtype=torch.float32)
