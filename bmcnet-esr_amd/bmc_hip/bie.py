@@ -194,11 +194,12 @@ def _spec2(c):
 
 
 def _conv(srcs, w4, spec, owner, bias, out, B, relu=False, residual=None, mask=None, bpg=None, accumulate=False,
-          out_b0=0):
+          out_b0=0, rule=None):
     """Forward-style launch: out[out_b0 : out_b0+B] = epi(conv(cat(srcs)) + bias)."""
     G, Cout, Cin, taps = w4.shape
     _, H, W, Co = out.shape
-    wn = ops.wino_ok(B, H, W, Cout, taps, fwd=not accumulate and mask is None)
+    stride = max([x.pix_stride for x in srcs] + [Co] + [x.pix_stride for x in (residual, mask) if x is not None])
+    wn = ops.wino_ok(B, H, W, Cout, taps, fwd=not accumulate and mask is None, stride=stride, rule=rule)
     wp = _packed_weight(w4, spec, owner, wino=wn)
     conv_raw(srcs, wp, spec.kpad * taps * coutpad(Cout), bias, Cout if bias is not None else 0,
              out.data_ptr() + 4 * out_b0 * H * W * Co, H * W * Co, Co, B, H, W, Cout, taps, relu=relu, residual=residual,
@@ -210,7 +211,8 @@ def _dgrad(g_src, w4, spec, src_index, owner, out, B, residual=None, mask=None, 
     G, Cout, Cin, taps = w4.shape
     _, H, W, Co = out.shape
     nch = spec.nch[src_index]
-    wn = ops.wino_ok(B, H, W, nch, taps)
+    stride = max([g_src.pix_stride, Co] + [x.pix_stride for x in (residual, mask) if x is not None])
+    wn = ops.wino_ok(B, H, W, nch, taps, stride=stride)
     wt = _packed_weight_t(w4, spec, src_index, owner, wino=wn)
     conv_raw([g_src], wt, round_up(Cout, CK) * taps * coutpad(nch), None, 0, out.data_ptr() + 4 * out_b0 * H * W * Co,
              H * W * Co, Co, B, H, W, nch, taps, residual=residual, mask=mask, bpg=bpg, accumulate=accumulate,
@@ -251,8 +253,8 @@ class BIETwinFn(torch.autograd.Function):
         d = lambda t: t.detach()
         # residual block on both halves (shared weights)
         t12, r12 = new(B2), new(B2)
-        _conv([X(x12)], d(rw1).reshape(1, Cn, Cn, 9), s1, rw1, d(rb1), t12, B2, relu=True)
-        _conv([X(t12)], d(rw2).reshape(1, Cn, Cn, 9), s1, rw2, d(rb2), r12, B2, residual=X(x12))
+        _conv([X(x12)], d(rw1).reshape(1, Cn, Cn, 9), s1, rw1, d(rb1), t12, B2, relu=True, rule=rb1)
+        _conv([X(t12)], d(rw2).reshape(1, Cn, Cn, 9), s1, rw2, d(rb2), r12, B2, residual=X(x12), rule=rb2)
         # centres: clustering(LN(convf(cat[xs, other half])))
         fused = chain_supported(Cn)
         if fused:       # one launch; saved for backward: yhat (normalised, before the affine) and rstd
@@ -460,8 +462,8 @@ class BIEFirstFn(torch.autograd.Function):
         d = lambda t: t.detach()
         second = X(x12, b0=n, B=n)
         t2, r2 = new(n), new(n)
-        _conv([second], d(rw1).reshape(1, Cn, Cn, 9), s1, rw1, d(rb1), t2, n, relu=True)
-        _conv([X(t2)], d(rw2).reshape(1, Cn, Cn, 9), s1, rw2, d(rb2), r2, n, residual=second)
+        _conv([second], d(rw1).reshape(1, Cn, Cn, 9), s1, rw1, d(rb1), t2, n, relu=True, rule=rb1)
+        _conv([X(t2)], d(rw2).reshape(1, Cn, Cn, 9), s1, rw2, d(rb2), r2, n, residual=second, rule=rb2)
         yhat, rstd, c12 = chain_fwd(X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2), wf, d(bf), d(gamma), d(beta), wc, d(bc), eps,
                                     B2, H, W, Cn, dev)
         vfree = vfree_supported(B2 * H * W)

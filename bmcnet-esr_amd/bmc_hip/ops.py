@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import weakref
 from typing import List, Optional, Sequence
 
@@ -266,39 +267,87 @@ WINO_MIN_TILES = int(os.environ.get("BMC_WINO_MIN_TILES", 200))   # >= ~1 tile p
 WINO4 = os.environ.get("BMC_WINO4", "1") != "0"
 WINO4_MIN_TILES = int(os.environ.get("BMC_WINO4_MIN_TILES", 300))    # workgroup tiles (16 tiles of 4x4 pixels x 128 channels)
 
-# Exact zeros.  With zero biases and a zero recurrent state (window 0 at initialisation) the reference's direct convolution
-# gives EXACTLY 0 wherever a pixel's receptive field holds no event, and relu'(0) = 0 gates the gradient there.  F(2x2)
-# preserves that (every output of its minimal algorithm is a combination of products of ITS OWN 3x3 field only); F(4x4) computes
-# such a pixel from a 6x6 patch through rounded transformed weights: +-1e-8 instead of 0, a coin flip of the ReLU mask that the
-# bias gradients of the first layers see (tests/wino_numerics.py, profiles/r04_wino_numerics.txt: conv_fps.bias 1.8e-1 off).
-# The model marks the FORWARD launches whose input can hold whole empty receptive fields -- the input-fusion convolutions on
-# the raw event counts and the residual blocks in front of the first BIE -- with this context; they keep F(2x2).
-_EXACT_ZERO = [0]
+# Exact zeros.  Where a pixel's 3x3 receptive field holds nothing, the reference's direct convolution gives EXACTLY its bias;
+# with a zero bias that is exactly 0, and relu'(0) = 0 gates the gradient there.  F(2x2) preserves that (every output of its
+# minimal algorithm is a combination of products of ITS OWN 3x3 field only), the direct kernel trivially; F(4x4) computes such a
+# pixel from a 6x6 patch that also holds its neighbours' data, through rounded transformed weights: +-1e-8 instead of 0, a coin
+# flip of the ReLU mask.  On dense inputs only the first layers of the first window see such fields (round 4's rule, keyed on the
+# caller's `init` flag); on a SPARSE recording with zero biases every layer of every window does -- nothing densifies a zero
+# pixel of zero-bias convolutions, LayerNorm2d and per-pixel attention -- and the bias gradients came out up to 58 % wrong
+# (tests/test_gpu_r5.py::test_sparse_recording_bias_gradients_vs_oracle, 0.026 events per pixel at 180x240).  The rule is
+# therefore keyed on DATA -- the bias vector that is added to the launch's result (its own, or for a bias-free launch that adds a
+# residual the bias inside that residual: `rule`): a FORWARD 3x3 launch takes the F(4x4) kernel only if every element of it is
+# at least DENSE_FLOOR away from zero, i.e. no output of the launch is decided by the kernel's 1e-8 residue.  As
+# `initialize_weights` leaves the biases (zero) every forward launch keeps F(2x2); one optimizer step moves every bias that
+# receives a gradient by the learning rate, and from then on F(4x4) serves them all.  Data gradients are never affected (nothing
+# gates on them).  The flags cost one device reduction and one host read per optimizer step for all biases of a model
+# (prime_bias_dense, cached per parameter version).  exact_zero_inputs() forces the safe kernels regardless (tests).
+_EXACT_ZERO = threading.local()          # .n: nesting depth of exact_zero_inputs on this thread
+DENSE_FLOOR = 1e-6
+_DENSE = {}                              # id(bias) -> (weakref, version, flag)
 
 
 class exact_zero_inputs:
     def __enter__(self):
-        _EXACT_ZERO[0] += 1
+        _EXACT_ZERO.n = getattr(_EXACT_ZERO, "n", 0) + 1
 
     def __exit__(self, *exc):
-        _EXACT_ZERO[0] -= 1
+        _EXACT_ZERO.n -= 1
         return False
 
 
-def wino_ok(B, H, W, Cout, taps, fwd=False):
+def _dense_cached(b):
+    hit = _DENSE.get(id(b))
+    if hit is not None and hit[0]() is b and hit[1] == b._version:
+        return hit[2]
+    return None
+
+
+def prime_bias_dense(biases):
+    """Evaluate `min |b| >= DENSE_FLOOR` for every bias whose flag is missing or stale: one stack of device reductions, ONE host
+    read.  (Not while a HIP graph is being captured: flags missing then read as "not dense" -- the safe kernels.)"""
+    need = [b for b in biases if b is not None and _dense_cached(b) is None]
+    if not need or not need[0].is_cuda or torch.cuda.is_current_stream_capturing():
+        return
+    mins = torch.stack([b.detach().abs().min() for b in need]).tolist()
+    if len(_DENSE) > 512:
+        for k in [k for k, v in _DENSE.items() if v[0]() is None]:
+            del _DENSE[k]
+    for b, m in zip(need, mins):
+        _DENSE[id(b)] = (weakref.ref(b), b._version, m >= DENSE_FLOOR)
+
+
+def bias_dense(b):
+    """Is every element of this bias (or of every bias of a tuple) at least DENSE_FLOOR away from zero?  None: no."""
+    if b is None:
+        return False
+    if isinstance(b, (tuple, list)):
+        prime_bias_dense(b)
+        return all(bool(_dense_cached(x)) for x in b)
+    hit = _dense_cached(b)
+    if hit is None:
+        prime_bias_dense([b])
+        hit = _dense_cached(b)
+    return bool(hit)
+
+
+def wino_ok(B, H, W, Cout, taps, fwd=False, stride=0, rule=None):
     """Which kernel takes a launch of this geometry?  0: the direct kernel, 2: Winograd F(2x2, 3x3), 4: F(4x4, 3x3).
     (Decided ONCE per launch by the caller and handed to the weight pack and to conv_raw alike: the packed layouts are not
-    interchangeable.)  fwd: a forward launch (subject to exact_zero_inputs)."""
+    interchangeable.)  fwd: a forward launch: F(4x4) only if `rule` -- the bias (tensor, or tuple of tensors) that is added to its
+    result -- is dense (see above).  stride: the widest pixel stride (floats) among the
+    launch's sources, residual, mask and output, where it can exceed 512 (channel windows of a wider buffer): the Winograd
+    launchers refuse what their 32-bit offsets cannot address, so such a launch must be routed to the direct kernel here."""
     if not WINO or MATH != 0 or taps != 9:
         return 0
     cp = coutpad(Cout)
     if cp % 128 or B * ((H + 7) // 8) * ((W + 15) // 16) * (cp // 128) < WINO_MIN_TILES:
         return 0
-    if H * W * 4 * 512 >= 2 ** 31:      # 32-bit per-lane DMA offsets in both Winograd kernels (pix_stride <= 512 floats): direct kernel
+    if H * W * 4 * max(stride, 512) >= 2 ** 31:      # 32-bit per-lane DMA offsets in both Winograd kernels: direct kernel
         return 0
-    if WINO4 and not (fwd and _EXACT_ZERO[0]) and W >= 17 and H * W < 2 ** 24:
+    if WINO4 and W >= 17 and H * W < 2 ** 24:
         n4 = B * ((((H + 3) // 4) * ((W + 3) // 4) + 15) // 16) * (cp // 128)
-        if n4 >= WINO4_MIN_TILES:
+        if n4 >= WINO4_MIN_TILES and not (fwd and (getattr(_EXACT_ZERO, "n", 0) or not bias_dense(rule))):
             return 4
     return 2
 
@@ -486,6 +535,18 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
 # through the Winograd transform too (csrc/wino_wgrad.hip: 16 instead of 36 multiplies per 2x2 tile and channel pair; fp32,
 # deterministic).  BMC_WINO_WGRAD=0 (or BMC_WINO=0) leaves them to the pixel-reduction GEMM.
 WINO_WGRAD = os.environ.get("BMC_WINO_WGRAD", "1") != "0"
+# Round 5: the same through F(4x4, 3x3) (csrc/wino4_wgrad.hip: 36 multiplies per 4x4 tile and channel pair, 1.78x fewer than
+# F(2x2)) for launches with at least WINO4_WGRAD_MIN_STAGES stages (4 tiles each) per workgroup: every workgroup writes its full
+# 288 KB slice of partial sums whatever the image size.  BMC_WINO4_WGRAD=0 keeps F(2x2).
+WINO4_WGRAD = os.environ.get("BMC_WINO4_WGRAD", "1") != "0"
+WINO4_WGRAD_MIN_STAGES = int(os.environ.get("BMC_WINO4_WGRAD_MIN_STAGES", 24))
+
+
+def wgrad_wino4_ok(B, H, W):
+    if not WINO4_WGRAD:
+        return False
+    stages = B * ((H + 3) // 4) * (((W + 3) // 4 + 3) // 4)
+    return stages >= 32 * WINO4_WGRAD_MIN_STAGES
 
 
 def wino_wgrad_ok(a_src, x_srcs, spec, taps, Cout, G):
@@ -509,25 +570,30 @@ def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want
 
 
 def _wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias, k0, full):
-    nsplit = lib._ww_nsplit(B, H, W)
-    part = torch.empty(nsplit * 16 * 128 * 128, device=dev, dtype=torch.float32)
+    f4 = wgrad_wino4_ok(B, H, W)
+    if f4:
+        f_ns, f_main, f_red, nm, npos, kind = lib._ww4_nsplit, lib._ww4, lib._ww4_red, "bmc_wgrad_wino4", 36, "wgrad_wino4<9>"
+    else:
+        f_ns, f_main, f_red, nm, npos, kind = lib._ww_nsplit, lib._ww, lib._ww_red, "bmc_wgrad_wino", 16, "wgrad_wino<9>"
+    nsplit = f_ns(B, H, W)
+    part = torch.empty(nsplit * npos * 128 * 128, device=dev, dtype=torch.float32)
     bpart = torch.empty(nsplit * 128, device=dev, dtype=torch.float32) if want_bias else None
     _on_side(part, bpart)
     e0 = _prof_begin()
-    lib.call(lib._ww, "bmc_wgrad_wino", C.byref(a_src), C.byref(x_src), B, H, W, nsplit, part.data_ptr(),
+    lib.call(f_main, nm, C.byref(a_src), C.byref(x_src), B, H, W, nsplit, part.data_ptr(),
              bpart.data_ptr() if want_bias else None, _stream())
-    _prof_end(e0, "wgrad_wino<9>", 2.0 * B * H * W * 128 * 9 * 128, 4.0 * B * H * W * 256 + 4.0 * part.numel())
+    _prof_end(e0, kind, 2.0 * B * H * W * 128 * 9 * 128, 4.0 * B * H * W * 256 + 4.0 * part.numel())
     k0 = spec.kmap_host[0] if k0 is None else k0
     full = spec.covers_all if full is None else full
     sg = sink_group([w_param, b_param] if want_bias else [w_param], full) if w_param is not None else None
     if sg is not None:
         (gw, *rest), acc = sg
-        lib.call(lib._ww_red, "bmc_wgrad_wino_reduce", part.data_ptr(), nsplit, gw.data_ptr(), spec.cin, k0, acc,
+        lib.call(f_red, nm + "_reduce", part.data_ptr(), nsplit, gw.data_ptr(), spec.cin, k0, acc,
                  bpart.data_ptr() if want_bias else None, rest[0].data_ptr() if want_bias else None, _stream())
         return None, None
     dw = (torch.empty if full else torch.zeros)(128 * spec.cin * 9, device=dev, dtype=torch.float32)
     db = torch.empty(128, device=dev, dtype=torch.float32) if want_bias else None
-    lib.call(lib._ww_red, "bmc_wgrad_wino_reduce", part.data_ptr(), nsplit, dw.data_ptr(), spec.cin, k0, 0,
+    lib.call(f_red, nm + "_reduce", part.data_ptr(), nsplit, dw.data_ptr(), spec.cin, k0, 0,
              bpart.data_ptr() if want_bias else None, db.data_ptr() if want_bias else None, _stream())
     return dw.view(w_shape), db
 
@@ -600,16 +666,22 @@ def is_sink(p):
     """May a launch add its weight gradient straight into p.grad?  Only for contiguous leaf parameters, and only when nobody
     is listening on autograd for them: a parameter with tensor hooks or post-accumulate-grad hooks keeps the autograd
     route (the hooks fire only when autograd accumulates), unless the hook's owner declared that it stages sink gradients
-    itself (parallel.GradAllReducer sets p._bmc_sink_aware = 1: exactly its one hook may be present -- a clipping or logging
-    hook registered beside it, before or after, sends the parameter back to the autograd route).  Not detectable from here, hence documented in INTEGRATION.md:
+    itself (parallel.GradAllReducer records the ids of its own hooks in p._bmc_sink_hooks: only those may be present -- a
+    clipping or logging hook registered beside them, before or after, or the hook of a reducer that was dropped without
+    detach(), sends the parameter back to the autograd route).  Not detectable from here, hence documented in INTEGRATION.md:
     torch DDP / FSDP (hooks on the AccumulateGrad nodes) and torch.autograd.grad(loss, params) need BMC_ACCUM_GRADS=0 /
     set_accumulate_param_grads(False)."""
     if not (ACCUM_PARAM_GRADS and p is not None and p.is_leaf and p.requires_grad and p.is_contiguous()):
         return False
-    nh = len(p._post_accumulate_grad_hooks or ()) + len(p._backward_hooks or ())
-    if nh and nh != getattr(p, "_bmc_sink_aware", 0):      # hooks other than the one sink-aware owner's
+    if p._backward_hooks:
+        return False
+    post = p._post_accumulate_grad_hooks
+    if post and not set(post.keys()) <= getattr(p, "_bmc_sink_hooks", _NO_HOOKS):      # a hook that is not a sink-aware owner's
         return False
     return True
+
+
+_NO_HOOKS = frozenset()
 
 
 def set_accumulate_param_grads(on: bool):
@@ -625,6 +697,8 @@ def sink_group(params, full=True):
     full=False: the launch defines only part of the gradient (ConvSpec.covers_all is false): new accumulators start as zeros."""
     if not all(is_sink(p) for p in params):
         return None
+    if _SIDE and torch._C._current_graph_task_id() < 0:
+        wgrad_join()        # outside a backward pass: nothing will run the join a raised backward left behind
     for p in params:        # seen by parallel.GradAllReducer.finish(): this gradient did not (only) come through autograd
         p._bmc_sink_touched = True
     missing = [p.grad is None for p in params]
@@ -699,13 +773,22 @@ def small_mm(terms, nbatch, bpg, M, N, K, c=None, alpha=1.0, uv=None, vec_out=No
 # bit-identical to the single-stream run (tests/test_gpu_r3.py, tests/test_gpu_r4.py).
 WGRAD_SIDE = os.environ.get("BMC_WGRAD_STREAM", "auto")          # "0" never, "1" always, "auto" (default): fp32 mode, launches of
 WGRAD_SIDE_MIN_PIXELS = int(os.environ.get("BMC_WGRAD_STREAM_MIN_PIXELS", 1 << 14))     # at least this many pixels (see above)
-WGRAD_SIDE_MAX_PIXELS = int(os.environ.get("BMC_WGRAD_STREAM_MAX_PIXELS", 1 << 17))     # operands kept (<=) or record_stream'ed (>)
+# operands of a side-stream launch: kept referenced until the join (<= this many pixels) or handed to the caching allocator with
+# record_stream (>: the allocator then defers the reuse of every such buffer to the side stream's progress, so peak memory
+# follows the side stream's lag).  (Until round 4 this was BMC_WGRAD_STREAM_MAX_PIXELS, which once meant "no side stream
+# above this size"; the old name is refused rather than silently reinterpreted.)
+if "BMC_WGRAD_STREAM_MAX_PIXELS" in os.environ:
+    import warnings
+    warnings.warn("BMC_WGRAD_STREAM_MAX_PIXELS is no longer read: the side stream has no upper size limit; "
+                  "BMC_WGRAD_KEEP_MAX_PIXELS sets the keep / record_stream threshold of its operands")
+WGRAD_KEEP_MAX_PIXELS = int(os.environ.get("BMC_WGRAD_KEEP_MAX_PIXELS", 1 << 17))
 
 
 class _SideState:
-    __slots__ = ("stream", "raw", "event", "keep", "armed", "side", "task")
+    __slots__ = ("stream", "raw", "event", "keep", "armed", "side", "task", "dev")
 
     def __init__(self, dev):
+        self.dev = dev
         # the device's lowest stream priority: the data-gradient chain (critical path) gets the CUs first, the weight gradients
         # what it leaves (C2: 745.5 vs 750.2 ms at the default priority, alternating runs; small frames: no difference)
         prio = os.environ.get("BMC_SIDE_PRIO", "low")
@@ -721,17 +804,40 @@ class _SideState:
 
     def follow_main(self):
         """Everything queued on the launch stream so far happens before what the side stream is given next."""
-        self.event.record()
+        self.event.record(torch.cuda.current_stream(self.dev))
         self.stream.wait_event(self.event)
 
     def join(self):
+        # (the device is named: as an autograd-engine callback this may run on a thread whose current device is not the
+        #  model's, and the wait must go onto the model's launch stream)
         if self.side:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            torch.cuda.current_stream(self.dev).wait_stream(self.stream)
         self.keep.clear()
         self.armed = False
 
 
 _SIDE = {}
+
+
+def wgrad_join():
+    """The launch stream waits for every weight gradient still running on the side stream; idempotent, free when nothing is
+    pending.  The backward pass that armed the side stream joins it by itself when it ends -- but a backward pass that RAISED
+    never gets there, and if the caller catches the exception the side stream may still be adding into .grad tensors (or into
+    blocks zero_grad(set_to_none=True) has meanwhile returned to the allocator).  Called from every place that is about to
+    read or free a .grad: the optimizers' step (a global pre-step hook registered below), GradAllReducer.finish(), the models'
+    forward, sink_group outside a backward pass.  Code that catches a backward exception and touches .grad by other means
+    (clip_grad_norm_, zero_grad followed by raw allocations) calls it first."""
+    for st in _SIDE.values():
+        if st.armed:
+            st.join()
+
+
+def _join_before_step(*_):
+    wgrad_join()
+
+
+from torch.optim.optimizer import register_optimizer_step_pre_hook as _reg_pre_step  # noqa: E402
+_reg_pre_step(_join_before_step)
 
 
 class _SideCtx:
@@ -797,7 +903,7 @@ def wgrad_side(npx, params, keep=()):
     ps = [p for p in params if p is not None]
     if not ps or not all(is_sink(p) for p in ps):
         return _NOCTX
-    if npx <= WGRAD_SIDE_MAX_PIXELS:
+    if npx <= WGRAD_KEEP_MAX_PIXELS:
         st.keep.extend(keep)
     else:                       # large operands: not kept until the join -- the allocator defers their reuse to the side stream's progress
         for t in keep:
@@ -853,11 +959,11 @@ def reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bias_slabs, w_param, b
 # convolution (3x3 / 1x1, multi-source, grouped weights)
 # --------------------------------------------------------------------------
 class ConvMeta:
-    __slots__ = ("spec", "views", "B", "relu", "G", "res", "cache", "taps", "out", "ngp")
+    __slots__ = ("spec", "views", "B", "relu", "G", "res", "cache", "taps", "out", "ngp", "rule")
 
-    def __init__(self, spec, views, B, relu, G, res, cache, taps, out=None, ngp=0):
-        self.spec, self.views, self.B, self.relu, self.G, self.res, self.cache, self.taps, self.out, self.ngp = \
-            spec, views, B, relu, G, res, cache, taps, out, ngp
+    def __init__(self, spec, views, B, relu, G, res, cache, taps, out=None, ngp=0, rule=None):
+        self.spec, self.views, self.B, self.relu, self.G, self.res, self.cache, self.taps, self.out, self.ngp, self.rule = \
+            spec, views, B, relu, G, res, cache, taps, out, ngp, rule
 
 
 class ConvFn(torch.autograd.Function):
@@ -878,7 +984,8 @@ class ConvFn(torch.autograd.Function):
         w4 = weight.detach().reshape(G, -1, meta.spec.cin, taps)
         Cout = w4.shape[1]
         ck = weight if meta.cache else None
-        wn = wino_ok(B, H, W, Cout, taps, fwd=True)
+        wn = wino_ok(B, H, W, Cout, taps, fwd=True, stride=max([t.shape[3] for t in src_ts] + [res_t.shape[3] if res_t is not None else 0]),
+                     rule=meta.rule if meta.rule is not None else bias)
         wp = _packed_weight(w4.contiguous(), meta.spec, ck, wino=wn)
         if meta.out is not None:       # write into a batch range of a preallocated buffer (see OutSlot)
             out = meta.out.t[meta.out.b0:meta.out.b0 + B]
@@ -1015,7 +1122,7 @@ class ConvFn(torch.autograd.Function):
                 c0, nch, shift, mod, b0 = v
                 Bt, _, _, Ct = t.shape
                 dxs_ = grp[1]
-                wn = wino_ok(B, H, W, nch, taps)
+                wn = wino_ok(B, H, W, nch, taps, stride=Ct)
                 wt = _packed_weight_t(w4, spec, i, ck, wino=wn)
                 conv_raw([_src(g, 0, Cout, 0, None, 0, B)], wt, round_up(Cout, CK) * taps * coutpad(nch), None, 0,
                          dxs_.data_ptr() + 4 * (b0 * H * W * Ct + c0), H * W * Ct, Ct, B, H, W, nch, taps, bpg=B,
@@ -1060,7 +1167,7 @@ class ConvFn(torch.autograd.Function):
             gsrc = _src(gs, 0, Cout, gshift, gmod, 0, nb)
             if Cout % CK:
                 raise RuntimeError("bmc_hip: conv output channels must be a multiple of 16 for the data gradient")
-            wn = wino_ok(nb, H, W, nch, taps)
+            wn = wino_ok(nb, H, W, nch, taps, stride=Ct)
             wt = _packed_weight_t(w4, spec, i, ck, wino=wn)
             conv_raw([gsrc], wt, c16 * taps * nkpad, None, 0, dx.data_ptr() + 4 * (b0 * H * W * Ct + c0), H * W * Ct, Ct,
                      nb, H, W, nch, taps, bpg=nb // G, flops=2.0 * nb * H * W * spec.real_nch[i] * taps * Cout, wino=wn)
@@ -1074,16 +1181,17 @@ class ConvFn(torch.autograd.Function):
 
 
 def conv(views: Sequence[View], weight, bias, spec: ConvSpec, *, B=None, relu=False, residual=None, G=1,
-         cache=True, taps=None, out=None):
+         cache=True, taps=None, out=None, rule=None):
     """views: operands (in packed-K order of `spec`); weight [Cout,Cin,kh,kw] (G == 1) or [G,Cout,Cin(,1,1)];
-    out: optional OutSlot -- the result is written into (and returned as a view of) a batch range of its buffer."""
+    out: optional OutSlot -- the result is written into (and returned as a view of) a batch range of its buffer.
+    rule: for a bias-free 3x3 launch whose residual carries a bias, that bias (the exact-zero rule above wino_ok)."""
     B = views[0].t.shape[0] if B is None else B
     if taps is None:
         taps = weight.shape[-1] * weight.shape[-2] if weight.dim() >= 4 else 1
     res_t, res_meta = None, None
     if residual is not None:
         res_t, res_meta = residual.t, (residual.shift, residual.mod)
-    meta = ConvMeta(spec, [v.meta() for v in views], B, relu, G, res_meta, cache, taps, out)
+    meta = ConvMeta(spec, [v.meta() for v in views], B, relu, G, res_meta, cache, taps, out, rule=rule)
     return ConvFn.apply(meta, weight, bias, res_t, *[v.t for v in views])
 
 
@@ -1102,7 +1210,8 @@ def conv_groups(views: Sequence[View], weights, biases, spec: ConvSpec, *, B=Non
     if residual is not None:
         res_t, res_meta = residual.t, (residual.shift, residual.mod)
     gps = tuple(weights) + (tuple(biases) if biases is not None else ())
-    meta = ConvMeta(spec, [v.meta() for v in views], B, relu, G, res_meta, True, taps, out, ngp=len(gps))
+    meta = ConvMeta(spec, [v.meta() for v in views], B, relu, G, res_meta, True, taps, out, ngp=len(gps),
+                    rule=tuple(biases) if biases is not None else None)
     return ConvFn.apply(meta, wst, bst, res_t, *[v.t for v in views], *gps)
 
 
@@ -1175,16 +1284,16 @@ class ResBlockFn(torch.autograd.Function):
         taps = w1.shape[-1] * w1.shape[-2]
         cp = coutpad(Cn)
         xs = _src(x.detach(), 0, Cn, 0, None, 0, B)
-        wn = wino_ok(B, H, W, Cn, taps, fwd=True)
-        wp1 = _packed_weight(w1.detach().reshape(1, Cn, Cn, taps), spec, w1, wino=wn)
-        wp2 = _packed_weight(w2.detach().reshape(1, Cn, Cn, taps), spec, w2, wino=wn)
+        wn1, wn2 = wino_ok(B, H, W, Cn, taps, fwd=True, rule=b1), wino_ok(B, H, W, Cn, taps, fwd=True, rule=b2)
+        wp1 = _packed_weight(w1.detach().reshape(1, Cn, Cn, taps), spec, w1, wino=wn1)
+        wp2 = _packed_weight(w2.detach().reshape(1, Cn, Cn, taps), spec, w2, wino=wn2)
         fl = 2.0 * B * H * W * Cn * taps * Cn
         t = torch.empty_like(x)
         conv_raw([xs], wp1, spec.kpad * taps * cp, b1.detach(), Cn, t.data_ptr(), H * W * Cn, Cn, B, H, W, Cn, taps, relu=True,
-                 flops=fl, wino=wn)
+                 flops=fl, wino=wn1)
         y = torch.empty_like(x) if out is None else out.t[out.b0:out.b0 + B]
         conv_raw([_src(t, 0, Cn, 0, None, 0, B)], wp2, spec.kpad * taps * cp, b2.detach(), Cn, y.data_ptr(), H * W * Cn, Cn, B, H,
-                 W, Cn, taps, residual=xs, flops=fl, wino=wn)
+                 W, Cn, taps, residual=xs, flops=fl, wino=wn2)
         ctx.save_for_backward(x, t, w1, w2)
         ctx.spec, ctx.taps = spec, taps
         ctx.owners = (w1, w2)

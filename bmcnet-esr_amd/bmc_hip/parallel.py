@@ -50,25 +50,38 @@ class GradAllReducer:
         # gloo with device buckets (the world-size-2 test of the HIP path on ONE GPU; RCCL refuses two ranks on one device):
         # the bucket travels through host memory -- independent of whether this gloo build takes device tensors
         self.host_stage = self.cuda and dist.is_initialized() and dist.get_backend(group) == "gloo"
+        self._handles = []
         for p in self.params:
             # bmc_hip.ops.is_sink: OUR hook does not need the autograd route (finish() stages sink gradients) -- but somebody
-            # else's hook on the parameter (clipping, logging) does: such a parameter keeps the autograd route
-            p._bmc_sink_aware = 0 if (p._post_accumulate_grad_hooks or p._backward_hooks) else 1      # (the number of hooks is_sink accepts)
+            # else's hook on the parameter (clipping, logging, a second reducer) does: such a parameter keeps the autograd
+            # route.  is_sink recognises our hook by its id, not by the number of hooks present.
+            h = p.register_post_accumulate_grad_hook(self._on_grad)
+            self._handles.append(h)
+            ids = getattr(p, "_bmc_sink_hooks", None)
+            if ids is None:
+                ids = p._bmc_sink_hooks = set()
+            ids.add(h.id)
             p._bmc_sink_touched = False
-        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._step_hook = optimizer.register_step_pre_hook(lambda *_: self.finish()) if optimizer is not None else None
 
     def detach(self):
         """Undo the constructor: hooks removed, the parameters no longer marked for the kernels' sink route on this reducer's
         behalf (a model that outlives its reducer must not keep bypassing autograd for hooks registered later)."""
-        for h in self._handles:
+        for p, h in zip(self.params, self._handles):
+            getattr(p, "_bmc_sink_hooks", set()).discard(h.id)
             h.remove()
         self._handles = []
         if self._step_hook is not None:
             self._step_hook.remove()
             self._step_hook = None
-        for p in self.params:
-            p._bmc_sink_aware = 0
+
+    def __del__(self):
+        # a reducer that is dropped without detach(): its hook ids must not keep vouching for whatever hook is registered next
+        try:
+            for p, h in zip(self.params, self._handles):
+                getattr(p, "_bmc_sink_hooks", set()).discard(h.id)
+        except Exception:
+            pass
 
     # -- called by autograd once per parameter per backward, after all its uses have been accumulated
     def _on_grad(self, p):
@@ -121,6 +134,9 @@ class GradAllReducer:
         Buckets whose parameters did not all come through the hooks -- gradient accumulation over several backward()
         calls, or gradients that the kernels accumulated straight into .grad (bmc_hip.ops.ACCUM_PARAM_GRADS: no autograd
         accumulation, hence no hook) -- are staged and reduced here."""
+        if self.cuda:
+            from . import ops
+            ops.wgrad_join()        # weight gradients still being added on the side stream (a backward that raised never joined)
         nb = len(self.buckets)
         active = [any(p.grad is not None for p in self.buckets[bi]) for bi in range(nb)]
         for bi in range(nb):

@@ -43,6 +43,10 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef BMC_W4_XP
+#define BMC_W4_XP 0        // experiments (tools/ builds only; results are wrong by design): 2 waves w and w + 4 stream the SAME rows of
+                           // U (does the CU's L1 serve the SIMD partner's copy?), 3 every second U request left out (half the stream)
+#endif
 #ifndef BMC_W4_ABL
 #define BMC_W4_ABL 0       // ablation bits (tools/ builds only): 1 no MFMAs, 2 no weight loads, 4 no halo DMA, 8 no stores,
                            // 16 no V production, 32 no V fragment reads, 64 no barriers, 128 no output transform
@@ -169,7 +173,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     auto ublock = [&](const W4Tile& it, int chunk) -> const float* {
         const int grp = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
         const float* p = static_cast<const float*>(a.w) + (long long)grp * a.w_group_stride + (long long)it.nt * nchunks * UCH +
-                         (long long)chunk * UCH + wave * UBLK;
+                         (long long)chunk * UCH + (BMC_W4_XP == 2 ? (wave & 3) : wave) * UBLK;
         const unsigned long long pv = reinterpret_cast<unsigned long long>(p);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pv), hi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
         return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
@@ -438,12 +442,12 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
                 const int q0 = p0 + D;
                 if (q0 < NPOS) {
                     const float* const b = ucur + (q0 / 4) * 1024;
-                    if (q0 % 4 == 0) { uload<0>(ur[s0], b, uvoff); uload<1024>(ur[s1], b, uvoff); }
-                    else { uload<2048>(ur[s0], b, uvoff); uload<3072>(ur[s1], b, uvoff); }
+                    if (q0 % 4 == 0) { uload<0>(ur[s0], b, uvoff); if (BMC_W4_XP != 3) uload<1024>(ur[s1], b, uvoff); }
+                    else { uload<2048>(ur[s0], b, uvoff); if (BMC_W4_XP != 3) uload<3072>(ur[s1], b, uvoff); }
                 } else {
                     const float* const b = unx + ((q0 - NPOS) / 4) * 1024;
-                    if ((q0 - NPOS) % 4 == 0) { uload<0>(ur[s0], b, uvoff); uload<1024>(ur[s1], b, uvoff); }
-                    else { uload<2048>(ur[s0], b, uvoff); uload<3072>(ur[s1], b, uvoff); }
+                    if ((q0 - NPOS) % 4 == 0) { uload<0>(ur[s0], b, uvoff); if (BMC_W4_XP != 3) uload<1024>(ur[s1], b, uvoff); }
+                    else { uload<2048>(ur[s0], b, uvoff); if (BMC_W4_XP != 3) uload<3072>(ur[s1], b, uvoff); }
                 }
             }
             if (LOADER) {

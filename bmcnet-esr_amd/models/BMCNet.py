@@ -36,17 +36,15 @@ class ParallelBlk(nn.Module):
     def forward_nhwc(self, x12, xs, xst12, xsst12, need_st=True, first=False):
         """x12 = [x_1; x_2], xst12 = [x_1_st; x_2_st], xsst12 = [x_1_s_st; x_2_s_st] (batch-stacked twins).
         need_st=False: the caller will not read the returned xst12 (it is None then).
-        first: this is the backbone's first block -- its two leading residual blocks read activations that can still hold
-        exact zeros over whole receptive fields (ops.exact_zero_inputs)."""
+        first: unused since round 5 (the exact-zero rule is decided per launch from the biases: ops.wino_ok)."""
         fused = need_st or (bie.FUSE_FIRST and bie.chain_supported(x12.shape[-1]))
-        with (ops.exact_zero_inputs() if first else contextlib.nullcontext()):
-            if fused:
-                # both residual blocks write into the halves of one buffer, so the two lBIE calls (and, inside them, the
-                # weight-shared conv1/conv2 and convf1/convf2 pairs) run as ONE fused twin node over 4B samples
-                pair = self._res_pair(x12, xst12)
-            else:
-                x12 = self.conv1.forward_nhwc(x12)
-                xst12 = self.conv1_st.forward_nhwc(xst12)
+        if fused:
+            # both residual blocks write into the halves of one buffer, so the two lBIE calls (and, inside them, the
+            # weight-shared conv1/conv2 and convf1/convf2 pairs) run as ONE fused twin node over 4B samples
+            pair = self._res_pair(x12, xst12)
+        else:
+            x12 = self.conv1.forward_nhwc(x12)
+            xst12 = self.conv1_st.forward_nhwc(xst12)
         if need_st:
             o, xsst12 = self.lBIE.forward_twin(pair, xsst12)
             x12, xst12 = bie.Unstack2Fn.unstack(o)
@@ -131,17 +129,29 @@ class Backbone(nn.Module):
         """xin12 [2B,H,W,16]: packed polarity inputs (p batch-half, n batch-half);
         h3 [3B,H,W,n_c] = [hp; hn; hs]; o12 [2B,H,W,s^2] = [o[:, :s^2]; o[:, s^2:]] (channel halves batch-stacked).
         Returns x_h, x_h_p, x_h_n, x_o (NHWC)."""
+        ops.wgrad_join()         # (a backward pass that raised leaves weight gradients running on the side stream: ops.wgrad_join)
         B = o12.shape[0] // 2
         hpn = h3[:2 * B]
-        # (zero_state: the recurrent state and the previous prediction may be all zero -- the first window of a sequence, where
-        #  the input-fusion convolutions see nothing but sparse event counts: ops.exact_zero_inputs.  From the second window on
-        #  every 3x3 field holds 128 channels of a dense state, and no pre-activation is exactly zero.)
-        with (ops.exact_zero_inputs() if zero_state else contextlib.nullcontext()):
-            st12, s12, sst12, xs = self._input_fusion(xin12, h3, hpn, o12, B)
+        # (which 3x3 launches may take the F(4x4) kernel is decided per launch from the bias that is added to its result -- the
+        #  exact-zero rule above ops.wino_ok; round 4 keyed it on `zero_state`, which a sparse recording defeats.  One device
+        #  reduction + one host read per optimizer step for all 3x3 biases of the backbone:)
+        ops.prime_bias_dense(self._biases3())
+        st12, s12, sst12, xs = self._input_fusion(xin12, h3, hpn, o12, B)
         n_layers = len(self.para_reschunk)
         for i, layer in enumerate(self.para_reschunk):      # x*_st of the last block is never read: skip what only feeds it
-            s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12, need_st=i + 1 < n_layers, first=zero_state and i == 0)
+            s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12, need_st=i + 1 < n_layers)
         return self._tail(s12, xs, sst12, B)
+
+    def _biases3(self):
+        """The bias vectors of the backbone's 3x3 convolutions (aliases once): what ops.wino_ok's exact-zero rule reads."""
+        b3 = getattr(self, "_b3", None)
+        if b3 is None:
+            seen = {}
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d) and tuple(m.kernel_size) == (3, 3) and m.bias is not None:
+                    seen.setdefault(id(m.bias), m.bias)
+            b3 = self._b3 = list(seen.values())
+        return b3
 
     def _input_fusion(self, xin12, h3, hpn, o12, B):
         st12 = ops.conv([View(xin12), View(hpn), View(o12)], self.conv_fpst.weight, self.conv_fpst.bias, self._sp_fpst,
@@ -153,7 +163,7 @@ class Backbone(nn.Module):
         shared = ops.conv([View(st12, b0=0), View(st12, b0=B), View(o12, b0=0), View(o12, b0=B)], wfs,
                           self.conv_fs.bias, self._sp_fs_shared, B=B)      # input channels of xp_st, xn_st, o (+ the bias)
         fs3 = ops.conv([View(h3)], wfs, None, self._sp_fs_h, B=3 * B, relu=True,
-                       residual=View(shared, mod=B))                       # + those of h*: [xs_p_st; xs_n_st; xs]
+                       residual=View(shared, mod=B), rule=self.conv_fs.bias)                       # + those of h*: [xs_p_st; xs_n_st; xs]
         sst12, xs = bie.Unstack2Fn.apply(fs3, 2 * B)       # (one concatenation in backward instead of two zero-filled slice gradients + add)
         return st12, s12, sst12, xs
 

@@ -268,6 +268,18 @@ int bmc_wgrad_wino(const bmc_src_t* dy, const bmc_src_t* x, int B, int H, int W,
 int bmc_wgrad_wino_reduce(const float* part, int nsplit, float* dw, int ldw, int k0, int accumulate, const float* bias_part,
                           float* db, bmc_stream_t s);
 
+/* ---- the same weight gradient through F(4x4, 3x3) (round 5): 36 multiplies per 4x4 output tile and channel pair, i.e. 2.25 per
+ * output pixel against 4 -- the transform of bmc_conv's BMC_MATH_FP32_WINO4 forward / data-gradient kernel applied to
+ * F.conv2d's weight gradient (models/submodules.py:25-26,33-34).  Same operands, same reduce semantics, same determinism;
+ * 3.0e-6 rel-L2 per convolution against float64 (contract 1e-3).
+ *   nsplit:  workgroups per output slice, 1 .. bmc_wgrad_wino4_nsplit(B, H, W) (8 slices x nsplit workgroups fill the chip)
+ *   part:    workspace of nsplit * 36 * 128 * 128 floats;  bias_part: NULL or nsplit * 128 floats */
+int bmc_wgrad_wino4_nsplit(int B, int H, int W);
+int bmc_wgrad_wino4(const bmc_src_t* dy, const bmc_src_t* x, int B, int H, int W, int nsplit, float* part, float* bias_part,
+                    bmc_stream_t s);
+int bmc_wgrad_wino4_reduce(const float* part, int nsplit, float* dw, int ldw, int k0, int accumulate, const float* bias_part,
+                           float* db, bmc_stream_t s);
+
 /* ---- streaming kernels ---------------------------------------------------*/
 /* out[i] = sum_{k < groups} in[k*n + i] (fixed order): gradient of an operand shared by several batch groups of a launch */
 int bmc_group_sum(const float* in, int groups, long long n, float* out, bmc_stream_t s);

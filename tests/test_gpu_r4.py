@@ -183,8 +183,8 @@ def test_side_stream_weight_gradients_bit_identical_with_winograd_kernels(force_
     gt = torch.poisson(torch.full((B, L, 2, scale * H, scale * W), 0.5), generator=g).to(dev)
 
     def run(mode):
-        old, old_lim, old_min = ops.WGRAD_SIDE, ops.WGRAD_SIDE_MAX_PIXELS, ops.WGRAD_SIDE_MIN_PIXELS
-        ops.WGRAD_SIDE, ops.WGRAD_SIDE_MAX_PIXELS, ops.WGRAD_SIDE_MIN_PIXELS = mode, keep_limit, 0     # (auto: at this test's size too)
+        old, old_lim, old_min = ops.WGRAD_SIDE, ops.WGRAD_KEEP_MAX_PIXELS, ops.WGRAD_SIDE_MIN_PIXELS
+        ops.WGRAD_SIDE, ops.WGRAD_KEEP_MAX_PIXELS, ops.WGRAD_SIDE_MIN_PIXELS = mode, keep_limit, 0     # (auto: at this test's size too)
         try:
             torch.manual_seed(192)
             m = BMCNet(scale, n_c, n_b).to(dev)
@@ -200,7 +200,7 @@ def test_side_stream_weight_gradients_bit_identical_with_winograd_kernels(force_
             ops.PROFILE = None
             return losses, [p.grad.clone() for p in m.parameters() if p.grad is not None], [p.detach().clone() for p in m.parameters()], kinds
         finally:
-            ops.WGRAD_SIDE, ops.WGRAD_SIDE_MAX_PIXELS, ops.WGRAD_SIDE_MIN_PIXELS = old, old_lim, old_min
+            ops.WGRAD_SIDE, ops.WGRAD_KEEP_MAX_PIXELS, ops.WGRAD_SIDE_MIN_PIXELS = old, old_lim, old_min
             ops.PROFILE = None
 
     assert ops.WGRAD_SIDE == "auto"                  # the shipped default

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Isolated timing of the 3x3 128->128 weight gradient: Winograd kernel (csrc/wino_wgrad.hip) vs the pixel-reduction GEMM.
+"""Isolated timing of the 3x3 128->128 weight gradient: Winograd kernels (csrc/wino4_wgrad.hip F(4x4), csrc/wino_wgrad.hip F(2x2)) vs the pixel-reduction GEMM.
 TW_B / TW_H / TW_W select the shape (default: the 4B = 16-sample launches of the C2 step)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,8 +31,9 @@ def run(n=20):
     return e0.elapsed_time(e1) / n
 
 
-for mode in ("winograd", "direct"):
-    ops.WINO_WGRAD = mode == "winograd"
+for mode in ((os.environ["TW_ONLY"],) if os.environ.get("TW_ONLY") else ("winograd4", "winograd", "direct")):
+    ops.WINO_WGRAD = mode != "direct"
+    ops.WINO4_WGRAD = mode == "winograd4"
     ms = run()
     ops.PROFILE = []
     run(10)
