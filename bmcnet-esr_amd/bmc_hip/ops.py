@@ -536,9 +536,14 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
 # deterministic).  BMC_WINO_WGRAD=0 (or BMC_WINO=0) leaves them to the pixel-reduction GEMM.
 WINO_WGRAD = os.environ.get("BMC_WINO_WGRAD", "1") != "0"
 # Round 5: the same through F(4x4, 3x3) (csrc/wino4_wgrad.hip: 36 multiplies per 4x4 tile and channel pair, 1.78x fewer than
-# F(2x2)) for launches with at least WINO4_WGRAD_MIN_STAGES stages (4 tiles each) per workgroup: every workgroup writes its full
-# 288 KB slice of partial sums whatever the image size.  BMC_WINO4_WGRAD=0 keeps F(2x2).
-WINO4_WGRAD = os.environ.get("BMC_WINO4_WGRAD", "1") != "0"
+# F(2x2)).  Built, bit-for-bit deterministic, 2.9e-6 against float64 -- and NOT faster on this chip: 0.377 ms against F(2x2)'s
+# 0.382 ms for the 8-image launch at 180x240 (0.44 against 0.40 with the reduction).  Both of its operands are transformed per
+# tile, so every workgroup moves 39 KB through the CU's vector-memory path per 2 304 matrix-pipe cycles (that path takes 1 KB per
+# 40-60 cycles: PMC + ablations) and runs ~100 vector instructions per wave and stage, each of which waits behind the fp32 MFMAs
+# the SIMD partner has queued (in-kernel stamps: the transform phase of a wave takes 2 100 cycles for ~60 instructions).
+# NOTEBOOK.md, "F(4x4) weight gradient", has the numbers.  Off by default; BMC_WINO4_WGRAD=1 routes launches with at least
+# WINO4_WGRAD_MIN_STAGES stages (4 tiles each) per workgroup to it (the tests do).
+WINO4_WGRAD = os.environ.get("BMC_WINO4_WGRAD", "0") != "0"
 WINO4_WGRAD_MIN_STAGES = int(os.environ.get("BMC_WINO4_WGRAD_MIN_STAGES", 24))
 
 

@@ -35,15 +35,19 @@
 #include "dma_ring.h"
 #include <stdlib.h>
 
+#ifndef BMC_W4G_PRIO
+#define BMC_W4G_PRIO 1    // 1: a wave raises its issue priority while it transforms / requests (its SIMD partner multiplies meanwhile)
+#endif
 #ifndef BMC_W4G_ABL
 #define BMC_W4G_ABL 0     // ablation builds (tools/): 1 no MFMA, 2 no DMA, 4 no transforms, 8 no fragment reads, 16 every DMA from the
                           // first stage's pixels (cache hits), 32 no wait for the DMA at the end of a stage
 #endif
 
-#ifndef BMC_W4G_MODE
-#define BMC_W4G_MODE 0    // how the raw strips are requested: 0 waves 0-3 five pieces at the top of the stage, waves 4-7 one behind each
-                          // of their first five positions; 1 every wave one piece behind positions 0, 2, 4, 6, 8 of its own MFMAs;
-                          // 2 the same with register staging (global_load_dwordx4, ds_write_b128 at the end of the stage)
+#ifdef BMC_W4G_STAMP      // diagnostic build (tools/ only): per-wave cycle stamps of workgroup 8, iterations 40..103
+__device__ unsigned long long g_w4g_stamp[8][64][8];
+#define W4G_STAMP(it, k) do { if (blockIdx.x == 8 && (threadIdx.x & 63) == 0 && (it) >= 40 && (it) < 104) g_w4g_stamp[threadIdx.x >> 6][(it) - 40][(k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W4G_STAMP(it, k) do { } while (0)
 #endif
 
 namespace {
@@ -78,7 +82,7 @@ constexpr int XPC = 23, YPC = 16;           // DMA pieces (4 pixels x 64 channel
 constexpr int RAWX = XPC * 256;             // floats
 constexpr int RAWF = (XPC + YPC) * 256;     // floats per raw buffer (39 KB)
 constexpr int NPC = XPC + YPC;
-constexpr int PPW = 5;                      // pieces per wave (8 x 5 = 40 >= 39)
+constexpr int PPW = 8;                      // pieces per wave: waves 0-3 carry 8 each (pieces 0..31), waves 4-7 two each (32..38)
 constexpr int LDSF = 2 * RAWF + 2 * SIMG;   // 153 600 bytes
 
 template <int TG>
@@ -100,96 +104,106 @@ __device__ __forceinline__ void wgrad4_body(const Wgrad4K& a, float* const lds, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    // ---- DMA role: pieces wave, wave + 8, ... of the 39; per piece and lane: pixel slot (row r, column c) of the strip
+    // ---- DMA role.  The CU's vector-memory path takes one 1 KB piece per ~38 cycles (PMC + ablations: a burst of pieces blocks
+    // the issuing waves -- in-order issue -- and with them their MFMAs), so the 39 pieces of a stage are issued where no MFMA waits
+    // behind them: waves 0-3 (which transform first) carry 8 each (pieces w, w + 4, ..., w + 28), spread between the steps of their
+    // transform while their SIMD partners multiply; waves 4-7 two each (32 + w - 4, 36 + w - 4; piece 38 twice) at the top of
+    // THEIR transform.  Per piece and lane: pixel slot (row r, column c) of the strip; pieces < 23 are x pieces, the rest dY pieces.
+    const bool early = wave < 4;          // SIMD partners (w, w + 4) out of phase: requests + transform first / multiply first
     unsigned poff[PPW];       // byte offset from the stage's base pixel (interior stages)
     int prc[PPW];             // r | c << 8, or -1 for a slot that is not a pixel
+    unsigned pla[PPW];        // LDS byte address of the piece in raw buffer 0
+    unsigned pxm = 0;         // bit j: piece j is an x piece
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int p = wave + 8 * j;
+        const int p = early ? wave + 4 * j : min(32 + (wave - 4) + 4 * (j & 1), NPC - 1);
         int r, c;
-        bool real;
+        bool real = true;
         if (p < XPC) { const int q = 4 * p + (lane >> 4); r = q / 18; c = q - 18 * r; real = q < 90; }
-        else { const int q = 4 * (p - XPC) + (lane >> 4); r = q >> 4; c = q & 15; real = p < NPC; }
+        else { const int q = 4 * (p - XPC) + (lane >> 4); r = q >> 4; c = q & 15; }
         poff[j] = real ? (unsigned)(((r * a.W + c) * 128 + (lane & 15) * 4) * 4) : 0u;
         prc[j] = real ? (r | (c << 8)) : -1;
+        pla[j] = lds_raw + (unsigned)(p * 1024);
+        pxm |= p < XPC ? 1u << j : 0u;
     }
     unsigned zm = 0;          // bit j: this lane's quad of piece j is a pixel outside the image (stage in flight)
 
     const int per_img = a.TY * a.SX;
     const int st0 = (int)((long long)a.nstages * split / a.nsplit), st1 = (int)((long long)a.nstages * (split + 1) / a.nsplit);
-    // (image, tile row, group of 4 tiles) of the next stage to request, advanced incrementally
+    // (image, tile row, group of 4 tiles) of the next stage to request, advanced incrementally; per tile row: the image's base
+    // pointers (channel half included), the first pixel of the two strips' first rows, "the rows touch the image border"
     int nb = st0 / per_img, nty, nsx;
     {
         const int r = st0 - nb * per_img;
         nty = r / a.SX; nsx = r - nty * a.SX;
     }
     nb = __builtin_amdgcn_readfirstlane(nb); nty = __builtin_amdgcn_readfirstlane(nty); nsx = __builtin_amdgcn_readfirstlane(nsx);
+    const float* xbat = nullptr;
+    const float* ybat = nullptr;
+    const float* xrow = nullptr;
+    const float* yrow = nullptr;
+    bool rowborder = false;
+    auto row_setup = [&]() __attribute__((always_inline)) {
+        xbat = uni(src_batch_ptr(a.x, nb) + kh * CH);
+        ybat = uni(src_batch_ptr(a.a, nb) + chh * CH);
+        const int y0 = 4 * nty - 1 + TG;                               // first staged patch row (TG = 1: patch rows 1..5)
+        rowborder = y0 < 0 || y0 + 4 >= a.H;
+        xrow = xbat + (long long)y0 * a.W * 128;                       // (only used when the rows are inside the image)
+        yrow = ybat + (long long)(4 * nty) * a.W * 128;
+    };
+    row_setup();
 
     // requests of the raw strips of the next stage: rq_begin fixes the stage (scalar state) and advances the cursor, rq_piece(j)
-    // issues this wave's piece j into raw buffer rq_rb
-    f32x4 stg[PPW];
+    // issues this wave's piece j into the raw buffer rq_begin named
     const float* rq_xs = nullptr;
     const float* rq_ys = nullptr;
-    int rq_y0 = 0, rq_x0 = 0, rq_yd = 0, rq_xd = 0, rq_rb = 0;
+    int rq_y0 = 0, rq_x0 = 0;
+    unsigned rq_lo = 0;
     bool rq_border = false;
     auto rq_begin = [&](const int rb) __attribute__((always_inline)) {
-        rq_rb = rb;
-        rq_y0 = 4 * nty - 1 + TG; rq_x0 = 16 * nsx - 1;               // first staged patch row / column (TG = 1: patch rows 1..5)
-        rq_yd = 4 * nty; rq_xd = 16 * nsx;                             // dY strip
-        rq_border = rq_y0 < 0 || rq_y0 + 4 >= a.H || rq_x0 < 0 || rq_x0 + 17 >= a.W;
-        const float* const xb = src_batch_ptr(a.x, nb) + kh * CH;
-        const float* const yb = src_batch_ptr(a.a, nb) + chh * CH;
+        rq_lo = (unsigned)(rb * RAWF * 4);
+        rq_y0 = 4 * nty - 1 + TG; rq_x0 = 16 * nsx - 1;
+        rq_border = rowborder || nsx == 0 || rq_x0 + 17 >= a.W;
         // interior: base = the strip's first pixel; border: base = the image (per-lane offsets are absolute then)
-        rq_xs = uni(rq_border ? xb : xb + ((long long)rq_y0 * a.W + rq_x0) * 128);
-        rq_ys = uni(rq_border ? yb : yb + ((long long)rq_yd * a.W + rq_xd) * 128);
+        rq_xs = rq_border ? xbat : xrow + rq_x0 * 128;
+        rq_ys = rq_border ? ybat : yrow + (rq_x0 + 1) * 128;
         zm = 0;
         if (BMC_W4G_ABL & 16) return;
         if (++nsx == a.SX) {
             nsx = 0;
             if (++nty == a.TY) { nty = 0; ++nb; }
+            row_setup();
         }
     };
     auto rq_piece = [&](const int j) __attribute__((always_inline)) {
-        const int p = wave + 8 * j;
-        if (p >= NPC || (BMC_W4G_ABL & 2)) return;
-        const bool isx = p < XPC;
+        if (BMC_W4G_ABL & 2) return;
         unsigned o = poff[j];
         if (rq_border) {
             asm volatile("; image border" ::: "memory");
+            const bool isx = (pxm >> j) & 1;
             const int r = prc[j] & 255, c = (prc[j] >> 8) & 255;
-            const int y = (isx ? rq_y0 : rq_yd) + r, x = (isx ? rq_x0 : rq_xd) + c;
+            const int y = (isx ? rq_y0 : rq_y0 + 1 - TG) + r, x = (isx ? rq_x0 : rq_x0 + 1) + c;
             const bool real = prc[j] >= 0;
             const bool inside = y >= 0 && y < a.H && x >= 0 && x < a.W;
             const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
             o = real ? (unsigned)(((yc * a.W + xc) * 128 + (lane & 15) * 4) * 4) : 0u;
             zm |= (real && !inside) ? (1u << j) : 0u;
         }
-        if (BMC_W4G_MODE == 2) {
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(stg[j]) : "v"(o), "s"(isx ? rq_xs : rq_ys) : "memory");
-            return;
-        }
-        const unsigned la = lds_raw + (unsigned)((rq_rb * RAWF + p * 256) * 4);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(o), "s"(isx ? rq_xs : rq_ys), "s"(la) : "memory");
-    };
-    auto rq_land = [&]() __attribute__((always_inline)) {       // (mode 2) the staged quads -> raw buffer, once they have arrived
-        if (BMC_W4G_MODE != 2 || (BMC_W4G_ABL & 2)) return;
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            asm volatile("" : "+v"(stg[j]));
-            if (wave + 8 * j < NPC) *reinterpret_cast<f32x4*>(rawb + rq_rb * RAWF + (wave + 8 * j) * 256 + lane * 4) = stg[j];
-        }
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(o), "s"(((pxm >> j) & 1) ? rq_xs : rq_ys),
+                     "s"(pla[j] + rq_lo) : "memory");
     };
     auto request = [&](const int rb) __attribute__((always_inline)) {
         rq_begin(rb);
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) rq_piece(j);
+        for (int j = 0; j < PPW; ++j)
+            if (early || j < 2) rq_piece(j);
     };
     // after the requests have landed, before the barrier that publishes them: pixels outside the image become zeros
     auto patch = [&](const int rb) __attribute__((always_inline)) {
         if (__builtin_amdgcn_ballot_w64(zm != 0) == 0) return;
 #pragma unroll
         for (int j = 0; j < PPW; ++j)
-            if ((zm >> j) & 1) *reinterpret_cast<f32x4*>(rawb + rb * RAWF + (wave + 8 * j) * 256 + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((zm >> j) & 1) *reinterpret_cast<f32x4*>(rawb + (pla[j] - lds_raw) / 4 + rb * RAWF + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
     // ---- producer role (waves 0-5): item = (tile t, channel pair cp) of the stage
@@ -218,79 +232,105 @@ __device__ __forceinline__ void wgrad4_body(const Wgrad4K& a, float* const lds, 
         *reinterpret_cast<f32x2*>(dst + 5 * PIMG) = w[3];
         return m1;
     };
-    auto transform = [&](const float* const raw, float* const img) __attribute__((always_inline)) {
-        if (BMC_W4G_ABL & 4) return;
+    // `pieces`: this wave issues its DMA pieces of the stage in flight between the steps (waves 0-3)
+    auto transform = [&](const float* const raw, float* const img, const bool pieces) __attribute__((always_inline)) {
+        if (BMC_W4G_ABL & 4) {
+            if (pieces) {
+#pragma unroll
+                for (int j = 0; j < PPW; ++j) rq_piece(j);
+            }
+            return;
+        }
+        auto ld2 = [](const float* p) __attribute__((always_inline)) { return *reinterpret_cast<const f32x2*>(p); };
         if (wave < 2) {
             // the lone xi row of x: xi = 0 = (4 0 -5 0 1 0) on patch rows 0, 2, 4; xi = 5 = (0 4 0 -5 0 1) on patch rows 1, 3, 5 --
-            // staged rows 0, 2, 4 either way
+            // staged rows 0, 2, 4 either way.  All 18 reads first, the pieces between the columns' sums
             const float* const s = raw + (4 * pt) * CH + 2 * cp;
-            f32x2 w[6];
+            f32x2 d[3][6], w[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) d[k][c] = ld2(s + (2 * k * 18 + c) * CH);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                const f32x2 d0 = *reinterpret_cast<const f32x2*>(s + c * CH), d2 = *reinterpret_cast<const f32x2*>(s + (2 * 18 + c) * CH),
-                            d4 = *reinterpret_cast<const f32x2*>(s + (4 * 18 + c) * CH);
-                w[c] = 4.f * d0 - 5.f * d2 + d4;
+                if (pieces) rq_piece(c);
+                w[c] = 4.f * d[0][c] - 5.f * d[1][c] + d[2][c];
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (pieces) { rq_piece(6); rq_piece(7); }
             xcols(w, img + IMG + ((TG == 0 ? 0 : 2) * 6) * PIMG + pt * CH + 2 * cp);
         } else if (wave < 4 || wave >= 6) {
             // the two xi rows on patch rows 1..4 (staged rows 1 - TG ..): xi = 1, 2 = (r4 - 4 r2) +- (r3 - 4 r1); xi = 3, 4 = (r4 - r2) +- 2 (r3 - r1);
-            // waves 2-3 the sum, waves 6-7 the difference
+            // waves 2-3 the sum, waves 6-7 the difference.  Reads in two halves of three columns
             const float* const s = raw + ((1 - TG) * 18 + 4 * pt) * CH + 2 * cp;
             constexpr float al = TG == 0 ? -4.f : -1.f;
             const float ga = (TG == 0 ? 1.f : 2.f) * (wave >= 6 ? -1.f : 1.f);
-            f32x2 w[6];
+            f32x2 d[4][6], w[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k][c] = ld2(s + (k * 18 + c) * CH);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                const f32x2 r1 = *reinterpret_cast<const f32x2*>(s + c * CH), r2 = *reinterpret_cast<const f32x2*>(s + (18 + c) * CH),
-                            r3 = *reinterpret_cast<const f32x2*>(s + (2 * 18 + c) * CH), r4 = *reinterpret_cast<const f32x2*>(s + (3 * 18 + c) * CH);
-                w[c] = (r4 + al * r2) + ga * (r3 + al * r1);
+                if (pieces) rq_piece(c);
+                w[c] = (d[3][c] + al * d[1][c]) + ga * (d[2][c] + al * d[0][c]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (pieces) { rq_piece(6); rq_piece(7); }
             xcols(w, img + IMG + (((TG == 0 ? 1 : 0) + (wave >= 6 ? 1 : 0)) * 6) * PIMG + pt * CH + 2 * cp);
         } else {
             // dY (waves 4-5), all three xi of the group: (y0, (y0 + y2) +- (y1 + y3)) or ((y0 + 4 y2) +- 2 (y1 + 4 y3), y3)
             const float* const s = raw + RAWX + (4 * pt) * CH + 2 * cp;
             constexpr float ka = TG == 0 ? 1.f : 4.f, la = TG == 0 ? 1.f : 2.f;
-            f32x2 u0[4], u1[4], u2[4];
+            f32x2 y[4][4], u0[4], u1[4], u2[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k][c] = ld2(s + (16 * k + c) * CH);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f32x2 y0 = *reinterpret_cast<const f32x2*>(s + c * CH), y1 = *reinterpret_cast<const f32x2*>(s + (16 + c) * CH),
-                            y2 = *reinterpret_cast<const f32x2*>(s + (32 + c) * CH), y3 = *reinterpret_cast<const f32x2*>(s + (48 + c) * CH);
-                const f32x2 p = y0 + ka * y2, q = y1 + ka * y3;
-                if (TG == 0) { u0[c] = y0; u1[c] = p + la * q; u2[c] = p - la * q; }
-                else { u0[c] = p + la * q; u1[c] = p - la * q; u2[c] = y3; }
+                const f32x2 p = y[0][c] + ka * y[2][c], q = y[1][c] + ka * y[3][c];
+                if (TG == 0) { u0[c] = y[0][c]; u1[c] = p + la * q; u2[c] = p - la * q; }
+                else { u0[c] = p + la * q; u1[c] = p - la * q; u2[c] = y[3][c]; }
             }
-            float* const d = img + pt * CH + 2 * cp;
-            ycols(u0, d);
-            const f32x2 m11 = ycols(u1, d + 6 * PIMG);
-            ycols(u2, d + 12 * PIMG);
+            float* const dd = img + pt * CH + 2 * cp;
+            ycols(u0, dd);
+            const f32x2 m11 = ycols(u1, dd + 6 * PIMG);
+            ycols(u2, dd + 12 * PIMG);
             if (TG == 0) bsum += m11;         // xi = 1, nu = 1: the sum of the tile's 16 dY pixels
         }
     };
 
-    // ---- matrix role: 9 positions x 2 k-steps on the stage's images
-    auto multiply = [&](const float* const img, const bool pieces) __attribute__((always_inline)) {
+    // ---- matrix role: 9 positions x 2 k-steps on the stage's images.  The operand fragments of position i + 2 are requested
+    // before the MFMAs of position i are issued (a ring of three register sets): no MFMA waits for an LDS round trip
+    auto multiply = [&](const float* const img) __attribute__((always_inline)) {
+        float af[3][2], bf[3][2];
+        auto frag = [&](const int i) __attribute__((always_inline)) {
+            const int u = i / 3, j = i - 3 * u, sl = i % 3;
 #pragma unroll
-        for (int u = 0; u < 3; ++u)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                float af[2], bf[2];
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    if (BMC_W4G_ABL & 8) { af[ks] = 1.f + ks; bf[ks] = 2.f + j; asm volatile("" : "+v"(af[ks]), "+v"(bf[ks])); continue; }
-                    af[ks] = img[aoff + (6 * u + j) * PIMG + 2 * ks * CH];
-                    bf[ks] = img[boff + (6 * u + j) * PIMG + 2 * ks * CH];
-                }
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    if (BMC_W4G_ABL & 1) acc[3 * u + j][0] += af[ks] * bf[ks];
-                    else acc[3 * u + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks], acc[3 * u + j], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (BMC_W4G_MODE == 0 ? (pieces && 3 * u + j < PPW) : (pieces && (3 * u + j) % 2 == 0)) {
-                    rq_piece(BMC_W4G_MODE == 0 ? 3 * u + j : (3 * u + j) / 2);      // this stage's DMA pieces behind the MFMAs
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int ks = 0; ks < 2; ++ks) {
+                if (BMC_W4G_ABL & 8) { af[sl][ks] = 1.f + ks; bf[sl][ks] = 2.f + j; asm volatile("" : "+v"(af[sl][ks]), "+v"(bf[sl][ks])); continue; }
+                af[sl][ks] = img[aoff + (6 * u + j) * PIMG + 2 * ks * CH];
+                bf[sl][ks] = img[boff + (6 * u + j) * PIMG + 2 * ks * CH];
             }
+        };
+        frag(0);
+        frag(1);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 2 < 9) frag(i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (BMC_W4G_ABL & 1) acc[i][0] += af[i % 3][ks] * bf[i % 3][ks];
+                else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i % 3][ks], bf[i % 3][ks], acc[i], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- prologue: stage st0 raw -> image 0, stage st0 + 1 requested
@@ -298,32 +338,43 @@ __device__ __forceinline__ void wgrad4_body(const Wgrad4K& a, float* const lds, 
     if (n > 0) {
         request(0);
         dma_wait<0>();
-        rq_land();
         patch(0);
         ring_publish();
         if (n > 1) request(1);
-        transform(rawb, imgb);
+        transform(rawb, imgb, false);
         dma_wait<0>();
-        if (n > 1) { rq_land(); patch(1); }
+        if (n > 1) patch(1);
         ring_publish();
     }
-    const bool early = wave < 4;          // SIMD partners (w, w + 4) out of phase: requests + transform first / multiply first
     for (int it = 0; it < n; ++it) {
         const float* const img = imgb + (it & 1) * SIMG;
         const bool req = it + 2 < n, more = it + 1 < n;                      // stage it + 2 -> the raw buffer stage it was made from
+        W4G_STAMP(it, 0);
         if (req) rq_begin(it & 1);
-        if (BMC_W4G_MODE == 0 && early && req) {
-#pragma unroll
-            for (int j = 0; j < PPW; ++j) rq_piece(j);
+        W4G_STAMP(it, 1);
+        if (early) {
+            if (BMC_W4G_PRIO) __builtin_amdgcn_s_setprio(3);
+            if (more) transform(rawb + ((it + 1) & 1) * RAWF, imgb + ((it + 1) & 1) * SIMG, req);
+            else if (req) { for (int j = 0; j < PPW; ++j) rq_piece(j); }
+            if (BMC_W4G_PRIO) __builtin_amdgcn_s_setprio(0);
         }
-        if (early && more) transform(rawb + ((it + 1) & 1) * RAWF, imgb + ((it + 1) & 1) * SIMG);
+        W4G_STAMP(it, 2);
         __builtin_amdgcn_sched_barrier(0);
-        multiply(img, (BMC_W4G_MODE != 0 || !early) && req);
+        multiply(img);
         __builtin_amdgcn_sched_barrier(0);
-        if (!early && more) transform(rawb + ((it + 1) & 1) * RAWF, imgb + ((it + 1) & 1) * SIMG);
+        W4G_STAMP(it, 3);
+        if (!early) {
+            if (BMC_W4G_PRIO) __builtin_amdgcn_s_setprio(3);
+            if (req) { rq_piece(0); rq_piece(1); }
+            if (more) transform(rawb + ((it + 1) & 1) * RAWF, imgb + ((it + 1) & 1) * SIMG, false);
+            if (BMC_W4G_PRIO) __builtin_amdgcn_s_setprio(0);
+        }
+        W4G_STAMP(it, 4);
         if (!(BMC_W4G_ABL & 32)) dma_wait<0>();
-        if (req) { rq_land(); patch(it & 1); }
+        W4G_STAMP(it, 5);
+        if (req) patch(it & 1);
         ring_publish();
+        W4G_STAMP(it, 6);
     }
 
     // ---- partial sums in register order: part[split][type][wave][position 3 u + j][quad m][lane][4] -- D row 8 m + 4 (l >> 5) + e
@@ -419,6 +470,12 @@ __global__ __launch_bounds__(256) void wino4_wgrad_reduce_kernel(const float* __
 }
 
 }  // namespace
+
+#ifdef BMC_W4G_STAMP
+extern "C" int bmc_w4g_read_stamps(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w4g_stamp), sizeof(unsigned long long) * 8 * 64 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 static long long w4g_stages(int B, int H, int W) { return (long long)B * ((H + 3) / 4) * (((W + 3) / 4 + TS - 1) / TS); }
 
