@@ -12,11 +12,12 @@ BASELINE.json configs[1] per GPU (BMCNet x4, 180x240 -> 720x960, bs=4/GPU, fp32,
 configs[2] (bs=32 over 8 GPUs) is exactly the N=8 point.  Inputs (events) are resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line.
 
-At N = 1 the same line also carries `extra` blocks measured after the headline run (`--also config3,config4,infer`,
+At N = 1 the same line also carries `extra` blocks measured after the headline run (`--also config3,config4,infer,dist1`,
 the default; `--also none` skips them): BASELINE configs[3] (EventZoom 31x56, its own bf16 arithmetic, and fp32 beside it),
 the reference's literal NFS LR shape (45x80, bs 2: config/train_nfs.yml:71), configs[4]'s per-GPU shape (RGB 180x190, T = 16
 windows, 8 sequences, per-window recompute) and the streaming-inference latency per window (infer_BMCNet.py:44-68)
-with and without HIP-graph replay.  They are short (a few steps each), labelled with their own workload strings, and
+with and without HIP-graph replay, and (`dist1`) the C2 step once more with the multi-GPU path's gradient reducer and an RCCL
+all-reduce over a world of one rank in the timed region.  They are short (a few steps each), labelled with their own workload strings, and
 never enter `value`.
 """
 import argparse
@@ -170,10 +171,12 @@ def cpu_baseline(dev=None, budget_hw=(180, 240), threads=16):
 # Executed / algorithmic multiplies of a kernel kind (ops.py's profile names): the Winograd kernels do not execute the
 # multiplies the metric counts (F(4x4): 36 of 144 per 4x4 tile; F(2x2): 16 of 36 per 2x2 tile), the fused centre chain's
 # backward executes 5 of the 6 C^2 it is credited with.  `roofline.frac` is built on EXECUTED work: a utilisation, <= 1.
-EXECUTED = {"wino4_conv<9,128>": 36.0 / 144.0, "wino_conv<9,128>": 16.0 / 36.0, "wgrad_wino<9>": 16.0 / 36.0, "chain_kernel<bwd>": 5.0 / 6.0}
+EXECUTED = {"wino4_conv<9,128>": 36.0 / 144.0, "wino_conv<9,128>": 16.0 / 36.0, "wgrad_wino<9>": 16.0 / 36.0, "wgrad_wino4<9>": 36.0 / 144.0,
+            "chain_kernel<bwd>": 5.0 / 6.0}
 KERNEL_LABEL = {"wino4_conv<9,128>": "wino4_conv_kernel [Winograd F(4x4,3x3) on the fp32 MFMA, csrc/wino4.hip]",
                 "wino_conv<9,128>": "wino2_conv_kernel [Winograd F(2x2,3x3) on the fp32 MFMA, csrc/wino.hip]",
-                "wgrad_wino<9>": "wino_wgrad_kernel [Winograd F(2x2,3x3) weight gradient, csrc/wino_wgrad.hip]"}
+                "wgrad_wino<9>": "wino_wgrad_kernel [Winograd F(2x2,3x3) weight gradient, csrc/wino_wgrad.hip]",
+                "wgrad_wino4<9>": "wino4_wgrad_kernel [Winograd F(4x4,3x3) weight gradient, csrc/wino4_wgrad.hip]"}
 PMC_NAME = {"wino4_conv<9,128>": "wino4_conv_kernel", "wino_conv<9,128>": "wino2_conv_kernel"}
 
 
@@ -222,7 +225,8 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
         alone = {}
         if agg is not agg_alone and agg_alone is not None and kind in agg_alone:
             ra = row(kind, agg_alone)
-            alone = {"avg_launch_ms_alone": ra["avg_launch_ms"], "frac_alone": ra["frac"], "hbm_frac_alone": ra["hbm_frac"]}
+            alone = {"avg_launch_ms_alone": ra["avg_launch_ms"], "frac_alone": ra["frac"], "hbm_frac_alone": ra["hbm_frac"],
+                     "ms_per_step_alone": ra["ms_per_step"]}
         return {"kernel": kind, **alone, "hbm_algorithmic_GBps": round(hbm, 1) if hbm else None,
                 "hbm_frac": round(hbm / HBM_PEAK_GBPS, 4) if hbm else None, "launches": n, "avg_launch_ms": round(ms / n, 4), "ms_per_step": round(ms, 2),
                 "share_of_profiled_kernel_time": round(ms / total_ms, 4),
@@ -233,7 +237,11 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
     mfma_kinds = [k for k, v in agg.items() if v[1] > 0]
     dom = max(mfma_kinds, key=lambda k: agg[k][2])
     n, fl, ms, _ = agg[dom]
-    d = row(dom)
+    d_situ = row(dom)
+    # Headline figures: the kernel BY ITSELF (the one-stream step) when the timed step runs two streams -- a launch's in-situ
+    # duration then contains CUs shared with the weight-gradient stream and understates every kernel; the
+    # in-situ-with-sharing figures stand beside them under `in_situ_shared`
+    d = row(dom, agg_alone) if agg_alone is not None and dom in agg_alone else d_situ
     # HBM bytes per launch and the PMC figures: from the committed rocprofv3 PMC passes over one bench step (the AVERAGE in-step
     # launch of this kernel, FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py) --
     # STATIC data, not measured in this run, attached ONLY when the summary was collected on this very workload and kernel
@@ -250,21 +258,23 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
            "achieved": d["executed_tflops"], "peak": round(peak, 1), "unit": "TFLOP/s", "frac": d["frac"],
            "achieved_algorithmic": d["achieved_algorithmic_tflops"], "frac_algorithmic": d["frac_algorithmic"],
            "hbm_algorithmic_GBps": d["hbm_algorithmic_GBps"], "hbm_frac": d["hbm_frac"],
-           "note": "achieved / frac: EXECUTED matrix FLOPs of the kernel (algorithmic x %.4f) over its in-situ time, against the dense "
+           "note": "achieved / frac: EXECUTED matrix FLOPs of the kernel (algorithmic x %.4f) over its launch time, against the dense "
                    "fp32 MFMA peak -- a utilisation; the algorithmic rate (2 x 9 x Cin x Cout FLOP per pixel, what the metric counts) is "
                    "achieved_algorithmic.%s" % (EXECUTED.get(dom, 1.0),
-                   "  In the timed step the weight-gradient kernels run CONCURRENTLY on a second stream, so the in-situ duration of a "
-                   "launch (these figures, and rocprofv3 --stats of this command) contains CUs shared with them and the kernel times "
-                   "add up to more than the step: `alone` is the kernel by itself, `step_frac_executed` the whole step as one "
-                   "utilisation (all executed matrix FLOPs over the step time)." if concurrent else ""),
+                   "  In the timed step the weight-gradient kernels run CONCURRENTLY on a second stream: a launch's in-situ duration "
+                   "(`in_situ_shared`, and rocprofv3 --stats of this command: profiles/r05_bench_fp32_kernel_stats.csv) contains CUs "
+                   "shared with them and the kernel times add up to more than the step.  The headline figures (achieved, frac, "
+                   "avg_launch_ms) are therefore the kernel BY ITSELF: the same step once more on one stream (BMC_WGRAD_STREAM=0; "
+                   "rocprofv3 --stats of that command: profiles/r05_bench_fp32_onestream_kernel_stats.csv).  `step_frac_executed` is the "
+                   "whole two-stream step as one utilisation, `mfma_floor_ms` what its executed matrix FLOPs cost at the dense peak." if concurrent else ""),
            "traffic": traffic, "traffic_static": traffic is not None,
            "avg_launch_ms": d["avg_launch_ms"], "flop_per_launch": fl / n, "launches_per_step": n,
            "isolated_2B_128to128": iso, "pmc": pmc,
            "streams": "weight-gradient kernels on a second stream beside the data-gradient chain (ops.wgrad_side): in-situ durations include shared CUs" if concurrent else "one stream",
-           "alone": None if agg_alone is None else dict(
-               {k: row(dom, agg_alone)[k] for k in ("avg_launch_ms", "ms_per_step", "executed_tflops", "frac", "achieved_algorithmic_tflops")},
-               note="the same step with every kernel on ONE stream (BMC_WGRAD_STREAM=0): the kernel with the chip to itself; "
-                    "rocprofv3 --stats of that command: profiles/r04_bench_fp32_onestream_kernel_stats.csv"),
+           "in_situ_shared": None if agg_alone is None else dict(
+               {k: d_situ[k] for k in ("avg_launch_ms", "ms_per_step", "executed_tflops", "frac", "achieved_algorithmic_tflops")},
+               note="the kernel's launches inside the timed two-stream step, CUs shared with the weight-gradient stream"),
+           "alone_ms_per_step": None if agg_alone is None else round(sum(v[2] for v in agg_alone.values()), 1),
            # every kernel kind with >= 4 % of the profiled kernel time, the same two rates each
            "kernels": [row(k) for k in sorted(agg, key=lambda k: -agg[k][2]) if agg[k][2] >= 0.04 * total_ms],
            "profiled_kernel_ms_per_step": round(total_ms, 1)}
@@ -273,6 +283,7 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
         ex_flops = sum(v[1] * EXECUTED.get(k, 1.0) for k, v in agg.items())
         out["step_executed_tflops_per_gpu"] = round(ex_flops / (step_ms * 1e-3) / 1e12, 2)
         out["step_frac_executed"] = round(ex_flops / (step_ms * 1e-3) / 1e12 / peak, 4)
+        out["mfma_floor_ms"] = round(ex_flops / (peak * 1e12) * 1e3, 1)      # the step's executed matrix FLOPs at the dense peak
     return out
 
 
@@ -389,13 +400,14 @@ def timed(fn, warmup, steps, use_dist, dev):
     return dt, loss
 
 
-def extra_train(dev, tag, B, H, W, L, math, steps, warmup, recompute=False, graph=False):
-    """A short side measurement of another BASELINE configuration on this GPU: same step code, its own shape and arithmetic."""
+def extra_train(dev, tag, B, H, W, L, math, steps, warmup, recompute=False, graph=False, use_dist=False):
+    """A short side measurement of another BASELINE configuration on this GPU: same step code, its own shape and arithmetic.
+    use_dist: with the gradient reducer (hooks + finish() + RCCL all-reduce) in the step; the process group must exist."""
     from bmc_hip import ops
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)
-    wl = Workload(dev, B, H, W, L, 128, 5, math, recompute=recompute, graph=graph)
-    dt, loss = timed(wl.step, warmup, steps, False, dev)
+    wl = Workload(dev, B, H, W, L, 128, 5, math, recompute=recompute, graph=graph, use_dist=use_dist)
+    dt, loss = timed(wl.step, warmup, steps, use_dist, dev)
     out = {"workload": workload_string(128, 5, H, W, B, L, math, recompute=recompute, graph=graph), "dtype": DTYPE[math],
            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
            "value": round(B * (L - 1) * steps / dt, 2), "unit": "LR-voxel-frames/s",
@@ -451,8 +463,8 @@ def main():
     ap.add_argument("--math", default=os.environ.get("BMC_MATH", "fp32"), choices=["fp32", "bf16x6", "bf16"],
                     help="arithmetic of the MFMA kernels for the headline measurement (default fp32 = native fp32 MFMA)")
     ap.add_argument("--no-bf16x6", action="store_true", help="skip the additional bf16x6-mode measurement")
-    ap.add_argument("--also", default="config3,config4,infer",
-                    help="comma list of extra blocks appended to the JSON line at --gpus 1 (config3, config4, infer; 'none' = skip)")
+    ap.add_argument("--also", default="config3,config4,infer,dist1",
+                    help="comma list of extra blocks appended to the JSON line at --gpus 1 (config3, config4, infer, dist1; 'none' = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -576,6 +588,22 @@ def main():
                     extra_train(dev, "c4", 8, 180, 190, 17, "fp32", 2, 1, recompute=True)
             if "infer" in also:
                 extra["streaming inference latency"] = extra_infer(dev)
+            if "dist1" in also:
+                # the multi-GPU step's own code on ONE rank: GradAllReducer (hooks, finish(), bucket staging) + an RCCL all-reduce
+                # over a world of 1 inside the timed region, next to the plain step (`ms_per_step` of this line) -- what the
+                # reducer costs before an 8-GPU node ever runs it
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29541")
+                try:
+                    dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+                    r = extra_train(dev, "dist1", 4, 180, 240, 9, "fp32", 5, 2, use_dist=True)
+                    r["plain_step_ms"] = out["ms_per_step"]
+                    extra["C2 step with the gradient reducer + 1-rank RCCL all-reduce in the timed region"] = r
+                except Exception as e:      # (an RCCL that refuses a world of one must not cost the headline line)
+                    extra["C2 step with the gradient reducer + 1-rank RCCL all-reduce in the timed region"] = {"error": repr(e)[:300]}
+                finally:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dev)
