@@ -28,12 +28,6 @@ FUSE_CHAIN = os.environ.get("BMC_FUSE_CHAIN", "1") != "0"
 _CHAIN_CACHE = {}
 
 
-# bf16x6 is an fp32-equivalent mode: the (native fp32) fused chain is a valid member of it
-CHAIN_IN_BF16X6 = os.environ.get("BMC_CHAIN_BF16X6", "1") != "0"
-
-
-FUSE_FIRST = os.environ.get("BMC_FUSE_FIRST", "1") != "0"      # BIEFirstFn for the last block's local BIE
-
 
 # Attention without the value tensor (fp32 arithmetic modes).  v = W_v x + b_v enters the BIE twice -- the Gram matrix
 # att = scale * c^T v and the product out = softmax(att) v -- and both are linear in v, so with G0 = c^T x (the same
@@ -107,7 +101,8 @@ def _value_param_grads(p, dM, tg, da, G0, sc, w_params, b_params, npx):
 
 
 def chain_supported(Cn):
-    return FUSE_CHAIN and (ops.MATH == 0 or (ops.MATH == 3 and CHAIN_IN_BF16X6)) and Cn in (32, 64, 128)
+    # (bf16x6 is an fp32-equivalent mode: the native fp32 fused chain is a valid member of it)
+    return FUSE_CHAIN and ops.MATH in (0, 3) and Cn in (32, 64, 128)
 
 
 def _chain_streams(wf, wc, Cn):
@@ -636,7 +631,7 @@ class Unstack2Fn(torch.autograd.Function):
         """apply() + the gradient-pair tags on the two views (ops.GradPair): consumers that know the protocol write their
         input gradients into the halves of one buffer, and backward below hands it on without a copy."""
         a, b = Unstack2Fn.apply(t)
-        if ops.GRAD_PAIRS and t.requires_grad and a.grad_fn is not None:
+        if t.requires_grad and a.grad_fn is not None:
             pair = ops.GradPair(t.shape[0] // 2, t.shape)
             a._bmc_gslot, b._bmc_gslot = (pair, 0), (pair, 1)
             a.grad_fn.pair = pair        # backward drops the pair's reference to the buffer (graph nodes outlive their backward)

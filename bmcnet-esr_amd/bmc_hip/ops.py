@@ -477,7 +477,7 @@ def _zeros(device):
     return z
 
 
-TAP_SPLIT_TILES = int(os.environ.get("BMC_TAP_SPLIT_TILES", 8))
+TAP_SPLIT_TILES = 8
 
 
 def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, device, flops=0.0, want_bias=False):
@@ -495,7 +495,6 @@ def pgemm_raw(a_src: lib.Src, srcs: List[lib.Src], B, H, W, taps, bpg, M, N, dev
         tiles = (H * W + 63) // 64
         target = 256
     other = G * ((mpad + 127) // 128) * n_nblk
-    target = int(os.environ.get("BMC_PGEMM_TARGET", target))
     nsplit = max(1, min(bpg * tiles, target // max(other, 1)))
     # small images: fewer than TAP_SPLIT_TILES pixel tiles per workgroup -> one tap row per workgroup, a third of the splits
     # (every split writes a whole slab: at 31x56 the slab writes cost as much as the MFMAs; bmc_pgemm_args_t.tap_groups)
@@ -796,13 +795,9 @@ class _SideState:
         self.dev = dev
         # the device's lowest stream priority: the data-gradient chain (critical path) gets the CUs first, the weight gradients
         # what it leaves (C2: 745.5 vs 750.2 ms at the default priority, alternating runs; small frames: no difference)
-        prio = os.environ.get("BMC_SIDE_PRIO", "low")
-        if prio == "low":
-            h = C.c_void_p()
-            lib.call(lib._stream_low, "bmc_stream_create_low_priority", C.byref(h))
-            self.stream = torch.cuda.ExternalStream(h.value, device=dev)
-        else:
-            self.stream = torch.cuda.Stream(device=dev, priority=int(prio))
+        h = C.c_void_p()
+        lib.call(lib._stream_low, "bmc_stream_create_low_priority", C.byref(h))
+        self.stream = torch.cuda.ExternalStream(h.value, device=dev)
         self.raw = self.stream.cuda_stream
         self.event = torch.cuda.Event()
         self.keep, self.armed, self.side, self.task = [], False, False, -1
@@ -1236,9 +1231,6 @@ def _wgrad_plain(g, x, spec, w_param, b_param, taps):
         slabs, nsplit, _, bsl = pgemm_raw(a_src, [x_src], B, H, W, taps,
                                           B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)
         return reduce_wgrad(slabs, nsplit, 1, taps, Cout, spec, dev, bsl, w_param, b_param, w_param.shape)
-
-
-GRAD_PAIRS = os.environ.get("BMC_GRAD_PAIRS", "1") != "0"
 
 
 class GradPair:

@@ -281,13 +281,10 @@ int bmc_conv1p_launch(ConvK k, int cus, hipStream_t st) {
     for (int i = 0; i < k.nsrc; ++i)
         if (hw * k.src[i].pix_stride * 4 >= (1ll << 32)) return 0;
     k.ntiles = (int)ntiles;
-    static const int depth = getenv("BMC_CONV1P_DEPTH") ? atoi(getenv("BMC_CONV1P_DEPTH")) : 1;      // (A/B runs)
-    const bool deep = k.nchunks == 8 && depth == 2;
-    const int per_cu = (k.nchunks == 8 && !deep) ? 2 : 1;
+    const int per_cu = k.nchunks == 8 ? 2 : 1;
     const long long max_blocks = (long long)per_cu * cus;
     dim3 grid((unsigned)(ntiles < max_blocks ? ntiles : max_blocks)), block(512);
-    if (deep) hipLaunchKernelGGL((conv1p_kernel<8, 2>), grid, block, 0, st, k);
-    else if (k.nchunks == 8) hipLaunchKernelGGL((conv1p_kernel<8, 1>), grid, block, 0, st, k);
+    if (k.nchunks == 8) hipLaunchKernelGGL((conv1p_kernel<8, 1>), grid, block, 0, st, k);
     else hipLaunchKernelGGL((conv1p_kernel<16, 1>), grid, block, 0, st, k);
     return 1;
 }

@@ -37,7 +37,7 @@ class ParallelBlk(nn.Module):
         """x12 = [x_1; x_2], xst12 = [x_1_st; x_2_st], xsst12 = [x_1_s_st; x_2_s_st] (batch-stacked twins).
         need_st=False: the caller will not read the returned xst12 (it is None then).
         first: unused since round 5 (the exact-zero rule is decided per launch from the biases: ops.wino_ok)."""
-        fused = need_st or (bie.FUSE_FIRST and bie.chain_supported(x12.shape[-1]))
+        fused = need_st or (bie.chain_supported(x12.shape[-1]))
         if fused:
             # both residual blocks write into the halves of one buffer, so the two lBIE calls (and, inside them, the
             # weight-shared conv1/conv2 and convf1/convf2 pairs) run as ONE fused twin node over 4B samples

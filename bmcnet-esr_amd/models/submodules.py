@@ -130,7 +130,7 @@ class BIE(nn.Module):
     def forward_first(self, x12, xs):
         """x12 = [first; second] -> (out_1 + Res(second), xs_new): forward_pair(need_second=False) as one fused autograd
         node (bmc_hip/bie.py: BIEFirstFn) when the fused centre chain serves this width and arithmetic."""
-        if bie.FUSE_FIRST and bie.chain_supported(self.nf):
+        if bie.chain_supported(self.nf):
             return bie.bie_first(self, x12, xs)
         n = x12.shape[0] // 2
         o1, _, xs_new = self.forward_pair(x12[:n], x12[n:], xs, need_second=False)

@@ -58,9 +58,10 @@ def test_winograd4_conv_fwd_bwd_vs_float64(force_wino4, B, H, W, cins, cout, rel
     if relu:
         y = torch.relu(y)
     y.backward(go.double())
-    assert ops.wino_ok(B, H, W, cout, 9, fwd=True) == 4
     xs_g = [nhwc(x).to(dev).requires_grad_() for x in xs]
     w_g, b_g = w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    # (a forward launch takes F(4x4) only with a bias that is dense -- the exact-zero rule above ops.wino_ok -- as this one is)
+    assert ops.wino_ok(B, H, W, cout, 9, fwd=True, rule=b_g) == 4 and ops.wino_ok(B, H, W, cout, 9, fwd=True) == 2
     r_g = nhwc(r).to(dev).requires_grad_() if res else None
     ops.PROFILE = []
     yg = ops.conv([View(x) for x in xs_g], w_g, b_g, ConvSpec.dense(*cins), relu=relu, residual=View(r_g) if res else None)
@@ -139,10 +140,12 @@ def test_winograd4_geometry_fuzz_vs_direct_kernel(force_wino4):
 
 
 def test_exact_zero_rule_keeps_reference_relu_gates(force_wino4):
-    """Sparse event counts, zero biases, zero state: the input-fusion convolutions must give EXACTLY 0 where a pixel's
-    receptive field holds no event (the reference's relu'(0) = 0 gates the gradient there).  Under ops.exact_zero_inputs the
-    forward launch keeps F(2x2), whose outputs are combinations of products of their own 3x3 field only; outside the context
-    the same launch takes F(4x4) and leaves rounding residue there -- which is why the rule exists."""
+    """Sparse event counts: where a pixel's receptive field holds no event the reference gives EXACTLY its bias.  With a zero
+    bias (as `initialize_weights` leaves it) that is exactly 0 and relu'(0) = 0 gates the gradient: the forward launch must
+    keep a kernel that is exact there (F(2x2): outputs are combinations of products of their own 3x3 field only).  With a
+    dense bias the launch takes F(4x4): its +-1e-8 residue on empty fields cannot move a gate.  Round 5: the rule reads the
+    bias (ops.bias_dense), not the caller's `init` flag; the last part forces F(4x4) onto the zero-bias launch to show what the
+    rule prevents."""
     dev = _gpu()
     ops = force_wino4
     from bmc_hip.ops import ConvSpec, View
@@ -155,13 +158,42 @@ def test_exact_zero_rule_keeps_reference_relu_gates(force_wino4):
     occupied = F.max_pool2d(x.abs().sum(-1, keepdim=True).permute(0, 3, 1, 2), 3, 1, 1).permute(0, 2, 3, 1) > 0
     empty = (~occupied).expand(B, H, W, Cn).to(dev)
     assert empty.float().mean() > 0.1
-    with ops.exact_zero_inputs():
-        assert ops.wino_ok(B, H, W, Cn, 9, fwd=True) == 2 and ops.wino_ok(B, H, W, Cn, 9) == 4
-        y_safe = ops.conv([View(xg)], w, None, ConvSpec.dense(Cn), relu=True)
-    y_f4 = ops.conv([View(xg)], w, None, ConvSpec.dense(Cn), relu=True)
-    assert torch.count_nonzero(y_safe[empty]) == 0
-    assert rel_l2(y_f4, y_safe) < 1e-5
+
+    def run(bias):
+        ops.PROFILE = []
+        try:
+            y = ops.conv([View(xg)], w, bias, ConvSpec.dense(Cn), relu=True)
+            torch.cuda.synchronize()
+            return y, [r[0] for r in ops.PROFILE]
+        finally:
+            ops.PROFILE = None
+
+    b_zero = torch.zeros(Cn, device=dev)
+    b_dense = ((torch.rand(Cn, generator=g) - 0.5) * 0.2).to(dev)
+    b_dense[b_dense.abs() < 1e-3] = 0.05
+    assert not ops.bias_dense(b_zero) and ops.bias_dense(b_dense) and not ops.bias_dense(None)
+    y_zero, k_zero = run(b_zero)
+    assert k_zero == ["wino_conv<9,128>"] and torch.count_nonzero(y_zero[empty]) == 0         # exact zeros on F(2x2)
+    y_none, k_none = run(None)
+    assert k_none == ["wino_conv<9,128>"] and torch.equal(y_none, y_zero)
+    y_dense, k_dense = run(b_dense)
+    assert k_dense == ["wino4_conv<9,128>"]
+    want = torch.relu(b_dense).expand(B, H, W, Cn)
+    assert float((y_dense - want)[empty].abs().max()) < 1e-6 and bool(((y_dense > 0) == (want > 0))[empty].all())   # the same gates
+    with ops.exact_zero_inputs():                                        # the context forces the exact kernels whatever the bias
+        assert run(b_dense)[1] == ["wino_conv<9,128>"]
+    # what the rule prevents: F(4x4) on the zero-bias launch
+    old = ops.DENSE_FLOOR
+    ops.DENSE_FLOOR = 0.0
+    ops._DENSE.clear()
+    try:
+        y_f4, k_f4 = run(b_zero)
+    finally:
+        ops.DENSE_FLOOR = old
+        ops._DENSE.clear()
+    assert k_f4 == ["wino4_conv<9,128>"] and rel_l2(y_f4, y_zero) < 1e-5
     print("F(4x4) residue on empty receptive fields: %d of %d outputs non-zero" % (torch.count_nonzero(y_f4[empty]), int(empty.sum())))
+    assert torch.count_nonzero(y_f4[empty]) > 0
 
 
 # ------------------------------------------------------------------ weight gradients on the side stream at every size (fp32 default)
