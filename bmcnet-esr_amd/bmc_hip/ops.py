@@ -270,21 +270,29 @@ WINO4_MIN_TILES = int(os.environ.get("BMC_WINO4_MIN_TILES", 300))    # workgroup
 # Exact zeros.  Where a pixel's 3x3 receptive field holds nothing, the reference's direct convolution gives EXACTLY its bias;
 # with a zero bias that is exactly 0, and relu'(0) = 0 gates the gradient there.  F(2x2) preserves that (every output of its
 # minimal algorithm is a combination of products of ITS OWN 3x3 field only), the direct kernel trivially; F(4x4) computes such a
-# pixel from a 6x6 patch that also holds its neighbours' data, through rounded transformed weights: +-1e-8 instead of 0, a coin
-# flip of the ReLU mask.  On dense inputs only the first layers of the first window see such fields (round 4's rule, keyed on the
-# caller's `init` flag); on a SPARSE recording with zero biases every layer of every window does -- nothing densifies a zero
-# pixel of zero-bias convolutions, LayerNorm2d and per-pixel attention -- and the bias gradients came out up to 58 % wrong
-# (tests/test_gpu_r5.py::test_sparse_recording_bias_gradients_vs_oracle, 0.026 events per pixel at 180x240).  The rule is
-# therefore keyed on DATA -- the bias vector that is added to the launch's result (its own, or for a bias-free launch that adds a
-# residual the bias inside that residual: `rule`): a FORWARD 3x3 launch takes the F(4x4) kernel only if every element of it is
-# at least DENSE_FLOOR away from zero, i.e. no output of the launch is decided by the kernel's 1e-8 residue.  As
-# `initialize_weights` leaves the biases (zero) every forward launch keeps F(2x2); one optimizer step moves every bias that
-# receives a gradient by the learning rate, and from then on F(4x4) serves them all.  Data gradients are never affected (nothing
-# gates on them).  The flags cost one device reduction and one host read per optimizer step for all biases of a model
-# (prime_bias_dense, cached per parameter version).  exact_zero_inputs() forces the safe kernels regardless (tests).
-_EXACT_ZERO = threading.local()          # .n: nesting depth of exact_zero_inputs on this thread
-DENSE_FLOOR = 1e-6
-_DENSE = {}                              # id(bias) -> (weakref, version, flag)
+# pixel from a 6x6 patch that also holds its neighbours' data, through rounded transformed weights: a residue of +-1e-8 ... 1e-6
+# (it scales with the neighbours' magnitude) instead of 0 -- a coin flip of the ReLU mask.  On dense inputs only the first layers
+# of the first window see such fields (round 4's rule, keyed on the caller's `init` flag); on a SPARSE recording with zero biases
+# every layer of every window does -- nothing densifies a zero pixel of zero-bias convolutions, LayerNorm2d and per-pixel
+# attention -- and bias gradients came out up to 58 % wrong (tests/test_gpu_r5.py::test_sparse_recording_bias_gradients_vs_
+# oracle, 0.026 events per pixel at 180x240).  Round 5's rule is keyed on DATA, in two parts:
+#   (1) own bias.  A FORWARD 3x3 launch may take F(4x4) if every element of the bias that is added to its result (its own, or for
+#       a bias-free launch that adds a residual the bias inside that residual: `rule`) is at least DENSE_FLOOR away from zero: no
+#       output of the launch is decided by the residue (bias_dense).
+#   (2) dense inputs.  A launch whose input has NO empty receptive field cannot meet the hazard whatever its bias.  The models
+#       prove that where they can and say so with the dense_inputs() context: once the input-fusion convolutions -- ReLU layers,
+#       evaluated under (1) -- have a bias element >= DENSE_FLOOR each (bias_positive), every pixel of their outputs carries a
+#       positive channel, and residual blocks (y = x + ...), LayerNorm2d, 1x1 convolutions and per-pixel attention keep a non-zero
+#       pixel non-zero: the whole block loop and the tail of that window run inside the context.
+# As `initialize_weights` leaves the biases (zero) every forward launch keeps F(2x2); one optimizer step moves every bias by
+# about the learning rate, (2) holds from then on, and only the 4 input-fusion launches of a window depend on (1) -- biases
+# cross zero now and then in early training (measured: 8 of 27 vectors had an element within 1e-6 of zero after step 3).  Data
+# gradients are never affected (nothing gates on them).  The flags cost one stack of device reductions and ONE host read per
+# optimizer step for all 3x3 biases of a model (prime_bias_dense, cached per parameter version).  exact_zero_inputs() forces the
+# exact kernels regardless (tests).
+_EXACT_ZERO = threading.local()          # .n: nesting depth of exact_zero_inputs on this thread, .d: of dense_inputs
+DENSE_FLOOR = 1e-5                       # ~10x the largest residue measured on event-count inputs (1.1e-6)
+_DENSE = {}                              # id(bias) -> (weakref, version, min |b|, max b)
 
 
 class exact_zero_inputs:
@@ -296,25 +304,43 @@ class exact_zero_inputs:
         return False
 
 
+class dense_inputs:
+    """The caller vouches that no input of the launches inside has an all-zero pixel (rule (2) above)."""
+    def __enter__(self):
+        _EXACT_ZERO.d = getattr(_EXACT_ZERO, "d", 0) + 1
+
+    def __exit__(self, *exc):
+        _EXACT_ZERO.d -= 1
+        return False
+
+
 def _dense_cached(b):
     hit = _DENSE.get(id(b))
     if hit is not None and hit[0]() is b and hit[1] == b._version:
-        return hit[2]
+        return hit
     return None
 
 
 def prime_bias_dense(biases):
-    """Evaluate `min |b| >= DENSE_FLOOR` for every bias whose flag is missing or stale: one stack of device reductions, ONE host
-    read.  (Not while a HIP graph is being captured: flags missing then read as "not dense" -- the safe kernels.)"""
+    """min |b| and max b of every bias whose entry is missing or stale: one stack of device reductions, ONE host read.
+    (Not while a HIP graph is being captured: entries missing then read as "not dense" -- the exact kernels.)"""
     need = [b for b in biases if b is not None and _dense_cached(b) is None]
     if not need or not need[0].is_cuda or torch.cuda.is_current_stream_capturing():
         return
-    mins = torch.stack([b.detach().abs().min() for b in need]).tolist()
+    vals = torch.stack([torch.stack((b.detach().abs().min(), b.detach().max())) for b in need]).tolist()
     if len(_DENSE) > 512:
         for k in [k for k, v in _DENSE.items() if v[0]() is None]:
             del _DENSE[k]
-    for b, m in zip(need, mins):
-        _DENSE[id(b)] = (weakref.ref(b), b._version, m >= DENSE_FLOOR)
+    for b, (mn, mx) in zip(need, vals):
+        _DENSE[id(b)] = (weakref.ref(b), b._version, mn, mx)
+
+
+def _bias_entry(b):
+    hit = _dense_cached(b)
+    if hit is None:
+        prime_bias_dense([b])
+        hit = _dense_cached(b)
+    return hit
 
 
 def bias_dense(b):
@@ -323,19 +349,28 @@ def bias_dense(b):
         return False
     if isinstance(b, (tuple, list)):
         prime_bias_dense(b)
-        return all(bool(_dense_cached(x)) for x in b)
-    hit = _dense_cached(b)
-    if hit is None:
-        prime_bias_dense([b])
-        hit = _dense_cached(b)
-    return bool(hit)
+        return all(bias_dense(x) for x in b)
+    hit = _bias_entry(b)
+    return hit is not None and hit[2] >= DENSE_FLOOR
+
+
+def bias_positive(b):
+    """Does this bias (every bias of a tuple) have an element >= DENSE_FLOOR -- does the ReLU layer it belongs to give every
+    pixel a positive channel?"""
+    if b is None:
+        return False
+    if isinstance(b, (tuple, list)):
+        prime_bias_dense(b)
+        return all(bias_positive(x) for x in b)
+    hit = _bias_entry(b)
+    return hit is not None and hit[3] >= DENSE_FLOOR
 
 
 def wino_ok(B, H, W, Cout, taps, fwd=False, stride=0, rule=None):
     """Which kernel takes a launch of this geometry?  0: the direct kernel, 2: Winograd F(2x2, 3x3), 4: F(4x4, 3x3).
     (Decided ONCE per launch by the caller and handed to the weight pack and to conv_raw alike: the packed layouts are not
-    interchangeable.)  fwd: a forward launch: F(4x4) only if `rule` -- the bias (tensor, or tuple of tensors) that is added to its
-    result -- is dense (see above).  stride: the widest pixel stride (floats) among the
+    interchangeable.)  fwd: a forward launch: F(4x4) only inside dense_inputs() or if `rule` -- the bias (tensor, or tuple of
+    tensors) that is added to its result -- is dense (the exact-zero rule above).  stride: the widest pixel stride (floats) among the
     launch's sources, residual, mask and output, where it can exceed 512 (channel windows of a wider buffer): the Winograd
     launchers refuse what their 32-bit offsets cannot address, so such a launch must be routed to the direct kernel here."""
     if not WINO or MATH != 0 or taps != 9:
@@ -347,7 +382,8 @@ def wino_ok(B, H, W, Cout, taps, fwd=False, stride=0, rule=None):
         return 0
     if WINO4 and W >= 17 and H * W < 2 ** 24:
         n4 = B * ((((H + 3) // 4) * ((W + 3) // 4) + 15) // 16) * (cp // 128)
-        if n4 >= WINO4_MIN_TILES and not (fwd and (getattr(_EXACT_ZERO, "n", 0) or not bias_dense(rule))):
+        if n4 >= WINO4_MIN_TILES and not (fwd and (getattr(_EXACT_ZERO, "n", 0) or
+                                                   not (getattr(_EXACT_ZERO, "d", 0) or bias_dense(rule)))):
             return 4
     return 2
 

@@ -132,15 +132,19 @@ class Backbone(nn.Module):
         ops.wgrad_join()         # (a backward pass that raised leaves weight gradients running on the side stream: ops.wgrad_join)
         B = o12.shape[0] // 2
         hpn = h3[:2 * B]
-        # (which 3x3 launches may take the F(4x4) kernel is decided per launch from the bias that is added to its result -- the
-        #  exact-zero rule above ops.wino_ok; round 4 keyed it on `zero_state`, which a sparse recording defeats.  One device
-        #  reduction + one host read per optimizer step for all 3x3 biases of the backbone:)
+        # (which 3x3 launches may take the F(4x4) kernel: the exact-zero rule above ops.wino_ok; round 4 keyed it on `zero_state`,
+        #  which a sparse recording defeats.  The input-fusion convolutions read raw event counts and a state that may be zero:
+        #  decided per launch from their own biases.  Once each of them has a positive bias element, every pixel of st12, s12, fs3
+        #  carries a positive channel and the residual blocks / BIEs keep it non-zero: the rest of the window has dense inputs.
+        #  One stack of device reductions + one host read per optimizer step for all 3x3 biases of the backbone:)
         ops.prime_bias_dense(self._biases3())
         st12, s12, sst12, xs = self._input_fusion(xin12, h3, hpn, o12, B)
-        n_layers = len(self.para_reschunk)
-        for i, layer in enumerate(self.para_reschunk):      # x*_st of the last block is never read: skip what only feeds it
-            s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12, need_st=i + 1 < n_layers)
-        return self._tail(s12, xs, sst12, B)
+        dense = ops.bias_positive((self.conv_fpst.bias, self.conv_fps.bias, self.conv_fs.bias))
+        with (ops.dense_inputs() if dense else contextlib.nullcontext()):
+            n_layers = len(self.para_reschunk)
+            for i, layer in enumerate(self.para_reschunk):      # x*_st of the last block is never read: skip what only feeds it
+                s12, xs, st12, sst12 = layer.forward_nhwc(s12, xs, st12, sst12, need_st=i + 1 < n_layers)
+            return self._tail(s12, xs, sst12, B)
 
     def _biases3(self):
         """The bias vectors of the backbone's 3x3 convolutions (aliases once): what ops.wino_ok's exact-zero rule reads."""

@@ -48,14 +48,18 @@ class Backbone(nn.Module):
                        B=2 * B, relu=True)
         xs = ops.conv([View(xin12, b0=0), View(xin12, b0=B), View(h), View(o12, b0=0), View(o12, b0=B)],
                       self.conv_fs.weight, self.conv_fs.bias, self._sp_fs, B=B, relu=True)
-        for layer in self.para_reschunk:
-            x12, xs = layer.forward_twin(x12, xs)
-        x_h = ops.conv([View(xs)], self.conv_h.weight, self.conv_h.bias, self._sp_h, relu=True)
-        w_o, b_o = self.conv_o.weight, self.conv_o.bias
-        if self.cop != 2 * self.s2:
-            w_o = F.pad(w_o, (0, 0, 0, 0, 0, 0, 0, self.cop - 2 * self.s2))
-            b_o = F.pad(b_o, (0, self.cop - 2 * self.s2))
-        x_o = ops.conv([View(x12, b0=0), View(x12, b0=B)], w_o, b_o, self._sp_o, B=B, cache=self.cop == 2 * self.s2)
+        # (both ReLU outputs carry a positive channel at every pixel once their biases have a positive element: dense inputs for
+        #  the rest of the window, ops.dense_inputs)
+        dense = ops.bias_positive((self.conv_f1.bias, self.conv_fs.bias))
+        with (ops.dense_inputs() if dense else contextlib.nullcontext()):
+            for layer in self.para_reschunk:
+                x12, xs = layer.forward_twin(x12, xs)
+            x_h = ops.conv([View(xs)], self.conv_h.weight, self.conv_h.bias, self._sp_h, relu=True)
+            w_o, b_o = self.conv_o.weight, self.conv_o.bias
+            if self.cop != 2 * self.s2:
+                w_o = F.pad(w_o, (0, 0, 0, 0, 0, 0, 0, self.cop - 2 * self.s2))
+                b_o = F.pad(b_o, (0, self.cop - 2 * self.s2))
+            x_o = ops.conv([View(x12, b0=0), View(x12, b0=B)], w_o, b_o, self._sp_o, B=B, cache=self.cop == 2 * self.s2)
         if self.cop != 2 * self.s2:
             x_o = x_o[..., :2 * self.s2].contiguous()
         return x_h, x_o
