@@ -602,7 +602,8 @@ def main():
                 os.environ.setdefault("MASTER_PORT", "29541")
                 try:
                     dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
-                    r = extra_train(dev, "dist1", 4, 180, 240, 9, "fp32", 5, 2, use_dist=True)
+                    # (the same warm-up as the headline run: the first steps after initialisation are slower -- exact-zero rule)
+                    r = extra_train(dev, "dist1", 4, 180, 240, 9, "fp32", min(args.steps, 10), args.warmup, use_dist=True)
                     r["plain_step_ms"] = out["ms_per_step"]
                     extra["C2 step with the gradient reducer + 1-rank RCCL all-reduce in the timed region"] = r
                 except Exception as e:      # (an RCCL that refuses a world of one must not cost the headline line)
