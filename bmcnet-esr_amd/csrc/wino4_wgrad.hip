@@ -24,20 +24,17 @@
 // the image a piece is "scalar base of the stage + a per-lane offset that never changes"; stages that touch the image border take
 // a slower path (clamped per-lane addresses; the quads of out-of-image pixels are overwritten with zeros once landed) so that
 // the transforms never see the border.  Two raw buffers and two transformed images: 150 KB of LDS, one barrier per stage.
-// The transforms are done on channel PAIRS (64 items = 2 tiles x 32 pairs per wave): waves 0-1 the lone xi row of x (xi = 0 / 5),
-// waves 2-3 and 6-7 the two xi rows of x that are sum and difference of the same two sub-sums (1, 2 / 3, 4), waves 4-5 all three
-// xi of dY.  SIMD partners (w, w + 4) are out of phase by construction: waves 0-3 request their DMA pieces and transform first
-// and multiply afterwards, waves 4-7 multiply first (their DMA pieces between the MFMAs) and transform afterwards -- the matrix
-// pipe of a SIMD always has one wave's MFMAs while the other one issues everything else.
+// Work that is not MFMAs is split by WAVE so that it never stands in front of MFMAs the matrix pipe is waiting for (SIMD partners
+// are waves w and w + 4): waves 0-3 multiply and THEN transform the next stage on channel pairs, two items per lane -- wave 0 the
+// lone xi row of x (xi = 0 / 5), waves 1 / 2 sum / difference of the two xi rows that share their sub-sums (1, 2 / 3, 4), wave 3
+// all three xi of dY; waves 4-7 request the raw strips of the stage after next (all 39 DMA pieces) and THEN multiply.  While one
+// partner's MFMAs run, the other one transforms or requests.
 // Partial sums leave in REGISTER order (one 1 KB store per accumulator quad: [split][type][wave][position][quad][lane][4]);
 // the reduction kernel knows the MFMA's D layout and reads them back as 16-byte quads of four consecutive output channels.
 #include "bmc_common.h"
 #include "dma_ring.h"
 #include <stdlib.h>
 
-#ifndef BMC_W4G_PRIO
-#define BMC_W4G_PRIO 1    // 1: a wave raises its issue priority while it transforms / requests (its SIMD partner multiplies meanwhile)
-#endif
 #ifndef BMC_W4G_ABL
 #define BMC_W4G_ABL 0     // ablation builds (tools/): 1 no MFMA, 2 no DMA, 4 no transforms, 8 no fragment reads, 16 every DMA from the
                           // first stage's pixels (cache hits), 32 no wait for the DMA at the end of a stage
@@ -82,7 +79,7 @@ constexpr int XPC = 23, YPC = 16;           // DMA pieces (4 pixels x 64 channel
 constexpr int RAWX = XPC * 256;             // floats
 constexpr int RAWF = (XPC + YPC) * 256;     // floats per raw buffer (39 KB)
 constexpr int NPC = XPC + YPC;
-constexpr int PPW = 8;                      // pieces per wave: waves 0-3 carry 8 each (pieces 0..31), waves 4-7 two each (32..38)
+constexpr int PPW = 10;                     // pieces per requesting wave: waves 4-7 carry 10 each (pieces w - 4 + 4 j; slot 39 = piece 38 once more)
 constexpr int LDSF = 2 * RAWF + 2 * SIMG;   // 153 600 bytes
 
 template <int TG>
@@ -104,29 +101,36 @@ __device__ __forceinline__ void wgrad4_body(const Wgrad4K& a, float* const lds, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    // ---- DMA role.  The CU's vector-memory path takes one 1 KB piece per ~38 cycles (PMC + ablations: a burst of pieces blocks
-    // the issuing waves -- in-order issue -- and with them their MFMAs), so the 39 pieces of a stage are issued where no MFMA waits
-    // behind them: waves 0-3 (which transform first) carry 8 each (pieces w, w + 4, ..., w + 28), spread between the steps of their
-    // transform while their SIMD partners multiply; waves 4-7 two each (32 + w - 4, 36 + w - 4; piece 38 twice) at the top of
-    // THEIR transform.  Per piece and lane: pixel slot (row r, column c) of the strip; pieces < 23 are x pieces, the rest dY pieces.
-    const bool early = wave < 4;          // SIMD partners (w, w + 4) out of phase: requests + transform first / multiply first
+    // ---- roles.  The CU's vector-memory path takes one 1 KB piece per ~40-60 cycles (PMC + ablations) and an in-order wave
+    // that issues a piece while requests queue there is blocked with everything behind it, its MFMAs included; a wave's
+    // transform is a chain of dependent packed operations behind LDS round trips.  Neither must stand in front of MFMAs the
+    // matrix pipe is waiting for, so the two kinds of work sit on DIFFERENT waves of every SIMD (partners are w and w + 4):
+    //   waves 0-3: multiply, THEN transform the next stage (wave 0 the lone xi row of x, wave 1 / 2 sum / difference of the xi pair,
+    //              wave 3 dY; two items per lane: tiles {0, 1} then {2, 3});
+    //   waves 4-7: request the raw strips of the stage after next (all 39 pieces, 10 slots each), THEN multiply.
+    // While one partner's MFMAs run, the other one transforms or requests.
+    const bool requester = wave >= 4;
     unsigned poff[PPW];       // byte offset from the stage's base pixel (interior stages)
-    int prc[PPW];             // r | c << 8, or -1 for a slot that is not a pixel
     unsigned pla[PPW];        // LDS byte address of the piece in raw buffer 0
     unsigned pxm = 0;         // bit j: piece j is an x piece
+    auto piece_of = [&](const int j) { return min((wave & 3) + 4 * j, NPC - 1); };
+    // pixel slot (row r, column c) of this lane's quad of piece p; false: not a pixel (the last two slots of the x strip)
+    auto slot_of = [&](const int p, int& r, int& c) __attribute__((always_inline)) {
+        if (p < XPC) { const int q = 4 * p + (lane >> 4); r = q / 18; c = q - 18 * r; return q < 90; }
+        const int q = 4 * (p - XPC) + (lane >> 4); r = q >> 4; c = q & 15;
+        return true;
+    };
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int p = early ? wave + 4 * j : min(32 + (wave - 4) + 4 * (j & 1), NPC - 1);
+        const int p = piece_of(j);
         int r, c;
-        bool real = true;
-        if (p < XPC) { const int q = 4 * p + (lane >> 4); r = q / 18; c = q - 18 * r; real = q < 90; }
-        else { const int q = 4 * (p - XPC) + (lane >> 4); r = q >> 4; c = q & 15; }
+        const bool real = slot_of(p, r, c);
         poff[j] = real ? (unsigned)(((r * a.W + c) * 128 + (lane & 15) * 4) * 4) : 0u;
-        prc[j] = real ? (r | (c << 8)) : -1;
         pla[j] = lds_raw + (unsigned)(p * 1024);
         pxm |= p < XPC ? 1u << j : 0u;
     }
     unsigned zm = 0;          // bit j: this lane's quad of piece j is a pixel outside the image (stage in flight)
+    static_assert(PPW <= 32, "zm is a bit mask");
 
     const int per_img = a.TY * a.SX;
     const int st0 = (int)((long long)a.nstages * split / a.nsplit), st1 = (int)((long long)a.nstages * (split + 1) / a.nsplit);
@@ -181,9 +185,9 @@ __device__ __forceinline__ void wgrad4_body(const Wgrad4K& a, float* const lds, 
         if (rq_border) {
             asm volatile("; image border" ::: "memory");
             const bool isx = (pxm >> j) & 1;
-            const int r = prc[j] & 255, c = (prc[j] >> 8) & 255;
+            int r, c;
+            const bool real = slot_of(piece_of(j), r, c);
             const int y = (isx ? rq_y0 : rq_y0 + 1 - TG) + r, x = (isx ? rq_x0 : rq_x0 + 1) + c;
-            const bool real = prc[j] >= 0;
             const bool inside = y >= 0 && y < a.H && x >= 0 && x < a.W;
             const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
             o = real ? (unsigned)(((yc * a.W + xc) * 128 + (lane & 15) * 4) * 4) : 0u;
@@ -191,12 +195,6 @@ __device__ __forceinline__ void wgrad4_body(const Wgrad4K& a, float* const lds, 
         }
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(o), "s"(((pxm >> j) & 1) ? rq_xs : rq_ys),
                      "s"(pla[j] + rq_lo) : "memory");
-    };
-    auto request = [&](const int rb) __attribute__((always_inline)) {
-        rq_begin(rb);
-#pragma unroll
-        for (int j = 0; j < PPW; ++j)
-            if (early || j < 2) rq_piece(j);
     };
     // after the requests have landed, before the barrier that publishes them: pixels outside the image become zeros
     auto patch = [&](const int rb) __attribute__((always_inline)) {
@@ -206,9 +204,8 @@ __device__ __forceinline__ void wgrad4_body(const Wgrad4K& a, float* const lds, 
             if ((zm >> j) & 1) *reinterpret_cast<f32x4*>(rawb + (pla[j] - lds_raw) / 4 + rb * RAWF + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
-    // ---- producer role (waves 0-5): item = (tile t, channel pair cp) of the stage
-    const int item = (wave & 1) * 64 + lane;
-    const int pt = item >> 5, cp = item & 31;
+    // ---- producer role (waves 0-3): item = (tile, channel pair cp) of the stage; instance i of a wave: tiles 2 i + (lane >> 5)
+    const int cp = lane & 31;
     f32x2 bsum = {0.f, 0.f};
     // B^T along a row of six: (4 0 -5 0 1 0) (0 -4 -4 1 1 0) (0 4 -4 -1 1 0) (0 -2 -1 2 1 0) (0 2 -1 -2 1 0) (0 4 0 -5 0 1)
     auto xcols = [&](const f32x2 (&w)[6], float* const dst) __attribute__((always_inline)) {
@@ -232,75 +229,60 @@ __device__ __forceinline__ void wgrad4_body(const Wgrad4K& a, float* const lds, 
         *reinterpret_cast<f32x2*>(dst + 5 * PIMG) = w[3];
         return m1;
     };
-    // `pieces`: this wave issues its DMA pieces of the stage in flight between the steps (waves 0-3)
-    auto transform = [&](const float* const raw, float* const img, const bool pieces) __attribute__((always_inline)) {
-        if (BMC_W4G_ABL & 4) {
-            if (pieces) {
-#pragma unroll
-                for (int j = 0; j < PPW; ++j) rq_piece(j);
-            }
-            return;
-        }
+    auto transform = [&](const float* const raw, float* const img) __attribute__((always_inline)) {
+        if (BMC_W4G_ABL & 4) return;
         auto ld2 = [](const float* p) __attribute__((always_inline)) { return *reinterpret_cast<const f32x2*>(p); };
-        if (wave < 2) {
-            // the lone xi row of x: xi = 0 = (4 0 -5 0 1 0) on patch rows 0, 2, 4; xi = 5 = (0 4 0 -5 0 1) on patch rows 1, 3, 5 --
-            // staged rows 0, 2, 4 either way.  All 18 reads first, the pieces between the columns' sums
-            const float* const s = raw + (4 * pt) * CH + 2 * cp;
-            f32x2 d[3][6], w[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c)
+        for (int inst = 0; inst < 2; ++inst) {
+            const int pt = 2 * inst + (lane >> 5);
+            if (wave == 0) {
+                // the lone xi row of x: xi = 0 = (4 0 -5 0 1 0) on patch rows 0, 2, 4; xi = 5 = (0 4 0 -5 0 1) on patch rows 1, 3, 5 --
+                // staged rows 0, 2, 4 either way.  All 18 reads first
+                const float* const s = raw + (4 * pt) * CH + 2 * cp;
+                f32x2 d[3][6], w[6];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) d[k][c] = ld2(s + (2 * k * 18 + c) * CH);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < 6; ++c)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                if (pieces) rq_piece(c);
-                w[c] = 4.f * d[0][c] - 5.f * d[1][c] + d[2][c];
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int k = 0; k < 3; ++k) d[k][c] = ld2(s + (2 * k * 18 + c) * CH);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) w[c] = 4.f * d[0][c] - 5.f * d[1][c] + d[2][c];
+                xcols(w, img + IMG + ((TG == 0 ? 0 : 2) * 6) * PIMG + pt * CH + 2 * cp);
+            } else if (wave < 3) {
+                // the two xi rows on patch rows 1..4 (staged rows 1 - TG ..): xi = 1, 2 = (r4 - 4 r2) +- (r3 - 4 r1); xi = 3, 4 = (r4 - r2) +- 2 (r3 - r1);
+                // wave 1 the sum, wave 2 the difference
+                const float* const s = raw + ((1 - TG) * 18 + 4 * pt) * CH + 2 * cp;
+                constexpr float al = TG == 0 ? -4.f : -1.f;
+                const float ga = (TG == 0 ? 1.f : 2.f) * (wave == 2 ? -1.f : 1.f);
+                f32x2 d[4][6], w[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k][c] = ld2(s + (k * 18 + c) * CH);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) w[c] = (d[3][c] + al * d[1][c]) + ga * (d[2][c] + al * d[0][c]);
+                xcols(w, img + IMG + (((TG == 0 ? 1 : 0) + (wave == 2 ? 1 : 0)) * 6) * PIMG + pt * CH + 2 * cp);
+            } else {
+                // dY (wave 3), all three xi of the group: (y0, (y0 + y2) +- (y1 + y3)) or ((y0 + 4 y2) +- 2 (y1 + 4 y3), y3)
+                const float* const s = raw + RAWX + (4 * pt) * CH + 2 * cp;
+                constexpr float ka = TG == 0 ? 1.f : 4.f, la = TG == 0 ? 1.f : 2.f;
+                f32x2 y[4][4], u0[4], u1[4], u2[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) y[k][c] = ld2(s + (16 * k + c) * CH);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x2 p = y[0][c] + ka * y[2][c], q = y[1][c] + ka * y[3][c];
+                    if (TG == 0) { u0[c] = y[0][c]; u1[c] = p + la * q; u2[c] = p - la * q; }
+                    else { u0[c] = p + la * q; u1[c] = p - la * q; u2[c] = y[3][c]; }
+                }
+                float* const dd = img + pt * CH + 2 * cp;
+                ycols(u0, dd);
+                const f32x2 m11 = ycols(u1, dd + 6 * PIMG);
+                ycols(u2, dd + 12 * PIMG);
+                if (TG == 0) bsum += m11;         // xi = 1, nu = 1: the sum of the tile's 16 dY pixels
             }
-            if (pieces) { rq_piece(6); rq_piece(7); }
-            xcols(w, img + IMG + ((TG == 0 ? 0 : 2) * 6) * PIMG + pt * CH + 2 * cp);
-        } else if (wave < 4 || wave >= 6) {
-            // the two xi rows on patch rows 1..4 (staged rows 1 - TG ..): xi = 1, 2 = (r4 - 4 r2) +- (r3 - 4 r1); xi = 3, 4 = (r4 - r2) +- 2 (r3 - r1);
-            // waves 2-3 the sum, waves 6-7 the difference.  Reads in two halves of three columns
-            const float* const s = raw + ((1 - TG) * 18 + 4 * pt) * CH + 2 * cp;
-            constexpr float al = TG == 0 ? -4.f : -1.f;
-            const float ga = (TG == 0 ? 1.f : 2.f) * (wave >= 6 ? -1.f : 1.f);
-            f32x2 d[4][6], w[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) d[k][c] = ld2(s + (k * 18 + c) * CH);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                if (pieces) rq_piece(c);
-                w[c] = (d[3][c] + al * d[1][c]) + ga * (d[2][c] + al * d[0][c]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (pieces) { rq_piece(6); rq_piece(7); }
-            xcols(w, img + IMG + (((TG == 0 ? 1 : 0) + (wave >= 6 ? 1 : 0)) * 6) * PIMG + pt * CH + 2 * cp);
-        } else {
-            // dY (waves 4-5), all three xi of the group: (y0, (y0 + y2) +- (y1 + y3)) or ((y0 + 4 y2) +- 2 (y1 + 4 y3), y3)
-            const float* const s = raw + RAWX + (4 * pt) * CH + 2 * cp;
-            constexpr float ka = TG == 0 ? 1.f : 4.f, la = TG == 0 ? 1.f : 2.f;
-            f32x2 y[4][4], u0[4], u1[4], u2[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) y[k][c] = ld2(s + (16 * k + c) * CH);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x2 p = y[0][c] + ka * y[2][c], q = y[1][c] + ka * y[3][c];
-                if (TG == 0) { u0[c] = y[0][c]; u1[c] = p + la * q; u2[c] = p - la * q; }
-                else { u0[c] = p + la * q; u1[c] = p - la * q; u2[c] = y[3][c]; }
-            }
-            float* const dd = img + pt * CH + 2 * cp;
-            ycols(u0, dd);
-            const f32x2 m11 = ycols(u1, dd + 6 * PIMG);
-            ycols(u2, dd + 12 * PIMG);
-            if (TG == 0) bsum += m11;         // xi = 1, nu = 1: the sum of the tile's 16 dY pixels
         }
     };
 
@@ -336,14 +318,24 @@ __device__ __forceinline__ void wgrad4_body(const Wgrad4K& a, float* const lds, 
     // ---- prologue: stage st0 raw -> image 0, stage st0 + 1 requested
     const int n = st1 - st0;
     if (n > 0) {
-        request(0);
-        dma_wait<0>();
-        patch(0);
+        rq_begin(0);
+        if (requester) {
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) rq_piece(j);
+            dma_wait<0>();
+            patch(0);
+        }
         ring_publish();
-        if (n > 1) request(1);
-        transform(rawb, imgb, false);
+        if (n > 1) {
+            rq_begin(1);
+            if (requester) {
+#pragma unroll
+                for (int j = 0; j < PPW; ++j) rq_piece(j);
+            }
+        }
+        if (!requester) transform(rawb, imgb);
         dma_wait<0>();
-        if (n > 1) patch(1);
+        if (n > 1 && requester) patch(1);
         ring_publish();
     }
     for (int it = 0; it < n; ++it) {
@@ -352,27 +344,20 @@ __device__ __forceinline__ void wgrad4_body(const Wgrad4K& a, float* const lds, 
         W4G_STAMP(it, 0);
         if (req) rq_begin(it & 1);
         W4G_STAMP(it, 1);
-        if (early) {
-            if (BMC_W4G_PRIO) __builtin_amdgcn_s_setprio(3);
-            if (more) transform(rawb + ((it + 1) & 1) * RAWF, imgb + ((it + 1) & 1) * SIMG, req);
-            else if (req) { for (int j = 0; j < PPW; ++j) rq_piece(j); }
-            if (BMC_W4G_PRIO) __builtin_amdgcn_s_setprio(0);
+        if (requester && req) {
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) rq_piece(j);
         }
         W4G_STAMP(it, 2);
         __builtin_amdgcn_sched_barrier(0);
         multiply(img);
         __builtin_amdgcn_sched_barrier(0);
         W4G_STAMP(it, 3);
-        if (!early) {
-            if (BMC_W4G_PRIO) __builtin_amdgcn_s_setprio(3);
-            if (req) { rq_piece(0); rq_piece(1); }
-            if (more) transform(rawb + ((it + 1) & 1) * RAWF, imgb + ((it + 1) & 1) * SIMG, false);
-            if (BMC_W4G_PRIO) __builtin_amdgcn_s_setprio(0);
-        }
+        if (!requester && more) transform(rawb + ((it + 1) & 1) * RAWF, imgb + ((it + 1) & 1) * SIMG);
         W4G_STAMP(it, 4);
         if (!(BMC_W4G_ABL & 32)) dma_wait<0>();
         W4G_STAMP(it, 5);
-        if (req) patch(it & 1);
+        if (requester && req) patch(it & 1);
         ring_publish();
         W4G_STAMP(it, 6);
     }
@@ -388,9 +373,9 @@ __device__ __forceinline__ void wgrad4_body(const Wgrad4K& a, float* const lds, 
                 stg16(P + (i * 4 + m) * 256, f32x4{acc[i][4 * m], acc[i][4 * m + 1], acc[i][4 * m + 2], acc[i][4 * m + 3]});
     }
     if (TG == 0 && kh == 0 && a.bias_part) {      // bias partial: the 4 tile slots added through LDS (the loop ended on a barrier)
-        if (wave >= 4 && wave < 6) *reinterpret_cast<f32x2*>(lds + pt * CH + 2 * cp) = bsum;      // (the dY waves)
+        if (wave == 3) *reinterpret_cast<f32x2*>(lds + (lane >> 5) * CH + 2 * cp) = bsum;      // (the dY wave: tiles t and t + 2 per lane)
         __syncthreads();
-        if (tid < CH) a.bias_part[(long long)split * 128 + 64 * chh + tid] = (lds[tid] + lds[CH + tid]) + (lds[2 * CH + tid] + lds[3 * CH + tid]);
+        if (tid < CH) a.bias_part[(long long)split * 128 + 64 * chh + tid] = lds[tid] + lds[CH + tid];
     }
 }
 
