@@ -214,7 +214,7 @@ def _dgrad(g_src, w4, spec, src_index, owner, out, B, residual=None, mask=None, 
              flops=2.0 * B * H * W * spec.real_nch[src_index] * taps * Cout, wino=wn)
 
 
-def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, w_param, b_param, G=1, w_shape=None, keep=()):
+def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, w_param, b_param, G=1, w_shape=None, keep=(), window=None):
     # (w_param / b_param: a parameter, None, or for G > 1 a tuple of the G parameters of the weight groups)
     """Weight gradient + bias gradient (column sums of the same A operand, taken from the tiles the pixel-reduction
     GEMM stages anyway) -> (dW, db) for autograd; None where the sums went straight into the leaf parameters' .grad
@@ -222,7 +222,7 @@ def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, w_param, b_param, G=1,
     # keep: the operand tensors behind a_src / x_srcs (ops.wgrad_side: small launches run on the side stream)
     if ops.wino_wgrad_ok(a_src, x_srcs, spec, taps, Cout, G) and w_param is not None:
         return ops.wgrad_wino(a_src, x_srcs[0], B, H, W, spec, dev, w_param, b_param, w_shape if w_shape is not None else w_param.shape,
-                              keep=keep)
+                              keep=keep, window=window)
     with ops.wgrad_side(B * H * W, ops._flat_params(w_param, b_param), keep):
         slabs, nsplit, _, bsl = pgemm_raw(a_src, x_srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
                                           flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)
@@ -295,6 +295,7 @@ class BIETwinFn(torch.autograd.Function):
                               *((sc, bv1, bv2) if vfree else ()))
         ctx.vfree = vfree
         ctx.owners = (rw1, rw2, wf, wc, wu)
+        ctx.window = ops.current_window()
         ctx.params = (rw1, rb1, rw2, rb2, wf, bf, gamma, beta, wc, bc, wu, bu)     # the caller's objects (gradient sinks)
         ctx.vparams = (wv1, wv2, bv1, bv2)
         ctx.scale = scale
@@ -427,10 +428,10 @@ class BIETwinFn(torch.autograd.Function):
             _dgrad(X(dz12, shift=n, mod=B2), w_f, s2, 1, o_wf, dx12, B2, accumulate=True)                # dx12 += (rotated)
         # ---- residual block, upstream gradient = batch-rotated g_o
         g_r = X(g_o, shift=n, mod=B2)
-        dw2, db2 = _wgrad(g_r, [X(t12)], s1, B2, H, W, 9, Cn, dev, p_rw2, p_rb2, keep=(g_o, t12))
+        dw2, db2 = _wgrad(g_r, [X(t12)], s1, B2, H, W, 9, Cn, dev, p_rw2, p_rb2, keep=(g_o, t12), window=ctx.window)
         dt = new(B2)
         _dgrad(g_r, w_r2, s1, 0, o_rw2, dt, B2, mask=X(t12))
-        dw1, db1 = _wgrad(X(dt), [X(x12)], s1, B2, H, W, 9, Cn, dev, p_rw1, p_rb1, keep=(dt, x12))
+        dw1, db1 = _wgrad(X(dt), [X(x12)], s1, B2, H, W, 9, Cn, dev, p_rw1, p_rb1, keep=(dt, x12), window=ctx.window)
         _dgrad(X(dt), w_r1, s1, 0, o_rw1, dx12, B2, residual=g_r, accumulate=True)                       # dx12 += conv1^T + skip
         v = lambda t, ref: None if t is None else t.view(ref.shape)
         gv = (None,) * 4 if dwv is None else (dwv[0].reshape(wv1.shape), dbv[0], dwv[1].reshape(wv2.shape), dbv[1])
@@ -488,6 +489,7 @@ class BIEFirstFn(torch.autograd.Function):
                               *((sc, bv1) if vfree else ()))
         ctx.vfree = vfree
         ctx.owners = (rw1, rw2, wf, wc, wu, wv1)
+        ctx.window = ops.current_window()
         ctx.params = (rw1, rb1, rw2, rb2, wf, bf, gamma, beta, wc, bc, wu, bu, wv1, bv1)     # the caller's objects (gradient sinks)
         ctx.scale = scale
         return o1, xs_new
@@ -572,10 +574,10 @@ class BIEFirstFn(torch.autograd.Function):
         else:
             _dgrad(X(dv1), w_v1, s1, 0, o_wv1, dx12, n, accumulate=True)                                 # dx12[first] += value conv
         # ---- residual block (second half), upstream gradient = g_o
-        dw2, db2 = _wgrad(X(g_o), [X(t2)], s1, n, H, W, 9, Cn, dev, p_rw2, p_rb2, keep=(g_o, t2))
+        dw2, db2 = _wgrad(X(g_o), [X(t2)], s1, n, H, W, 9, Cn, dev, p_rw2, p_rb2, keep=(g_o, t2), window=ctx.window)
         dt = new(n)
         _dgrad(X(g_o), w_r2, s1, 0, o_rw2, dt, n, mask=X(t2))
-        dw1, db1 = _wgrad(X(dt), [X(x12, b0=n, B=n)], s1, n, H, W, 9, Cn, dev, p_rw1, p_rb1, keep=(dt, x12))
+        dw1, db1 = _wgrad(X(dt), [X(x12, b0=n, B=n)], s1, n, H, W, 9, Cn, dev, p_rw1, p_rb1, keep=(dt, x12), window=ctx.window)
         _dgrad(X(dt), w_r1, s1, 0, o_rw1, dx12, n, residual=X(g_o), accumulate=True, out_b0=n)           # dx12[second] += conv1^T + skip
         v = lambda t, ref: None if t is None else t.view(ref.shape)
         return (dx12, dxs, dw1, db1, dw2, db2, dwf, dbf, dgamma, dbeta, v(dwc, wc), dbc, dwu, dbu, v(dwv1, wv1), dbv1, None, None)

@@ -601,28 +601,121 @@ def wino_wgrad_ok(a_src, x_srcs, spec, taps, Cout, G):
     return k0 >= 0 and spec.kmap_host == list(range(k0, k0 + 128))
 
 
-def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias=True, k0=None, full=None, keep=()):
+# Merged weight gradients (round 5).  `para_reschunk` holds ONE ParallelBlk n_b times (models/BMCNet.py:19-32), so every 3x3 weight of
+# the block loop is used n_b times per window, and backward meets those uses one after the other: n_b launches of the Winograd
+# weight-gradient kernel, each with its own set of partial sums (64 MB written and read again whatever the image size) and its own
+# reduction, all adding into the same .grad.  The sum over uses is a sum over more images: inside a backward pass the uses of a
+# sink parameter are QUEUED (operand descriptors + references that keep the operands alive) and every WGRAD_MERGE of them leave as
+# ONE launch over several (dY, x) pairs (bmc_wgrad_wino_multi) with one reduction.  Queues that are not full are flushed when the
+# backward pass ends (engine callback, queued before the side stream's join) and by wgrad_join() -- i.e. before anything reads a
+# .grad.  Uses of different windows never share a launch (next_window(): the groups must not depend on how backward is cut into
+# passes).  Costs: at most WGRAD_MERGE - 1 transient gradients per weight stay alive a little longer (C2: +R5_MERGE_MEM GiB peak).
+# BMC_WGRAD_MERGE=1 switches it off.  Deterministic (the queue order is backward's order); NOT bit-identical to the unmerged
+# order of summation.
+WGRAD_MERGE = max(1, min(8, int(os.environ.get("BMC_WGRAD_MERGE", 5))))
+# ... for uses of at most this many pixels: what merging saves is per-launch overhead (partial sums, reduction, ramp and drain),
+# 31x56 bs 4: 82.8 -> 74.4 ms per step, 45x80 bs 2: 82.6 -> 73.6; at C2 (345 600 pixels per use) the launches are long enough and
+# five of them in one cost the overlap with the data-gradient chain more than they save: 722.2 -> 726.1 ms
+WGRAD_MERGE_MAX_PIXELS = int(os.environ.get("BMC_WGRAD_MERGE_MAX_PIXELS", 1 << 17))
+
+
+_WINDOW = [0]                # id of the recurrent window whose forward is running (models: next_window() per Backbone forward)
+
+
+def next_window():
+    """Called by the models at the top of every window's forward: weight-gradient uses are merged within a window only, so the
+    launches are the same whether a window's backward runs in the step's one backward pass or (per-window recompute) from a
+    checkpoint's recomputed graph -- and the two stay bit-identical."""
+    _WINDOW[0] += 1
+    return _WINDOW[0]
+
+
+def current_window():
+    return _WINDOW[0]
+
+
+class _MergeQueue:
+    __slots__ = ("items", "spec", "dev", "w_param", "b_param", "want_bias", "k0", "full", "H", "W", "window")
+
+    def __init__(self, spec, dev, w_param, b_param, want_bias, k0, full, H, W, window):
+        self.items = []
+        self.spec, self.dev, self.w_param, self.b_param, self.want_bias, self.k0, self.full, self.H, self.W, self.window = \
+            spec, dev, w_param, b_param, want_bias, k0, full, H, W, window
+
+
+_MERGE = {}                  # (id(w_param), k0, H, W, want_bias) -> _MergeQueue
+_MERGE_TASK = [-1]           # the autograd graph task whose end-of-pass flush is queued
+
+
+def flush_wgrads():
+    """Launch every queued weight gradient (idempotent)."""
+    if not _MERGE:
+        return
+    qs = list(_MERGE.values())
+    _MERGE.clear()
+    for q in qs:
+        if q.items:
+            _launch_merged(q)
+
+
+def _launch_merged(q):
+    items, q.items = q.items, []
+    keep = tuple(t for it in items for t in it[3])
+    npx = items[0][2] * q.H * q.W          # (the side-stream decision of a pass is made per launch size as before: first segment)
+    with wgrad_side(npx, [q.w_param, q.b_param] if q.want_bias else [q.w_param], keep):
+        _wgrad_wino([it[0] for it in items], [it[1] for it in items], [it[2] for it in items], q.H, q.W, q.spec, q.dev, q.w_param,
+                    q.b_param, None, q.want_bias, q.k0, q.full)
+
+
+def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias=True, k0=None, full=None, keep=(), window=None):
     """(dW, db) of a convolution wino_wgrad_ok() accepted, with reduce_wgrad's conventions: None where the sums went straight
     into a leaf parameter's .grad.  k0 / full: the launch covers only the weight columns [k0, k0 + 128) of a wider convolution
-    (one 128-channel source of a multi-source launch: split_wgrad_ok)."""
+    (one 128-channel source of a multi-source launch: split_wgrad_ok).  window: the recurrent window the use belongs to
+    (current_window() at its forward) -- uses are merged within one window; None: not merged."""
+    task = torch._C._current_graph_task_id()
+    if (WGRAD_MERGE > 1 and window is not None and B * H * W <= WGRAD_MERGE_MAX_PIXELS and task >= 0 and w_param is not None and is_sink(w_param) and (not want_bias or is_sink(b_param))
+            and keep and not wgrad_wino4_ok(B, H, W) and not torch.cuda.is_current_stream_capturing()):
+        k0_ = spec.kmap_host[0] if k0 is None else k0
+        key = (id(w_param), k0_, H, W, bool(want_bias))
+        q = _MERGE.get(key)
+        if q is None or q.w_param is not w_param or q.window != window:       # (another window's uses: the old queue leaves first)
+            if q is not None and q.items:
+                _launch_merged(q)
+            q = _MERGE[key] = _MergeQueue(spec, dev, w_param, b_param, want_bias, k0_, spec.covers_all if full is None else full, H, W,
+                                          window)
+        if _MERGE_TASK[0] != task:       # the first queued use of this backward pass: flush what is left when the pass ends
+            _MERGE_TASK[0] = task
+            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+        q.items.append((a_src, x_src, B, tuple(keep)))
+        if len(q.items) >= WGRAD_MERGE:
+            _launch_merged(q)
+        return None, None
     with (wgrad_side(B * H * W, [w_param, b_param] if want_bias else [w_param], keep) if w_param is not None else _NOCTX):
         return _wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias, k0, full)
 
 
 def _wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias, k0, full):
-    f4 = wgrad_wino4_ok(B, H, W)
+    # a_src / x_src / B: one operand pair, or lists of them (a merged launch: several uses of one weight)
+    multi = isinstance(a_src, (list, tuple))
+    Bt = sum(B) if multi else B
+    f4 = not multi and wgrad_wino4_ok(B, H, W)
     if f4:
         f_ns, f_main, f_red, nm, npos, kind = lib._ww4_nsplit, lib._ww4, lib._ww4_red, "bmc_wgrad_wino4", 36, "wgrad_wino4<9>"
     else:
         f_ns, f_main, f_red, nm, npos, kind = lib._ww_nsplit, lib._ww, lib._ww_red, "bmc_wgrad_wino", 16, "wgrad_wino<9>"
-    nsplit = f_ns(B, H, W)
+    nsplit = f_ns(Bt, H, W)
     part = torch.empty(nsplit * npos * 128 * 128, device=dev, dtype=torch.float32)
     bpart = torch.empty(nsplit * 128, device=dev, dtype=torch.float32) if want_bias else None
     _on_side(part, bpart)
     e0 = _prof_begin()
-    lib.call(f_main, nm, C.byref(a_src), C.byref(x_src), B, H, W, nsplit, part.data_ptr(),
-             bpart.data_ptr() if want_bias else None, _stream())
-    _prof_end(e0, kind, 2.0 * B * H * W * 128 * 9 * 128, 4.0 * B * H * W * 256 + 4.0 * part.numel())
+    if multi:
+        n = len(a_src)
+        lib.call(lib._ww_multi, "bmc_wgrad_wino_multi", (lib.Src * n)(*a_src), (lib.Src * n)(*x_src), (C.c_int * n)(*B), n, H, W, nsplit,
+                 part.data_ptr(), bpart.data_ptr() if want_bias else None, _stream())
+    else:
+        lib.call(f_main, nm, C.byref(a_src), C.byref(x_src), B, H, W, nsplit, part.data_ptr(),
+                 bpart.data_ptr() if want_bias else None, _stream())
+    _prof_end(e0, kind, 2.0 * Bt * H * W * 128 * 9 * 128, 4.0 * Bt * H * W * 256 + 4.0 * part.numel())
     k0 = spec.kmap_host[0] if k0 is None else k0
     full = spec.covers_all if full is None else full
     sg = sink_group([w_param, b_param] if want_bias else [w_param], full) if w_param is not None else None
@@ -631,6 +724,7 @@ def _wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, wan
         lib.call(f_red, nm + "_reduce", part.data_ptr(), nsplit, gw.data_ptr(), spec.cin, k0, acc,
                  bpart.data_ptr() if want_bias else None, rest[0].data_ptr() if want_bias else None, _stream())
         return None, None
+    assert not multi
     dw = (torch.empty if full else torch.zeros)(128 * spec.cin * 9, device=dev, dtype=torch.float32)
     db = torch.empty(128, device=dev, dtype=torch.float32) if want_bias else None
     lib.call(f_red, nm + "_reduce", part.data_ptr(), nsplit, dw.data_ptr(), spec.cin, k0, 0,
@@ -863,8 +957,11 @@ def wgrad_join():
     read or free a .grad: the optimizers' step (a global pre-step hook registered below), GradAllReducer.finish(), the models'
     forward, sink_group outside a backward pass.  Code that catches a backward exception and touches .grad by other means
     (clip_grad_norm_, zero_grad followed by raw allocations) calls it first."""
+    cur = torch._C._current_graph_task_id()
+    if cur < 0:
+        flush_wgrads()              # (inside a backward pass the queues belong to the pass that is running)
     for st in _SIDE.values():
-        if st.armed:
+        if st.armed and (cur < 0 or st.task != cur):      # (a forward recomputed INSIDE the pass that armed it: nothing to join)
             st.join()
 
 
@@ -1043,6 +1140,7 @@ class ConvFn(torch.autograd.Function):
         ctx.w_owner = ck            # identity of the parameter object (saved_tensors may hand back a new wrapper)
         ctx.has_bias = bias is not None
         ctx.has_res = res_t is not None
+        ctx.window = current_window()
         ctx.save_for_backward(weight, out if meta.relu else None, *src_ts)
         return out
 
@@ -1085,7 +1183,7 @@ class ConvFn(torch.autograd.Function):
                 big, rest, sub = sp
                 for n, (i, k0) in enumerate(big):
                     wgrad_wino(a_src, srcs[i], B, H, W, spec, dev, wp_, bp_ if (wb and n == 0) else None, weight.shape,
-                               want_bias=wb and n == 0, k0=k0, full=False, keep=(g, src_ts[i]))
+                               want_bias=wb and n == 0, k0=k0, full=False, keep=(g, src_ts[i]), window=ctx.window)
                 if rest:
                     with wgrad_side(B * H * W, [wp_], (g, *src_ts)):
                         r_pg = pgemm_raw(a_src, [srcs[i] for i in rest], B, H, W, taps, B, Cout, sub.kpad, dev,
@@ -1094,7 +1192,7 @@ class ConvFn(torch.autograd.Function):
                 dw = db = None
             elif wino_wgrad_ok(a_src, srcs, spec, taps, Cout, G) and not isinstance(wp_, (tuple, list)):
                 dw, db = wgrad_wino(a_src, srcs[0], B, H, W, spec, dev, wp_, bp_ if wb else None, weight.shape, want_bias=wb,
-                                    keep=(g, src_ts[0]))
+                                    keep=(g, src_ts[0]), window=ctx.window)
             elif (ngp and 1 < G <= 4 and len(wp_) == G and wino_wgrad_ok(a_src, srcs, spec, taps, Cout, 1) and v0[2] == 0
                   and v0[3] is None):
                 # grouped launch over separate parameters (conv_hp / conv_hn): one Winograd weight gradient per group, on the
@@ -1105,7 +1203,7 @@ class ConvFn(torch.autograd.Function):
                     a_g = _src(g, 0, Cout, 0, None, gi * bpg, bpg)
                     x_g = _src(src_ts[0], v0[0], v0[1], 0, None, v0[4] + gi * bpg, bpg)
                     outs.append(wgrad_wino(a_g, x_g, bpg, H, W, spec, dev, wp_[gi], bp_[gi] if wb else None, wp_[gi].shape, want_bias=wb,
-                                           keep=(g, src_ts[0])))
+                                           keep=(g, src_ts[0]), window=ctx.window))
                 dw = None if all(o[0] is None for o in outs) else torch.stack([
                     o[0] if o[0] is not None else torch.zeros_like(wp_[i]) for i, o in enumerate(outs)])
                 db = None if (not wb or all(o[1] is None for o in outs)) else torch.stack([
@@ -1255,14 +1353,14 @@ def conv_groups(views: Sequence[View], weights, biases, spec: ConvSpec, *, B=Non
 # fused residual block (models/submodules.py:17-35): both ReLU-backward and the skip-path gradient add live in
 # convolution epilogues, so the backward is exactly 2 data-gradient + 2 weight-gradient launches (+ bias sums)
 # --------------------------------------------------------------------------
-def _wgrad_plain(g, x, spec, w_param, b_param, taps):
+def _wgrad_plain(g, x, spec, w_param, b_param, taps, window=None):
     """-> (dW, db) for autograd (None where accumulated into the leaf parameter's .grad): weight gradient and bias
     gradient (column sums of g) from one pgemm launch."""
     B, H, W, Cout = g.shape
     dev = g.device
     a_src, x_src = _src(g, 0, Cout, 0, None, 0, B), _src(x, 0, x.shape[3], 0, None, 0, B)
     if wino_wgrad_ok(a_src, [x_src], spec, taps, Cout, 1):
-        return wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_param.shape, keep=(g, x))
+        return wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_param.shape, keep=(g, x), window=window)
     with wgrad_side(B * H * W, [w_param, b_param], (g, x)):
         slabs, nsplit, _, bsl = pgemm_raw(a_src, [x_src], B, H, W, taps,
                                           B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)
@@ -1332,6 +1430,7 @@ class ResBlockFn(torch.autograd.Function):
         ctx.owners = (w1, w2)
         ctx.params = (w1, b1, w2, b2)
         ctx.gslot = getattr(x, "_bmc_gslot", None)
+        ctx.window = current_window()
         return y
 
     @staticmethod
@@ -1346,14 +1445,14 @@ class ResBlockFn(torch.autograd.Function):
         gs = _src(g, 0, Cn, 0, None, 0, B)
         nkpad, c16 = coutpad(Cn), round_up(Cn, CK)
         p_w1, p_b1, p_w2, p_b2 = ctx.params
-        dw2, db2 = _wgrad_plain(g, t, spec, p_w2, p_b2, taps) if (need[3] or need[4]) else (None, None)
+        dw2, db2 = _wgrad_plain(g, t, spec, p_w2, p_b2, taps, ctx.window) if (need[3] or need[4]) else (None, None)
         # d(pre-activation of conv1) = ReLU'(t) * conv2^T(g): mask epilogue
         wn = wino_ok(B, H, W, Cn, taps)
         w2t = _packed_weight_t(w2.detach().reshape(1, Cn, Cn, taps), spec, 0, ctx.owners[1], wino=wn)
         dt = torch.empty_like(g)
         conv_raw([gs], w2t, c16 * taps * nkpad, None, 0, dt.data_ptr(), H * W * Cn, Cn, B, H, W, Cn, taps,
                  mask=_src(t, 0, Cn, 0, None, 0, B), flops=fl, wino=wn)
-        dw1, db1 = _wgrad_plain(dt, x, spec, p_w1, p_b1, taps) if (need[1] or need[2]) else (None, None)
+        dw1, db1 = _wgrad_plain(dt, x, spec, p_w1, p_b1, taps, ctx.window) if (need[1] or need[2]) else (None, None)
         dx = None
         if need[0]:   # dx = conv1^T(dt) + g (skip path): residual epilogue
             w1t = _packed_weight_t(w1.detach().reshape(1, Cn, Cn, taps), spec, 0, ctx.owners[0], wino=wn)

@@ -109,8 +109,19 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
         nsy = r / a.SX; nsx = r - nsy * a.SX;
     }
     nb = __builtin_amdgcn_readfirstlane(nb); nsy = __builtin_amdgcn_readfirstlane(nsy); nsx = __builtin_amdgcn_readfirstlane(nsx);
-    const char* xbase = uni(src_batch_ptr(a.x, nb));
-    const char* abase = uni(src_batch_ptr(a.a, nb));
+    // image nb of the launch -> its segment's operand pair (a handful of scalar compares, once per image)
+    auto xptr = [&](const int b) __attribute__((always_inline)) {
+        int s = 0;
+        while (s + 1 < a.nseg && b >= a.segb[s + 1]) ++s;
+        return uni(src_batch_ptr(a.x[s], b - a.segb[s]));
+    };
+    auto aptr = [&](const int b) __attribute__((always_inline)) {
+        int s = 0;
+        while (s + 1 < a.nseg && b >= a.segb[s + 1]) ++s;
+        return uni(src_batch_ptr(a.a[s], b - a.segb[s]));
+    };
+    const char* xbase = xptr(nb);
+    const char* abase = aptr(nb);
 
     f32x4 xa[4], xb[4], y0[2], y1[2];        // the two patch rows; dY row 0 (row 1 for xi = 3); dY row 1 (xi = 1, 2)
     // Requests the rows of the next stage.  Every address is clamped into the image (one scalar base per image row + one
@@ -153,8 +164,10 @@ __device__ __forceinline__ void wgrad_body(const WgradK& a, float* const lds, co
             nsx = 0;
             if (++nsy == a.SY) {
                 nsy = 0; ++nb;
-                xbase = uni(src_batch_ptr(a.x, nb));
-                abase = uni(src_batch_ptr(a.a, nb));
+                if (nb < a.B) {
+                    xbase = xptr(nb);
+                    abase = aptr(nb);
+                }
             }
         }
         return zm;
@@ -361,16 +374,25 @@ extern "C" int bmc_wgrad_wino_nsplit(int B, int H, int W) {
     return (int)(stages < per_xi ? stages : per_xi);
 }
 
-extern "C" int bmc_wgrad_wino(const bmc_src_t* dy, const bmc_src_t* x, int B, int H, int W, int nsplit, float* part,
-                              float* bias_part, bmc_stream_t s) {
-    BMC_CHECK_ARG(dy && x && part && dy->ptr && x->ptr, "bmc_wgrad_wino: null argument");
-    BMC_CHECK_ARG(dy->nch == 128 && x->nch == 128, "bmc_wgrad_wino: both operands must be 128-channel windows (got %d, %d)", dy->nch,
-                  x->nch);
-    BMC_CHECK_ARG(dy->pix_stride == 128 && x->pix_stride == 128, "bmc_wgrad_wino: both operands must be dense in the channel axis "
-                  "(pix_stride 128; got %d, %d)", dy->pix_stride, x->pix_stride);
-    BMC_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && (long long)H * W * 128 < (1ll << 29), "bmc_wgrad_wino: bad geometry");
+extern "C" int bmc_wgrad_wino_multi(const bmc_src_t* dy, const bmc_src_t* x, const int* batches, int nseg, int H, int W, int nsplit,
+                                    float* part, float* bias_part, bmc_stream_t s) {
+    BMC_CHECK_ARG(dy && x && batches && part, "bmc_wgrad_wino: null argument");
+    BMC_CHECK_ARG(nseg >= 1 && nseg <= BMC_WG_MAXSEG, "bmc_wgrad_wino: 1 .. %d operand pairs per launch (got %d)", BMC_WG_MAXSEG, nseg);
     WgradK k;
-    k.a = to_dev(*dy); k.x = to_dev(*x);
+    k.nseg = nseg;
+    k.segb[0] = 0;
+    for (int i = 0; i < nseg; ++i) {
+        BMC_CHECK_ARG(dy[i].ptr && x[i].ptr && batches[i] >= 1, "bmc_wgrad_wino: null operand / empty segment %d", i);
+        BMC_CHECK_ARG(dy[i].nch == 128 && x[i].nch == 128, "bmc_wgrad_wino: both operands must be 128-channel windows (got %d, %d)",
+                      dy[i].nch, x[i].nch);
+        BMC_CHECK_ARG(dy[i].pix_stride == 128 && x[i].pix_stride == 128, "bmc_wgrad_wino: both operands must be dense in the channel "
+                      "axis (pix_stride 128; got %d, %d)", dy[i].pix_stride, x[i].pix_stride);
+        k.a[i] = to_dev(dy[i]); k.x[i] = to_dev(x[i]);
+        k.segb[i + 1] = k.segb[i] + batches[i];
+    }
+    for (int i = nseg; i < BMC_WG_MAXSEG; ++i) { k.a[i] = k.a[0]; k.x[i] = k.x[0]; k.segb[i + 1] = k.segb[nseg]; }
+    const int B = k.segb[nseg];
+    BMC_CHECK_ARG(H >= 1 && W >= 1 && (long long)H * W * 128 < (1ll << 29), "bmc_wgrad_wino: bad geometry");
     k.B = B; k.H = H; k.W = W;
     k.SY = ((H + 1) / 2 + 1) / 2; k.SX = ((W + 1) / 2 + 7) / 8;
     const long long stages = (long long)B * k.SY * k.SX;
@@ -381,6 +403,12 @@ extern "C" int bmc_wgrad_wino(const bmc_src_t* dy, const bmc_src_t* x, int B, in
     hipLaunchKernelGGL(wino_wgrad_kernel, dim3((unsigned)nsplit * 4), dim3(512), 0, (hipStream_t)s, k);
     BMC_CHECK_LAUNCH("bmc_wgrad_wino");
     return 0;
+}
+
+extern "C" int bmc_wgrad_wino(const bmc_src_t* dy, const bmc_src_t* x, int B, int H, int W, int nsplit, float* part,
+                              float* bias_part, bmc_stream_t s) {
+    BMC_CHECK_ARG(dy && x && B >= 1, "bmc_wgrad_wino: null argument");
+    return bmc_wgrad_wino_multi(dy, x, &B, 1, H, W, nsplit, part, bias_part, s);
 }
 
 extern "C" int bmc_wgrad_wino_reduce(const float* part, int nsplit, float* dw, int ldw, int k0, int accumulate,

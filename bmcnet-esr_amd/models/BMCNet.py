@@ -130,6 +130,7 @@ class Backbone(nn.Module):
         h3 [3B,H,W,n_c] = [hp; hn; hs]; o12 [2B,H,W,s^2] = [o[:, :s^2]; o[:, s^2:]] (channel halves batch-stacked).
         Returns x_h, x_h_p, x_h_n, x_o (NHWC)."""
         ops.wgrad_join()         # (a backward pass that raised leaves weight gradients running on the side stream: ops.wgrad_join)
+        ops.next_window()        # (weight-gradient uses are merged within a window: ops.wgrad_wino)
         B = o12.shape[0] // 2
         hpn = h3[:2 * B]
         # (which 3x3 launches may take the F(4x4) kernel: the exact-zero rule above ops.wino_ok; round 4 keyed it on `zero_state`,

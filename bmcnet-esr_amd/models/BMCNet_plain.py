@@ -40,6 +40,7 @@ class Backbone(nn.Module):
 
     def forward_nhwc(self, xin12, h, o12, zero_state=True):
         ops.wgrad_join()         # (a backward pass that raised leaves weight gradients running on the side stream: ops.wgrad_join)
+        ops.next_window()        # (weight-gradient uses are merged within a window: ops.wgrad_wino)
         B = h.shape[0]
         # (F(4x4) or a kernel that is exact on empty receptive fields: decided per launch from its bias, ops.wino_ok's exact-zero
         #  rule; `zero_state` is unused since round 5)

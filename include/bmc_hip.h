@@ -267,6 +267,12 @@ int bmc_wgrad_wino(const bmc_src_t* dy, const bmc_src_t* x, int B, int H, int W,
                    bmc_stream_t s);
 int bmc_wgrad_wino_reduce(const float* part, int nsplit, float* dw, int ldw, int k0, int accumulate, const float* bias_part,
                           float* db, bmc_stream_t s);
+/* The same sum over SEVERAL (dy, x) operand pairs in one launch -- the uses of one weight by the weight-sharing blocks of a
+ * window (models/BMCNet.py:19-32: `para_reschunk` holds ONE ParallelBlk n_b times), which autograd would add one by one:
+ * dy[i], x[i] with batches[i] images each, i < nseg <= 8; nsplit <= bmc_wgrad_wino_nsplit(sum of batches, H, W); the result
+ * goes through bmc_wgrad_wino_reduce as before (one partial-sum set, one reduction instead of nseg). */
+int bmc_wgrad_wino_multi(const bmc_src_t* dy, const bmc_src_t* x, const int* batches, int nseg, int H, int W, int nsplit,
+                         float* part, float* bias_part, bmc_stream_t s);
 
 /* ---- the same weight gradient through F(4x4, 3x3) (round 5): 36 multiplies per 4x4 output tile and channel pair, i.e. 2.25 per
  * output pixel against 4 -- the transform of bmc_conv's BMC_MATH_FP32_WINO4 forward / data-gradient kernel applied to
