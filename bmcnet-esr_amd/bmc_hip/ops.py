@@ -609,7 +609,7 @@ def wino_wgrad_ok(a_src, x_srcs, spec, taps, Cout, G):
 # ONE launch over several (dY, x) pairs (bmc_wgrad_wino_multi) with one reduction.  Queues that are not full are flushed when the
 # backward pass ends (engine callback, queued before the side stream's join) and by wgrad_join() -- i.e. before anything reads a
 # .grad.  Uses of different windows never share a launch (next_window(): the groups must not depend on how backward is cut into
-# passes).  Costs: at most WGRAD_MERGE - 1 transient gradients per weight stay alive a little longer (C2: +R5_MERGE_MEM GiB peak).
+# passes).  Costs: at most WGRAD_MERGE - 1 transient gradients per weight stay alive a little longer (31x56 bs 4: peak memory unchanged, 6.4 GiB).
 # BMC_WGRAD_MERGE=1 switches it off.  Deterministic (the queue order is backward's order); NOT bit-identical to the unmerged
 # order of summation.
 WGRAD_MERGE = max(1, min(8, int(os.environ.get("BMC_WGRAD_MERGE", 5))))
@@ -673,6 +673,8 @@ def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want
     (one 128-channel source of a multi-source launch: split_wgrad_ok).  window: the recurrent window the use belongs to
     (current_window() at its forward) -- uses are merged within one window; None: not merged."""
     task = torch._C._current_graph_task_id()
+    if task >= 0 and _MERGE and _MERGE_TASK[0] != task:
+        _MERGE.clear()                   # uses queued by a backward pass that raised (a pass that ends flushes its own): dropped
     if (WGRAD_MERGE > 1 and window is not None and B * H * W <= WGRAD_MERGE_MAX_PIXELS and task >= 0 and w_param is not None and is_sink(w_param) and (not want_bias or is_sink(b_param))
             and keep and not wgrad_wino4_ok(B, H, W) and not torch.cuda.is_current_stream_capturing()):
         k0_ = spec.kmap_host[0] if k0 is None else k0
@@ -686,6 +688,7 @@ def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want
         if _MERGE_TASK[0] != task:       # the first queued use of this backward pass: flush what is left when the pass ends
             _MERGE_TASK[0] = task
             torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+        _side_arm(B * H * W)             # (the pass's side-stream decision is made by its first USE, as without the queue)
         q.items.append((a_src, x_src, B, tuple(keep)))
         if len(q.items) >= WGRAD_MERGE:
             _launch_merged(q)
@@ -958,8 +961,11 @@ def wgrad_join():
     forward, sink_group outside a backward pass.  Code that catches a backward exception and touches .grad by other means
     (clip_grad_norm_, zero_grad followed by raw allocations) calls it first."""
     cur = torch._C._current_graph_task_id()
-    if cur < 0:
-        flush_wgrads()              # (inside a backward pass the queues belong to the pass that is running)
+    if cur < 0 and _MERGE:
+        # weight-gradient uses still queued outside a backward pass: the pass that queued them raised (a pass that ends flushes
+        # its own queues).  Its gradients are undefined anyway; launching them NOW would add them to whatever .grad holds after
+        # the caller's zero_grad -- they are dropped
+        _MERGE.clear()
     for st in _SIDE.values():
         if st.armed and (cur < 0 or st.task != cur):      # (a forward recomputed INSIDE the pass that armed it: nothing to join)
             st.join()
@@ -1006,12 +1012,11 @@ _NOCTX = _NoCtx()
 
 
 
-def wgrad_side(npx, params, keep=()):
-    """Context for one weight-gradient launch (+ its reduction): the side stream when the mode has it (above), all its
-    destinations are sink parameters and an autograd backward pass is running (the join hangs on its end), else nothing.
-    keep: the operand tensors of the launch (referenced until the join)."""
+def _side_arm(npx):
+    """The side-stream decision of the running backward pass (made by its FIRST weight-gradient use, launched or queued): ->
+    the device's _SideState, or None outside a backward pass / with the stream switched off."""
     if WGRAD_SIDE == "0" or torch._C._current_graph_task_id() < 0:
-        return _NOCTX
+        return None
     dev = _cur_dev()
     st = _SIDE.get(dev)
     if st is None:
@@ -1023,7 +1028,7 @@ def wgrad_side(npx, params, keep=()):
         st.join()
     if not st.armed:
         st.task = task
-        # the FIRST weight-gradient launch of a backward pass decides for the whole pass: one parameter's gradient is
+        # the FIRST weight-gradient use of a backward pass decides for the whole pass: one parameter's gradient is
         # accumulated by launches of different batch sizes (conv_fs: B and 3B), and its read-modify-writes must not be
         # split over two streams
         # (not while a HIP graph is being captured: replaying the two-stream graph serialises badly -- 31x56: 174.9 ms against
@@ -1031,7 +1036,15 @@ def wgrad_side(npx, params, keep=()):
         st.side = WGRAD_SIDE == "1" or (MATH == 0 and npx >= WGRAD_SIDE_MIN_PIXELS and not torch.cuda.is_current_stream_capturing())
         torch.autograd.Variable._execution_engine.queue_callback(st.join)
         st.armed = True
-    if not st.side:
+    return st
+
+
+def wgrad_side(npx, params, keep=()):
+    """Context for one weight-gradient launch (+ its reduction): the side stream when the mode has it (above), all its
+    destinations are sink parameters and an autograd backward pass is running (the join hangs on its end), else nothing.
+    keep: the operand tensors of the launch (referenced until the join)."""
+    st = _side_arm(npx)
+    if st is None or not st.side:
         return _NOCTX
     ps = [p for p in params if p is not None]
     if not ps or not all(is_sink(p) for p in ps):

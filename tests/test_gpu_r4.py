@@ -372,8 +372,8 @@ def test_weight_gradient_stream_recovers_from_a_backward_that_raised():
     b = torch.zeros(128, device=dev, requires_grad=True)
     x = torch.randn(2, 24, 32, 128, device=dev, requires_grad=True)
     spec = ConvSpec.dense(128)
-    old = ops.WGRAD_SIDE
-    ops.WGRAD_SIDE = "1"
+    old, old_merge = ops.WGRAD_SIDE, ops.WGRAD_MERGE
+    ops.WGRAD_SIDE, ops.WGRAD_MERGE = "1", 1          # (no queue: the weight gradient of the raising pass is LAUNCHED before it raises)
     try:
         with pytest.raises(RuntimeError, match="boom"):
             ops.conv([View(Boom.apply(x))], w, b, spec).sum().backward()
@@ -389,4 +389,4 @@ def test_weight_gradient_stream_recovers_from_a_backward_that_raised():
         ops.conv([View(x)], w, b, spec).sum().backward()
         assert torch.equal(got, w.grad)
     finally:
-        ops.WGRAD_SIDE = old
+        ops.WGRAD_SIDE, ops.WGRAD_MERGE = old, old_merge

@@ -132,9 +132,9 @@ def test_side_stream_is_joined_after_a_caught_backward_exception():
         def backward(ctx, gr):
             raise RuntimeError("boom")
 
-    def run(mode):
-        old, old_min = ops.WGRAD_SIDE, ops.WGRAD_SIDE_MIN_PIXELS
-        ops.WGRAD_SIDE, ops.WGRAD_SIDE_MIN_PIXELS = mode, 0
+    def run(mode, merge=1, fail_first=True):
+        old, old_min, old_merge = ops.WGRAD_SIDE, ops.WGRAD_SIDE_MIN_PIXELS, ops.WGRAD_MERGE
+        ops.WGRAD_SIDE, ops.WGRAD_SIDE_MIN_PIXELS, ops.WGRAD_MERGE = mode, 0, merge
         try:
             torch.manual_seed(512)
             m = BMCNet(scale, n_c, 1).to(dev)
@@ -143,17 +143,20 @@ def test_side_stream_is_joined_after_a_caught_backward_exception():
             z = lambda c: torch.zeros(B, c, H, W, device=dev)
             st0 = (z(n_c), z(n_c), z(n_c), z(2 * scale * scale))
             # pass 1 raises deep inside backward: the head's weight gradients are already on the side stream
-            hs = list(m(x, *st0, True))
-            out2 = m(x, Boom.apply(hs[0]), *hs[1:], False)
-            with pytest.raises(RuntimeError, match="boom"):
-                F.mse_loss(out2[-1], gt).backward()
-            if mode != "0":
-                assert any(s.armed for s in ops._SIDE.values())       # nothing has joined the raised pass yet
+            if fail_first:
+                hs = list(m(x, *st0, True))
+                out2 = m(x, Boom.apply(hs[0]), *hs[1:], False)
+                with pytest.raises(RuntimeError, match="boom"):
+                    F.mse_loss(out2[-1], gt).backward()
+                if mode != "0":
+                    assert any(s.armed for s in ops._SIDE.values())       # nothing has joined the raised pass yet
+                if merge > 1:
+                    assert ops._MERGE                                      # ... and its queued weight gradients never left
             opt.zero_grad(set_to_none=True)                           # frees .grad blocks the side stream may still be writing
             filler = [torch.full((1 << 20,), 7.0, device=dev) for _ in range(8)]   # ... and the allocator hands them out again
             # pass 2: a clean step
             out = m(x, *st0, True)
-            assert not any(s.armed for s in ops._SIDE.values())       # the forward joined
+            assert not any(s.armed for s in ops._SIDE.values()) and not ops._MERGE       # the forward joined, stale queues are dropped
             loss = F.mse_loss(out[-1], gt)
             loss.backward()
             opt.step()
@@ -161,16 +164,20 @@ def test_side_stream_is_joined_after_a_caught_backward_exception():
             assert all(bool((f == 7.0).all()) for f in filler)        # nothing landed in re-used memory
             return loss.item(), [p.grad.clone() for p in m.parameters() if p.grad is not None], [p.detach().clone() for p in m.parameters()]
         finally:
-            ops.WGRAD_SIDE, ops.WGRAD_SIDE_MIN_PIXELS = old, old_min
+            ops.WGRAD_SIDE, ops.WGRAD_SIDE_MIN_PIXELS, ops.WGRAD_MERGE = old, old_min, old_merge
 
-    l0, g0, p0 = run("0")
-    for _ in range(2):
-        l1, g1, p1 = run("1")
-        assert l0 == l1 and len(g0) == len(g1)
-        assert all(torch.equal(a, b) for a, b in zip(g0, g1)) and all(torch.equal(a, b) for a, b in zip(p0, p1))
+    for merge in (1, 5):             # launches one by one / queued and merged (ops.wgrad_wino): the raised pass leaves queues behind
+        l0, g0, p0 = run("0", merge)
+        for _ in range(2):
+            l1, g1, p1 = run("1", merge)
+            assert l0 == l1 and len(g0) == len(g1)
+            assert all(torch.equal(a, b) for a, b in zip(g0, g1)) and all(torch.equal(a, b) for a, b in zip(p0, p1))
+        # nothing of the raised pass reaches the clean step: the same as never having run it
+        lc, gc, pc = run("1", merge, fail_first=False)
+        assert lc == l0 and all(torch.equal(a, b) for a, b in zip(gc, g0)) and all(torch.equal(a, b) for a, b in zip(pc, p0))
     # the optimizers' pre-step hook alone (no forward in between): step() right after a raised backward reads joined gradients
-    old = ops.WGRAD_SIDE
-    ops.WGRAD_SIDE = "1"
+    old, old_merge = ops.WGRAD_SIDE, ops.WGRAD_MERGE
+    ops.WGRAD_SIDE, ops.WGRAD_MERGE = "1", 1
     try:
         from bmc_hip.ops import ConvSpec, View
         w = (torch.randn(128, 128, 3, 3, device=dev) * 0.05).requires_grad_()
@@ -183,7 +190,7 @@ def test_side_stream_is_joined_after_a_caught_backward_exception():
         opt.step()
         assert not st.armed and not st.keep
     finally:
-        ops.WGRAD_SIDE = old
+        ops.WGRAD_SIDE, ops.WGRAD_MERGE = old, old_merge
 
 
 # ------------------------------------------------------------------ F(4x4) Winograd weight gradient (csrc/wino4_wgrad.hip)
