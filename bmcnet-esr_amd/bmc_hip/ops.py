@@ -645,6 +645,7 @@ class _MergeQueue:
 
 _MERGE = {}                  # (id(w_param), k0, H, W, want_bias) -> _MergeQueue
 _MERGE_TASK = [-1]           # the autograd graph task whose end-of-pass flush is queued
+_MERGE_OWNER = [-1]          # the graph task that queued what is in _MERGE
 
 
 def flush_wgrads():
@@ -673,7 +674,7 @@ def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want
     (one 128-channel source of a multi-source launch: split_wgrad_ok).  window: the recurrent window the use belongs to
     (current_window() at its forward) -- uses are merged within one window; None: not merged."""
     task = torch._C._current_graph_task_id()
-    if task >= 0 and _MERGE and _MERGE_TASK[0] != task:
+    if task >= 0 and _MERGE and _MERGE_OWNER[0] != task:
         _MERGE.clear()                   # uses queued by a backward pass that raised (a pass that ends flushes its own): dropped
     if (WGRAD_MERGE > 1 and window is not None and B * H * W <= WGRAD_MERGE_MAX_PIXELS and task >= 0 and w_param is not None and is_sink(w_param) and (not want_bias or is_sink(b_param))
             and keep and not wgrad_wino4_ok(B, H, W) and not torch.cuda.is_current_stream_capturing()):
@@ -689,6 +690,7 @@ def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want
             _MERGE_TASK[0] = task
             torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
         _side_arm(B * H * W)             # (the pass's side-stream decision is made by its first USE, as without the queue)
+        _MERGE_OWNER[0] = task
         q.items.append((a_src, x_src, B, tuple(keep)))
         if len(q.items) >= WGRAD_MERGE:
             _launch_merged(q)
@@ -1034,6 +1036,10 @@ def _side_arm(npx):
         # (not while a HIP graph is being captured: replaying the two-stream graph serialises badly -- 31x56: 174.9 ms against
         #  82.3 ms eager and 88 ms for the one-stream graph; "1" forces it)
         st.side = WGRAD_SIDE == "1" or (MATH == 0 and npx >= WGRAD_SIDE_MIN_PIXELS and not torch.cuda.is_current_stream_capturing())
+        # (end-of-pass callbacks run in the order they were queued: what is left in the merge queues leaves BEFORE the join)
+        if _MERGE_TASK[0] != task:
+            _MERGE_TASK[0] = task
+            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
         torch.autograd.Variable._execution_engine.queue_callback(st.join)
         st.armed = True
     return st
