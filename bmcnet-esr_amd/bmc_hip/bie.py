@@ -223,11 +223,8 @@ def _wgrad(a_src, x_srcs, spec, B, H, W, taps, Cout, dev, w_param, b_param, G=1,
     if ops.wino_wgrad_ok(a_src, x_srcs, spec, taps, Cout, G) and w_param is not None:
         return ops.wgrad_wino(a_src, x_srcs[0], B, H, W, spec, dev, w_param, b_param, w_shape if w_shape is not None else w_param.shape,
                               keep=keep, window=window)
-    with ops.wgrad_side(B * H * W, ops._flat_params(w_param, b_param), keep):
-        slabs, nsplit, _, bsl = pgemm_raw(a_src, x_srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev,
-                                          flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)
-        return ops.reduce_wgrad(slabs, nsplit, G, taps, Cout, spec, dev, bsl, w_param, b_param,
-                                w_shape if w_shape is not None else w_param.shape)
+    return ops.wgrad_pgemm(a_src, x_srcs, B, H, W, taps, Cout, spec, dev, w_param, b_param,
+                           w_shape if w_shape is not None else w_param.shape, G=G, keep=keep, window=window)
 
 
 class BIETwinFn(torch.autograd.Function):
@@ -368,11 +365,11 @@ class BIETwinFn(torch.autograd.Function):
             w_dc = torch.cat([da, w_ut], 2).view(B2, Cn, 2 * Cn, 1)
             _conv([X(v12), X(g_x, mod=n, B=B2)], w_dc, s2, None, None, dc12, B2, bpg=1)
         # ---- unclustering(cat[c1, c2]) + xs: weight gradient
-        dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu, keep=(g_x, c12))
+        dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu, keep=(g_x, c12), window=ctx.window)
         # ---- value convs (two weight groups)
         if not vfree:
             dwv, dbv = _wgrad(X(dv12), [X(x12)], s1, B2, H, W, 1, Cn, dev, ctx.vparams[:2], ctx.vparams[2:], G=2,
-                              w_shape=(2, Cn, Cn, 1, 1), keep=(dv12, x12))
+                              w_shape=(2, Cn, Cn, 1, 1), keep=(dv12, x12), window=ctx.window)
         if ctx.fused:
             # ---- clustering, LayerNorm, convf: ONE data-gradient launch (csrc/chain.hip); y12 holds yhat, stats rstd.
             # dx12 = conv_f^T (second half of its inputs), dxs = skip + conv_f^T (first half) summed over both halves.
@@ -393,7 +390,7 @@ class BIETwinFn(torch.autograd.Function):
                      gamma.detach().data_ptr(), beta.detach().data_ptr(), Cn, o_w.data_ptr(),
                      o_b.data_ptr() if o_b is not None else None, o_g.data_ptr(), o_bt.data_ptr(), acc, _stream())
             dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf,
-                              keep=(dz12, xs, x12))
+                              keep=(dz12, xs, x12), window=ctx.window)
             if vfree:
                 _conv([X(g_o), X(c12)], w_dx, s2, None, None, dx12, B2, bpg=1, accumulate=True)         # dx12 += attention
             else:
@@ -405,7 +402,7 @@ class BIETwinFn(torch.autograd.Function):
             else:
                 _dgrad(X(dv12), w_v, s1, 0, w_v, dx12, B2, bpg=n)                                       # dx12  =
             # ---- clustering, LayerNorm, convf
-            dwc, dbc = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev, p_wc, p_bc, keep=(dc12, y12))
+            dwc, dbc = _wgrad(X(dc12), [X(y12)], s1, B2, H, W, 1, Cn, dev, p_wc, p_bc, keep=(dc12, y12), window=ctx.window)
             dy12 = new(B2)
             _dgrad(X(dc12), w_c, s1, 0, o_wc, dy12, B2)
             dz12 = new(B2)
@@ -421,7 +418,7 @@ class BIETwinFn(torch.autograd.Function):
             lib.call(lib._ln_bwd, "bmc_layernorm_bwd", dy12.data_ptr(), z12.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
                      B2 * H * W, Cn, dz12.data_ptr(), ws.data_ptr(), o_g.data_ptr(), o_bt.data_ptr(), ln_acc, _stream())
             dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf,
-                              keep=(dz12, xs, x12))
+                              keep=(dz12, xs, x12), window=ctx.window)
             dxs = new(n)
             _dgrad(X(dz12, b0=0, B=n), w_f, s2, 0, o_wf, dxs, n, residual=X(g_x))                        # dxs  = skip + half 0
             _dgrad(X(dz12, b0=n, B=n), w_f, s2, 0, o_wf, dxs, n, accumulate=True)                        # dxs += half 1
@@ -549,9 +546,9 @@ class BIEFirstFn(torch.autograd.Function):
             _conv([X(g_o), X(c12, b0=0, B=n)], w_dv, s2, None, None, dv1, n, bpg=1)
             w_dc = torch.cat([torch.cat([da, torch.zeros_like(da)], 0), w_ut], 2).view(B2, Cn, 2 * Cn, 1)
             _conv([X(v1, mod=n, B=B2), X(g_x, mod=n, B=B2)], w_dc, s2, None, None, dc12, B2, bpg=1)
-        dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu, keep=(g_x, c12))
+        dwu, dbu = _wgrad(X(g_x), [X(c12, b0=0, B=n), X(c12, b0=n, B=n)], s2, n, H, W, 1, Cn, dev, p_wu, p_bu, keep=(g_x, c12), window=ctx.window)
         if not vfree:
-            dwv1, dbv1 = _wgrad(X(dv1), [X(x12, b0=0, B=n)], s1, n, H, W, 1, Cn, dev, p_wv1, p_bv1, keep=(dv1, x12))
+            dwv1, dbv1 = _wgrad(X(dv1), [X(x12, b0=0, B=n)], s1, n, H, W, 1, Cn, dev, p_wv1, p_bv1, keep=(dv1, x12), window=ctx.window)
         # ---- clustering, LayerNorm, convf (csrc/chain.hip), as in BIETwinFn
         dz12, dx12, dxs = chain_bwd(X(dc12), yhat, rstd, gamma.detach(), wf, wc, X(g_x), n, H, W, Cn, dev)
         Gm, dbc_t = _wgrad(X(dc12), [X(yhat)], s1, B2, H, W, 1, Cn, dev, None, None, w_shape=(Cn, Cn))
@@ -568,7 +565,7 @@ class BIEFirstFn(torch.autograd.Function):
                  gamma.detach().data_ptr(), beta.detach().data_ptr(), Cn, o_w.data_ptr(),
                  o_b.data_ptr() if o_b is not None else None, o_g.data_ptr(), o_bt.data_ptr(), acc, _stream())
         dwf, dbf = _wgrad(X(dz12), [X(xs, mod=n, B=B2), X(x12, shift=n, mod=B2)], s2, B2, H, W, 1, Cn, dev, p_wf, p_bf,
-                          keep=(dz12, xs, x12))
+                          keep=(dz12, xs, x12), window=ctx.window)
         if vfree:
             _conv([X(g_o), X(c12, b0=0, B=n)], w_dx, s2, None, None, dx12, n, bpg=1, accumulate=True)    # dx12[first] += attention
         else:

@@ -635,12 +635,12 @@ def current_window():
 
 
 class _MergeQueue:
-    __slots__ = ("items", "spec", "dev", "w_param", "b_param", "want_bias", "k0", "full", "H", "W", "window")
+    __slots__ = ("items", "spec", "dev", "w_param", "b_param", "want_bias", "k0", "full", "H", "W", "window", "pg")
 
-    def __init__(self, spec, dev, w_param, b_param, want_bias, k0, full, H, W, window):
+    def __init__(self, spec, dev, w_param, b_param, want_bias, k0, full, H, W, window, pg=None):
         self.items = []
-        self.spec, self.dev, self.w_param, self.b_param, self.want_bias, self.k0, self.full, self.H, self.W, self.window = \
-            spec, dev, w_param, b_param, want_bias, k0, full, H, W, window
+        self.spec, self.dev, self.w_param, self.b_param, self.want_bias, self.k0, self.full, self.H, self.W, self.window, self.pg = \
+            spec, dev, w_param, b_param, want_bias, k0, full, H, W, window, pg      # pg: (taps, Cout, w_shape) of a pixel-reduction queue
 
 
 _MERGE = {}                  # (id(w_param), k0, H, W, want_bias) -> _MergeQueue
@@ -659,13 +659,88 @@ def flush_wgrads():
             _launch_merged(q)
 
 
+def _table_src(srcs, batches, table, slot, btot):
+    """One operand of a merged pixel-reduction launch: the images of `srcs` (one lib.Src per use, batches[i] images each) behind
+    ONE descriptor in BMC_SRC_TABLE mode -- slot `slot` of the device pointer table (btot entries per slot)."""
+    ptrs = []
+    for s_, nb in zip(srcs, batches):
+        mod = s_.batch_mod if s_.batch_mod >= 1 else 1
+        ptrs.extend(s_.ptr + 4 * (((i + s_.batch_shift) % mod) * s_.batch_stride) for i in range(nb))
+    lib.call(lib._ptr_table, "bmc_ptr_table", (C.c_ulonglong * btot)(*ptrs), btot, table.data_ptr() + 8 * slot * btot, _stream())
+    t = lib.Src()
+    t.ptr = table.data_ptr() + 8 * slot * btot
+    t.batch_stride, t.pix_stride, t.nch, t.batch_shift, t.batch_mod = 0, srcs[0].pix_stride, srcs[0].nch, 0, -1      # BMC_SRC_TABLE
+    return t
+
+
 def _launch_merged(q):
     items, q.items = q.items, []
     keep = tuple(t for it in items for t in it[3])
     npx = items[0][2] * q.H * q.W          # (the side-stream decision of a pass is made per launch size as before: first segment)
+    if q.pg is not None:
+        taps, Cout, w_shape = q.pg
+        batches = [it[2] for it in items]
+        btot = sum(batches)
+        nx = len(items[0][1])
+        with wgrad_side(npx, [q.w_param, q.b_param] if q.want_bias else [q.w_param], keep):
+            table = torch.empty((nx + 1) * btot, device=q.dev, dtype=torch.int64)
+            _on_side(table)
+            a_t = _table_src([it[0] for it in items], batches, table, 0, btot)
+            x_t = [_table_src([it[1][k] for it in items], batches, table, k + 1, btot) for k in range(nx)]
+            r = pgemm_raw(a_t, x_t, btot, q.H, q.W, taps, btot, Cout, q.spec.kpad, q.dev,
+                          flops=2.0 * btot * q.H * q.W * Cout * taps * q.spec.kreal, want_bias=q.want_bias)
+            reduce_wgrad(r[0], r[1], 1, taps, Cout, q.spec, q.dev, r[3] if q.want_bias else None, q.w_param,
+                         q.b_param if q.want_bias else None, w_shape)
+        return
     with wgrad_side(npx, [q.w_param, q.b_param] if q.want_bias else [q.w_param], keep):
         _wgrad_wino([it[0] for it in items], [it[1] for it in items], [it[2] for it in items], q.H, q.W, q.spec, q.dev, q.w_param,
                     q.b_param, None, q.want_bias, q.k0, q.full)
+
+
+def _queue_use(key, make_queue, item, task, npx):
+    """Append one use to its merge queue (created by make_queue() if new / stale) and launch the queue when it is full."""
+    q = _MERGE.get(key)
+    if q is None or q.w_param is not item[4] or q.window != item[5]:       # (another window's uses: the old queue leaves first)
+        if q is not None and q.items:
+            _launch_merged(q)
+        q = _MERGE[key] = make_queue()
+    if _MERGE_TASK[0] != task:       # the first queued use of this backward pass: flush what is left when the pass ends
+        _MERGE_TASK[0] = task
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+    _side_arm(npx)                   # (the pass's side-stream decision is made by its first USE, as without the queue)
+    _MERGE_OWNER[0] = task
+    q.items.append(item[:4])
+    if len(q.items) >= WGRAD_MERGE:
+        _launch_merged(q)
+
+
+def _mergeable(B, H, W, w_param, b_param, want_bias, keep, window):
+    task = torch._C._current_graph_task_id()
+    if task >= 0 and _MERGE and _MERGE_OWNER[0] != task:
+        _MERGE.clear()                   # uses queued by a backward pass that raised (a pass that ends flushes its own): dropped
+    ok = (WGRAD_MERGE > 1 and window is not None and B * H * W <= WGRAD_MERGE_MAX_PIXELS and task >= 0 and w_param is not None
+          and not isinstance(w_param, (tuple, list)) and is_sink(w_param) and (not want_bias or is_sink(b_param)) and keep
+          and not torch.cuda.is_current_stream_capturing())
+    return ok, task
+
+
+def wgrad_pgemm(a_src, x_srcs, B, H, W, taps, Cout, spec, dev, w_param, b_param, w_shape, G=1, want_bias=True, keep=(), window=None):
+    """Weight (+ bias) gradient through the pixel-reduction GEMM + its slab reduction, with reduce_wgrad's conventions.  Uses of one
+    sink parameter inside a window are queued and merged like wgrad_wino's: the merged launch reads its operands through
+    per-image pointer tables (bmc_src_t BMC_SRC_TABLE; bmc_ptr_table)."""
+    if G == 1:
+        ok, task = _mergeable(B, H, W, w_param, b_param, want_bias, keep, window)
+        if ok and all(x.batch_mod != -1 for x in x_srcs) and a_src.batch_mod != -1:
+            key = (id(w_param), "pg", taps, len(x_srcs), H, W, bool(want_bias))
+            _queue_use(key, lambda: _MergeQueue(spec, dev, w_param, b_param, want_bias, None, spec.covers_all, H, W, window,
+                                                pg=(taps, Cout, w_shape)),
+                       (a_src, list(x_srcs), B, tuple(keep), w_param, window), task, B * H * W)
+            return None, None
+    with wgrad_side(B * H * W, _flat_params(w_param, b_param if want_bias else None), keep):
+        r = pgemm_raw(a_src, x_srcs, B, H, W, taps, B // G, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.kreal,
+                      want_bias=want_bias)
+        return reduce_wgrad(r[0], r[1], G, taps, Cout, spec, dev, r[3] if want_bias else None, w_param,
+                            b_param if want_bias else None, w_shape)
 
 
 def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias=True, k0=None, full=None, keep=(), window=None):
@@ -673,27 +748,13 @@ def wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want
     into a leaf parameter's .grad.  k0 / full: the launch covers only the weight columns [k0, k0 + 128) of a wider convolution
     (one 128-channel source of a multi-source launch: split_wgrad_ok).  window: the recurrent window the use belongs to
     (current_window() at its forward) -- uses are merged within one window; None: not merged."""
-    task = torch._C._current_graph_task_id()
-    if task >= 0 and _MERGE and _MERGE_OWNER[0] != task:
-        _MERGE.clear()                   # uses queued by a backward pass that raised (a pass that ends flushes its own): dropped
-    if (WGRAD_MERGE > 1 and window is not None and B * H * W <= WGRAD_MERGE_MAX_PIXELS and task >= 0 and w_param is not None and is_sink(w_param) and (not want_bias or is_sink(b_param))
-            and keep and not wgrad_wino4_ok(B, H, W) and not torch.cuda.is_current_stream_capturing()):
+    ok, task = _mergeable(B, H, W, w_param, b_param, want_bias, keep, window)
+    if ok and not wgrad_wino4_ok(B, H, W):
         k0_ = spec.kmap_host[0] if k0 is None else k0
         key = (id(w_param), k0_, H, W, bool(want_bias))
-        q = _MERGE.get(key)
-        if q is None or q.w_param is not w_param or q.window != window:       # (another window's uses: the old queue leaves first)
-            if q is not None and q.items:
-                _launch_merged(q)
-            q = _MERGE[key] = _MergeQueue(spec, dev, w_param, b_param, want_bias, k0_, spec.covers_all if full is None else full, H, W,
-                                          window)
-        if _MERGE_TASK[0] != task:       # the first queued use of this backward pass: flush what is left when the pass ends
-            _MERGE_TASK[0] = task
-            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
-        _side_arm(B * H * W)             # (the pass's side-stream decision is made by its first USE, as without the queue)
-        _MERGE_OWNER[0] = task
-        q.items.append((a_src, x_src, B, tuple(keep)))
-        if len(q.items) >= WGRAD_MERGE:
-            _launch_merged(q)
+        _queue_use(key, lambda: _MergeQueue(spec, dev, w_param, b_param, want_bias, k0_, spec.covers_all if full is None else full, H, W,
+                                            window),
+                   (a_src, x_src, B, tuple(keep), w_param, window), task, B * H * W)
         return None, None
     with (wgrad_side(B * H * W, [w_param, b_param] if want_bias else [w_param], keep) if w_param is not None else _NOCTX):
         return _wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_shape, want_bias, k0, full)
@@ -1380,10 +1441,7 @@ def _wgrad_plain(g, x, spec, w_param, b_param, taps, window=None):
     a_src, x_src = _src(g, 0, Cout, 0, None, 0, B), _src(x, 0, x.shape[3], 0, None, 0, B)
     if wino_wgrad_ok(a_src, [x_src], spec, taps, Cout, 1):
         return wgrad_wino(a_src, x_src, B, H, W, spec, dev, w_param, b_param, w_param.shape, keep=(g, x), window=window)
-    with wgrad_side(B * H * W, [w_param, b_param], (g, x)):
-        slabs, nsplit, _, bsl = pgemm_raw(a_src, [x_src], B, H, W, taps,
-                                          B, Cout, spec.kpad, dev, flops=2.0 * B * H * W * Cout * taps * spec.kreal, want_bias=True)
-        return reduce_wgrad(slabs, nsplit, 1, taps, Cout, spec, dev, bsl, w_param, b_param, w_param.shape)
+    return wgrad_pgemm(a_src, [x_src], B, H, W, taps, Cout, spec, dev, w_param, b_param, w_param.shape, keep=(g, x), window=window)
 
 
 class GradPair:

@@ -57,11 +57,23 @@ static_assert(sizeof(SrcDev) == 32 && alignof(SrcDev) == 8, "SrcDev must stay 32
 static inline SrcDev to_dev(const bmc_src_t& s) {
     SrcDev d;
     d.ptr = s.ptr; d.batch_stride = s.batch_stride; d.pix_stride = s.pix_stride; d.nch = s.nch;
-    d.batch_shift = s.batch_shift; d.batch_mod = s.batch_mod < 1 ? 1 : s.batch_mod;
+    d.batch_shift = s.batch_shift; d.batch_mod = s.batch_mod == BMC_SRC_TABLE ? BMC_SRC_TABLE : (s.batch_mod < 1 ? 1 : s.batch_mod);
     return d;
 }
 __device__ __forceinline__ const float* src_batch_ptr(const SrcDev& s, int b) {
     int bs = b + s.batch_shift;
     if (s.batch_mod > 0) bs %= s.batch_mod;
     return s.ptr + (long long)bs * s.batch_stride;
+}
+// The same for the kernels that accept BMC_SRC_TABLE operands (the pixel-reduction GEMMs: pgemm.hip, pgemm_bf.hip).
+__device__ __forceinline__ const float* src_batch_ptr_tab(const SrcDev& s, int b) {
+    if (s.batch_mod == BMC_SRC_TABLE) {    // ptr = device table of per-image base pointers (bmc_ptr_table): operands gathered from several tensors
+        // (b is wave-uniform at every call site -- a workgroup works on one image at a time -- and the callers hand the result
+        //  to scalar-base memory instructions: made uniform explicitly)
+        const unsigned long long v = *(const __attribute__((address_space(1))) unsigned long long*)(
+            reinterpret_cast<unsigned long long>(s.ptr) + 8ull * (unsigned)b);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    }
+    return src_batch_ptr(s, b);
 }

@@ -117,11 +117,11 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
             if (nx_tx >= a.tiles_x) { nx_tx -= a.tiles_x; ++nx_ty; }
             if (nx_ty >= a.tiles_y) { nx_ty -= a.tiles_y; ++nx_bb; }
         } else if (nx_tx >= a.tiles_per_img) { nx_tx -= a.tiles_per_img; ++nx_bb; }
-        const float* ab = src_batch_ptr(a.a, b);
+        const float* ab = src_batch_ptr_tab(a.a, b);
         const bool interior = TAPS == 9 ? (y0 >= 1 && x0 >= 1 && y0 + PT_H + 1 <= a.H && x0 + PT_W + 1 <= a.W) : (p0 + PT <= HWp);
         if (interior && all_ch) {
             const float* const abt = ab + (TAPS == 9 ? (long long)y0 * a.W + x0 : (long long)p0) * a.a.pix_stride;
-            const float* const xbt = src_batch_ptr(xs, b) +
+            const float* const xbt = src_batch_ptr_tab(xs, b) +
                                      (TAPS == 9 ? (long long)(y0 - 1) * a.W + (x0 - 1) : (long long)p0) * xs.pix_stride;
 #pragma unroll
             for (int i = 0; i < 4; ++i) dma(abt, (unsigned)a_off[i], lds + buf * BUF + (i * 512 + wave * 64) * 4);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
                 for (int si = 1; si < BMC_MAX_SRC; ++si)
                     if (s_i == si - 1 && ch >= tab[si - 1].nch && si < a.nsrc) { ch -= tab[si - 1].nch; s_i = si; }
                 const SrcDev S = tab[s_i];
-                src = src_batch_ptr(S, b) + pix * S.pix_stride + ch;
+                src = src_batch_ptr_tab(S, b) + pix * S.pix_stride + ch;
             }
             dma16v(src, (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + (2 + buf) * BUF + (i * 512 + wave * 64) * 4));
         }

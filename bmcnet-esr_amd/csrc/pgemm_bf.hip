@@ -121,11 +121,11 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
         int y0 = 0, x0 = 0, p0 = 0;
         if (TAPS == 9) { y0 = (tin / a.tiles_x) * PT_H; x0 = (tin % a.tiles_x) * PT_W; }
         else p0 = tin * PT;
-        const float* ab = src_batch_ptr(a.a, b);
+        const float* ab = src_batch_ptr_tab(a.a, b);
         const bool interior = TAPS == 9 ? (y0 >= 1 && x0 >= 1 && y0 + PT_H + 1 <= a.H && x0 + PT_W + 1 <= a.W) : (p0 + PT <= HWp);
         if (interior && all_ch) {
             const char* const abt = uniform_ptr(ab + (TAPS == 9 ? (long long)y0 * a.W + x0 : (long long)p0) * a.a.pix_stride);
-            const char* const xbt = uniform_ptr(src_batch_ptr(xs, b) +
+            const char* const xbt = uniform_ptr(src_batch_ptr_tab(xs, b) +
                                                 (TAPS == 9 ? (long long)(y0 - 1) * a.W + (x0 - 1) : (long long)p0) * xs.pix_stride);
 #pragma unroll
             for (int i = 0; i < NAL; ++i) ar[slot][i] = ldg16(abt + fa_off[i]);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
 #pragma unroll
             for (int si = 1; si < BMC_MAX_SRC; ++si)
                 if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; }
-            const float* src = ok ? src_batch_ptr(S, b) + pix * S.pix_stride + ch : a.zeros;
+            const float* src = ok ? src_batch_ptr_tab(S, b) + pix * S.pix_stride + ch : a.zeros;
             xr[slot][i] = ldg16(src);
         }
     };
@@ -392,10 +392,10 @@ __global__ __launch_bounds__(768, 1) void pgemm_bf9x3_kernel(const PgemmK a) {
             if (nx_ty >= a.tiles_y) { nx_ty -= a.tiles_y; ++nx_bb; }
             const bool interior = t.y0 >= 1 && t.x0 >= 1 && t.y0 + PT_H + 1 <= a.H && t.x0 + PT_W + 1 <= a.W;   // halo inside the image
             t.fast = t.live && interior && all_ch;
-            t.ab = src_batch_ptr(a.a, b) + ((long long)t.y0 * a.W + t.x0) * a.a.pix_stride;
+            t.ab = src_batch_ptr_tab(a.a, b) + ((long long)t.y0 * a.W + t.x0) * a.a.pix_stride;
 #pragma unroll
             for (int si = 0; si < BMC_MAX_SRC; ++si)
-                t.xb[si] = src_batch_ptr(a.src[si], b) + ((long long)(t.y0 - 1) * a.W + (t.x0 - 1)) * a.src[si].pix_stride;
+                t.xb[si] = src_batch_ptr_tab(a.src[si], b) + ((long long)(t.y0 - 1) * a.W + (t.x0 - 1)) * a.src[si].pix_stride;
             return t;
         };
         // Loads are inline asm, waited for by hand (the compiler cannot count vmcnt across this loop).  Hazard of the

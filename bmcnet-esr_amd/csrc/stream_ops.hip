@@ -560,3 +560,22 @@ extern "C" int bmc_pack_weight_t(const float* w, const int* kmap, int G, int Cou
     BMC_CHECK_LAUNCH("bmc_pack_weight_t");
     return 0;
 }
+
+// ---- per-image pointer tables (bmc_src_t, BMC_SRC_TABLE)
+namespace {
+struct PtrTab { unsigned long long p[256]; };
+__global__ void ptr_table_kernel(const PtrTab t, int n, unsigned long long* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = t.p[i];
+}
+}  // namespace
+
+extern "C" int bmc_ptr_table(const unsigned long long* ptrs, int n, unsigned long long* table, bmc_stream_t s) {
+    BMC_CHECK_ARG(ptrs && table && n >= 1 && n <= 256, "bmc_ptr_table: 1 .. 256 pointers");
+    PtrTab t;
+    for (int i = 0; i < n; ++i) t.p[i] = ptrs[i];
+    for (int i = n; i < 256; ++i) t.p[i] = 0;
+    hipLaunchKernelGGL(ptr_table_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, t, n, table);
+    BMC_CHECK_LAUNCH("bmc_ptr_table");
+    return 0;
+}

@@ -41,8 +41,13 @@ typedef struct bmc_src {
     int pix_stride;         /* floats */
     int nch;                /* channels consumed from ptr, multiple of 16 */
     int batch_shift;
-    int batch_mod;          /* >= 1 */
+    int batch_mod;          /* >= 1, or BMC_SRC_TABLE: `ptr` is a device table of per-image base pointers (bmc_ptr_table) */
 } bmc_src_t;
+/* batch_mod == BMC_SRC_TABLE: image b of the launch starts at ((const float* const*)ptr)[b] -- the images of one operand gathered
+ * from several tensors (the uses of ONE weight by the weight-sharing blocks of a window reduced by one weight-gradient launch,
+ * models/BMCNet.py:19-32); pix_stride / nch as usual, batch_stride / batch_shift unused. */
+#define BMC_SRC_TABLE (-1)
+
 
 /* ---- library ---- */
 int bmc_version(void);
@@ -285,6 +290,10 @@ int bmc_wgrad_wino4(const bmc_src_t* dy, const bmc_src_t* x, int B, int H, int W
                     bmc_stream_t s);
 int bmc_wgrad_wino4_reduce(const float* part, int nsplit, float* dw, int ldw, int k0, int accumulate, const float* bias_part,
                            float* db, bmc_stream_t s);
+
+/* table[i] = ptrs[i], i < n <= 256: a device table of per-image base pointers for bmc_src_t's BMC_SRC_TABLE mode, written by a
+ * kernel on stream s (the pointers travel in its argument block: no host buffer has to outlive the call). */
+int bmc_ptr_table(const unsigned long long* ptrs, int n, unsigned long long* table, bmc_stream_t s);
 
 /* ---- streaming kernels ---------------------------------------------------*/
 /* out[i] = sum_{k < groups} in[k*n + i] (fixed order): gradient of an operand shared by several batch groups of a launch */
