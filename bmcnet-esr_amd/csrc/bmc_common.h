@@ -68,12 +68,16 @@ __device__ __forceinline__ const float* src_batch_ptr(const SrcDev& s, int b) {
 // The same for the kernels that accept BMC_SRC_TABLE operands (the pixel-reduction GEMMs: pgemm.hip, pgemm_bf.hip).
 __device__ __forceinline__ const float* src_batch_ptr_tab(const SrcDev& s, int b) {
     if (s.batch_mod == BMC_SRC_TABLE) {    // ptr = device table of per-image base pointers (bmc_ptr_table): operands gathered from several tensors
-        // (b is wave-uniform at every call site -- a workgroup works on one image at a time -- and the callers hand the result
-        //  to scalar-base memory instructions: made uniform explicitly)
+        // (the descriptor may differ from lane to lane -- lanes of one wave read columns of different sources: no readfirstlane here)
         const unsigned long long v = *(const __attribute__((address_space(1))) unsigned long long*)(
             reinterpret_cast<unsigned long long>(s.ptr) + 8ull * (unsigned)b);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+        return reinterpret_cast<const float*>(v);
     }
     return src_batch_ptr(s, b);
+}
+// ... where descriptor and image are wave-uniform and the result feeds a scalar-base memory instruction
+__device__ __forceinline__ const float* src_batch_ptr_tab_uni(const SrcDev& s, int b) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(src_batch_ptr_tab(s, b));
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
 }

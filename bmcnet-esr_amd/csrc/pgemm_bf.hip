@@ -392,10 +392,10 @@ __global__ __launch_bounds__(768, 1) void pgemm_bf9x3_kernel(const PgemmK a) {
             if (nx_ty >= a.tiles_y) { nx_ty -= a.tiles_y; ++nx_bb; }
             const bool interior = t.y0 >= 1 && t.x0 >= 1 && t.y0 + PT_H + 1 <= a.H && t.x0 + PT_W + 1 <= a.W;   // halo inside the image
             t.fast = t.live && interior && all_ch;
-            t.ab = src_batch_ptr_tab(a.a, b) + ((long long)t.y0 * a.W + t.x0) * a.a.pix_stride;
+            t.ab = src_batch_ptr_tab_uni(a.a, b) + ((long long)t.y0 * a.W + t.x0) * a.a.pix_stride;
 #pragma unroll
             for (int si = 0; si < BMC_MAX_SRC; ++si)
-                t.xb[si] = src_batch_ptr_tab(a.src[si], b) + ((long long)(t.y0 - 1) * a.W + (t.x0 - 1)) * a.src[si].pix_stride;
+                t.xb[si] = src_batch_ptr_tab_uni(a.src[si], b) + ((long long)(t.y0 - 1) * a.W + (t.x0 - 1)) * a.src[si].pix_stride;
             return t;
         };
         // Loads are inline asm, waited for by hand (the compiler cannot count vmcnt across this loop).  Hazard of the
