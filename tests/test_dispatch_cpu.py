@@ -1,0 +1,70 @@
+"""CPU checks of the host-side dispatch logic added in round 5 (no kernel runs): the exact-zero routing rule of ops.wino_ok and
+the hook bookkeeping of the sink route."""
+import gc
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "bmcnet-esr_amd"))
+
+
+def test_wino_ok_forward_launches_follow_the_exact_zero_rule():
+    """F(4x4) for a forward 3x3 launch only with a dense bias or inside dense_inputs(); exact_zero_inputs() overrides both; data
+    gradients (fwd=False) are never affected.  A bias whose flags cannot be evaluated (here: a CPU tensor) reads as not dense."""
+    from bmc_hip import ops
+    B, H, W, C = 8, 180, 240, 128
+    assert ops.wino_ok(B, H, W, C, 9) == 4                                  # data gradient
+    assert ops.wino_ok(B, H, W, C, 9, fwd=True) == 2                        # forward, no bias known
+    assert ops.wino_ok(B, H, W, C, 9, fwd=True, rule=torch.ones(C)) == 2    # flags unknown -> the exact kernel
+    with ops.dense_inputs():
+        assert ops.wino_ok(B, H, W, C, 9, fwd=True) == 4
+        with ops.exact_zero_inputs():
+            assert ops.wino_ok(B, H, W, C, 9, fwd=True) == 2
+            assert ops.wino_ok(B, H, W, C, 9) == 4
+    assert ops.wino_ok(B, H, W, C, 9, fwd=True) == 2
+    # a known-dense bias (cache entry as prime_bias_dense would write it)
+    b = torch.full((C,), 0.01)
+    import weakref
+    ops._DENSE[id(b)] = (weakref.ref(b), b._version, 0.01, 0.01)
+    assert ops.bias_dense(b) and ops.bias_positive(b) and ops.wino_ok(B, H, W, C, 9, fwd=True, rule=b) == 4
+    assert not ops.bias_dense((b, None)) and not ops.bias_dense(None)
+    b.add_(1.0)                                                               # version bump: the entry is stale
+    assert not ops.bias_dense(b)
+    # sizes / strides
+    assert ops.wino_ok(1, 45, 80, C, 9) == 0 or ops.wino_ok(1, 45, 80, C, 9) == 2
+    assert ops.wino_ok(B, H, W, C, 9, stride=1 << 14) == 0                    # offsets beyond 32 bits: direct kernel
+    assert ops.wino_ok(B, H, W, 32, 9) == 0 and ops.wino_ok(B, H, W, C, 1) == 0
+
+
+def test_sink_route_recognises_reducer_hooks_by_id():
+    """is_sink must know WHOSE hook sits on a parameter.  A reducer's own hooks are fine; a foreign hook, a second
+    reducer that was detached, or the hook that takes the place of a reducer dropped without detach() are not."""
+    from bmc_hip import ops
+    from bmc_hip.parallel import GradAllReducer
+    net = torch.nn.Linear(4, 4)
+    p = net.weight
+    assert ops.is_sink(p)
+    red = GradAllReducer(net)
+    assert ops.is_sink(p) and len(p._bmc_sink_hooks) == 1
+    red2 = GradAllReducer(net)                       # two reducers on one model: both known
+    assert ops.is_sink(p) and len(p._bmc_sink_hooks) == 2
+    red2.detach()
+    assert ops.is_sink(p) and len(p._bmc_sink_hooks) == 1
+    h = p.register_post_accumulate_grad_hook(lambda t: None)
+    assert not ops.is_sink(p)                        # a foreign hook beside the reducer's
+    h.remove()
+    assert ops.is_sink(p)
+    red.detach()
+    assert ops.is_sink(p) and not p._bmc_sink_hooks
+    # a reducer that is dropped without detach(): its ids no longer vouch for anything
+    red3 = GradAllReducer(net)
+    ids = set(p._bmc_sink_hooks)
+    for hd in red3._handles:
+        hd.remove()
+    del red3
+    gc.collect()
+    assert not (ids & p._bmc_sink_hooks)
+    p.register_post_accumulate_grad_hook(lambda t: None)
+    assert not ops.is_sink(p)
