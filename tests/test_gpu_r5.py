@@ -41,7 +41,7 @@ def test_sparse_recording_bias_gradients_vs_oracle(bias_mode):
     zero: biases exactly zero as `initialize_weights` leaves them (models/submodules.py:183-201): where a pixel's receptive field
           holds nothing, the reference gives exactly 0 at EVERY depth of the network (nothing densifies a zero pixel of zero-bias
           convolutions, LayerNorm2d and per-pixel attention), relu'(0) = 0 gates the gradient, and a kernel that returns +-1e-8 there
-          flips those gates.  The dispatch must keep such launches on kernels that are exact on empty fields (ops.bias_is_dense).
+          flips those gates.  The dispatch must keep such launches on kernels that are exact on empty fields (ops.bias_dense, ops.dense_inputs).
     trained: every bias moved off zero (what one optimizer step does): no pre-activation is exactly zero, the F(4x4) kernel
           serves every launch -- the routing rule may not cost the trained network its fast path."""
     dev = _gpu()
