@@ -73,21 +73,29 @@ def test_sparse_recording_bias_gradients_vs_oracle(bias_mode):
     loss_ref.backward()
     m.to(dev)
     z = lambda c: torch.zeros(B, c, H, W, device=dev)
-    st = (z(n_c), z(n_c), z(n_c), z(2 * scale * scale))
-    ops.PROFILE, ops.PROFILE_WINO[:] = [], [0, 0]
-    loss = 0
-    try:
-        for i in range(NW):
-            st = m(xs[i].to(dev), *st, i == 0)
-            within(rel_l2(st[-1], preds_ref[i]), 1e-5, CONTRACT_SR, "sparse recording (%s biases), SR of window %d" % (bias_mode, i))
-            loss = loss + F.mse_loss(st[-1], gts[:, i + 1].to(dev))
-        loss.backward()
-        torch.cuda.synchronize()
-        kinds = {}
-        for r in ops.PROFILE:
-            kinds[r[0]] = kinds.get(r[0], 0) + 1
-    finally:
-        ops.PROFILE = None
+
+    def hip_pass(check_sr):
+        for p in m.parameters():
+            p.grad = None
+        st = (z(n_c), z(n_c), z(n_c), z(2 * scale * scale))
+        ops.PROFILE, ops.PROFILE_WINO[:] = [], [0, 0]
+        loss = 0
+        try:
+            for i in range(NW):
+                st = m(xs[i].to(dev), *st, i == 0)
+                if check_sr:
+                    within(rel_l2(st[-1], preds_ref[i]), 1e-5, CONTRACT_SR, "sparse recording (%s biases), SR of window %d" % (bias_mode, i))
+                loss = loss + F.mse_loss(st[-1], gts[:, i + 1].to(dev))
+            loss.backward()
+            torch.cuda.synchronize()
+            kinds = {}
+            for r in ops.PROFILE:
+                kinds[r[0]] = kinds.get(r[0], 0) + 1
+        finally:
+            ops.PROFILE = None
+        return loss, kinds
+
+    loss, kinds = hip_pass(True)
     print("launches: %s" % {k: v for k, v in kinds.items() if "conv" in k and "9" in k})
     within(abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()), 5e-6, 1e-5, "sparse recording, loss")
     errs = {n: rel_l2(p.grad, params[n].grad) for n, p in m.named_parameters() if params[n].grad is not None}
@@ -105,6 +113,21 @@ def test_sparse_recording_bias_gradients_vs_oracle(bias_mode):
             assert kinds.get("wino4_conv<9,128>", 0) > 3 * kinds.get("wino_conv<9,128>", 0)   # ... and the forward launches too
         else:
             assert kinds.get("wino_conv<9,128>", 0) > kinds.get("wino4_conv<9,128>", 0)       # zero biases: forward on F(2x2)
+            # the control: the same pass with the rule switched off (a floor of -1 calls every bias dense, every forward launch goes
+            # to F(4x4)) must FAIL this test's bar on the bias gradients -- the recording and the bar do exercise the hazard
+            floor = ops.DENSE_FLOOR
+            ops.DENSE_FLOOR = -1.0
+            ops._DENSE.clear()
+            try:
+                _, ckinds = hip_pass(False)
+                cerr = max(rel_l2(p.grad, params[n].grad) for n, p in m.named_parameters() if n.endswith("bias") and params[n].grad is not None)
+            finally:
+                ops.DENSE_FLOOR = floor
+                ops._DENSE.clear()
+            print("control, rule off (%d F(4x4) / %d F(2x2) launches): worst bias gradient %.1e" % (
+                ckinds.get("wino4_conv<9,128>", 0), ckinds.get("wino_conv<9,128>", 0), cerr))
+            assert ckinds.get("wino4_conv<9,128>", 0) > kinds.get("wino4_conv<9,128>", 0)
+            assert cerr > 1e-2 > 20 * worst_b[0][1]
 
 
 # ------------------------------------------------------------------ side stream after a backward pass that raised
@@ -378,72 +401,3 @@ def test_dispatch_thresholds_both_sides_meet_the_oracle(name, below, above):
         n0 = sum(v for k, v in k0.items() if "conv" in k and "9" in k)
         n1 = sum(v for k, v in k1.items() if "conv" in k and "9" in k)
         assert n0 < n1, (k0, k1)
-
-
-# ------------------------------------------------------------------ the own-bias half of the exact-zero rule, where it still decides
-def test_own_bias_rule_decides_the_input_fusion_launches():
-    """Inside a window the model proves dense inputs and the bias of a launch is irrelevant; the input-fusion convolutions read raw
-    event counts and (first window) a zero state, so THEIR kernel is decided by their own bias: one element within DENSE_FLOOR of
-    zero (a bias crossing zero in early training: 27 of 27 vectors did after step 4 of the bench) sends the launch to a kernel that
-    is exact on empty receptive fields.  Sparse recording, one window at 180x240, every other bias dense; the gradient of that
-    bias against the CPU oracle -- and, as the control, the same with the floor at 0 (F(4x4) on the launch): the gate of the
-    near-zero channel on the empty pixels becomes a coin flip and its gradient is wrong."""
-    dev = _gpu()
-    from bmc_hip import ops
-    from models.BMCNet import BMCNet
-    from oracle import bmc_oracle as O
-    ops.set_math("fp32")
-    scale, n_c, n_b, B, H, W = 4, 128, 1, 1, 180, 240
-    CH = 7
-
-    def build():
-        torch.manual_seed(531)
-        m = BMCNet(scale, n_c, n_b)
-        scaled_init(m, 2.0)
-        gb = torch.Generator().manual_seed(532)
-        with torch.no_grad():
-            for n, p in m.named_parameters():
-                if n.endswith("bias") and p.dim() == 1:
-                    p.add_((torch.rand(p.shape, generator=gb) - 0.5) * 2e-2)
-                    p[p.abs() < 1e-3] = 2e-3
-            m.neuro.conv_fps.bias[CH] = 3e-6          # positive, inside the floor: the reference's gate on empty fields is OPEN
-        return m
-
-    m = build()
-    params = oracle_params(m)
-    g = torch.Generator().manual_seed(533)
-    frames = sparse_frames(B, 2, H, W, g)
-    gts = sparse_frames(B, 2, scale * H, scale * W, g, rate=0.06 / 4)
-    x = frames[:, 0:2].transpose(1, 2)
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    loss_ref, _, _ = O.bptt_loss(params, [x], [gts[:, 1]], n_c, scale)
-    loss_ref.backward()
-    ref = params["neuro.conv_fps.bias"].grad
-
-    def run(floor):
-        old = ops.DENSE_FLOOR
-        ops.DENSE_FLOOR = floor
-        ops._DENSE.clear()
-        try:
-            mm = build().to(dev)
-            z = lambda c: torch.zeros(B, c, H, W, device=dev)
-            ops.PROFILE = []
-            out = mm(x.to(dev), z(n_c), z(n_c), z(n_c), z(2 * scale * scale), True)
-            F.mse_loss(out[-1], gts[:, 1].to(dev)).backward()
-            torch.cuda.synchronize()
-            n2 = sum(1 for r in ops.PROFILE if r[0] == "wino_conv<9,128>")
-            gb = mm.neuro.conv_fps.bias.grad.cpu()
-            return n2, rel_l2(gb, ref), abs(float(gb[CH] - ref[CH])) / max(abs(float(ref[CH])), 1e-30)
-        finally:
-            ops.PROFILE = None
-            ops.DENSE_FLOOR = old
-            ops._DENSE.clear()
-
-    n2, e_all, e_ch = run(ops.DENSE_FLOOR)
-    n2c, c_all, c_ch = run(0.0)
-    print("conv_fps.bias gradient vs the oracle: rule on: %d F(2x2) launches, whole vector %.1e, channel %d %.1e | floor 0 (F(4x4) on "
-          "the launch): %d F(2x2) launches, whole vector %.1e, channel %d %.1e" % (n2, e_all, CH, e_ch, n2c, c_all, CH, c_ch))
-    assert n2 >= 1 and n2c == 0
-    within(e_all, 3e-4, CONTRACT_GRAD, "own-bias rule, conv_fps.bias gradient")
-    assert e_ch < 1e-3
-    assert c_ch > 10 * max(e_ch, 1e-5)          # the control has teeth: without the rule that channel's gradient is off
