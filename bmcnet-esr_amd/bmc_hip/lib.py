@@ -108,6 +108,7 @@ _ww = _sig("bmc_wgrad_wino", [C.POINTER(Src), C.POINTER(Src), _i, _i, _i, _i, _p
 _ww_red = _sig("bmc_wgrad_wino_reduce", [_p, _i, _p, _i, _i, _i, _p, _p, _p])
 _ww_multi = _sig("bmc_wgrad_wino_multi", [C.POINTER(Src), C.POINTER(Src), C.POINTER(C.c_int), _i, _i, _i, _i, _p, _p, _p])
 _ptr_table = _sig("bmc_ptr_table", [C.POINTER(C.c_ulonglong), _i, _p, _p])
+_wino_rows = _sig("bmc_conv_wino_rows", [_i, _i, _i, _i, _i])
 _ww4_nsplit = _sig("bmc_wgrad_wino4_nsplit", [_i, _i, _i])
 _ww4 = _sig("bmc_wgrad_wino4", [C.POINTER(Src), C.POINTER(Src), _i, _i, _i, _i, _p, _p, _p])
 _ww4_red = _sig("bmc_wgrad_wino4_reduce", [_p, _i, _p, _i, _i, _i, _p, _p, _p])
@@ -145,7 +146,8 @@ EXPORTS = ["bmc_version", "bmc_last_error", "bmc_events_to_channels", "bmc_event
            "bmc_encode_raw_events_binned", "bmc_pack_weight_wino", "bmc_pack_weight_wino4", "bmc_wgrad_wino_nsplit", "bmc_wgrad_wino",
            "bmc_wgrad_wino_reduce", "bmc_events_torch_ws_ints", "bmc_events_to_image_torch",
            "bmc_events_to_voxel_torch", "bmc_stream_create_low_priority", "bmc_small_mm",
-           "bmc_wgrad_wino4_nsplit", "bmc_wgrad_wino4", "bmc_wgrad_wino4_reduce", "bmc_wgrad_wino_multi", "bmc_ptr_table"]
+           "bmc_wgrad_wino4_nsplit", "bmc_wgrad_wino4", "bmc_wgrad_wino4_reduce", "bmc_wgrad_wino_multi", "bmc_ptr_table",
+           "bmc_conv_wino_rows"]
 
 
 def check(rc, what):

@@ -366,6 +366,20 @@ def bias_positive(b):
     return hit is not None and hit[3] >= DENSE_FLOOR
 
 
+_WINO_ROWS = {}
+WINO_MIN_TILES4 = int(os.environ.get("BMC_WINO_MIN_TILES4", 128))   # the same for launches the 4-row tiling takes (a 4-row workgroup: 30 us at 128 channels; the direct kernel's 64-channel tiling of such a launch: 44)
+
+
+def wino_tiles(B, H, W, cp):
+    """-> (workgroup tiles of an F(2x2) launch, rows per tile): 8 x 16 pixels x 128 channels, or 4 x 16 where the launcher picks its
+    4-row kernel (csrc/wino.hip::wino_rows: launches that would leave CUs without a tile -- small frames)."""
+    key = (B, H, W, cp)
+    th = _WINO_ROWS.get(key)
+    if th is None:
+        th = _WINO_ROWS[key] = lib._wino_rows(B, H, W, cp, 0)
+    return B * ((H + th - 1) // th) * ((W + 15) // 16) * (cp // 128), th
+
+
 def wino_ok(B, H, W, Cout, taps, fwd=False, stride=0, rule=None):
     """Which kernel takes a launch of this geometry?  0: the direct kernel, 2: Winograd F(2x2, 3x3), 4: F(4x4, 3x3).
     (Decided ONCE per launch by the caller and handed to the weight pack and to conv_raw alike: the packed layouts are not
@@ -376,7 +390,10 @@ def wino_ok(B, H, W, Cout, taps, fwd=False, stride=0, rule=None):
     if not WINO or MATH != 0 or taps != 9:
         return 0
     cp = coutpad(Cout)
-    if cp % 128 or B * ((H + 7) // 8) * ((W + 15) // 16) * (cp // 128) < WINO_MIN_TILES:
+    if cp % 128:
+        return 0
+    nt, th = wino_tiles(B, H, W, cp)
+    if nt < (WINO_MIN_TILES if th == 8 else min(WINO_MIN_TILES, WINO_MIN_TILES4)):
         return 0
     if H * W * 4 * max(stride, 512) >= 2 ** 31:      # 32-bit per-lane DMA offsets in both Winograd kernels: direct kernel
         return 0

@@ -29,10 +29,11 @@ namespace {
 
 constexpr int CK = BMC_CK;
 constexpr int RS = 20;                  // floats per halo pixel in LDS (16 + 4 pad)
-constexpr int TH = 8, TW = 16;          // output pixels per workgroup tile
-constexpr int HHT = TH + 2, HWD = TW + 2;
+constexpr int TW = 16;                  // output pixel columns per workgroup tile; rows: the kernel's TH (8, or 4 for launches that
+                                        // would leave CUs without a tile: small frames)
+constexpr int HWD = TW + 2;
 constexpr int XROW = (HWD * RS + 63) / 64 * 64;      // halo row stride (as conv.hip: rows start on a 256-byte boundary)
-constexpr int XBUFA = 4096;              // floats per X buffer as allocated: 16 DMA instructions x 64 lanes x 4 floats >= XBUF
+constexpr int XBUFA = 4096;              // floats per X buffer as allocated: 16 DMA instructions x 64 lanes x 4 floats >= 10 rows x XROW
 constexpr int BN = 128;                 // output channels per workgroup tile
 constexpr int WSTAGE = 4 * BN * CK;     // floats per weight stage: 4 positions (nu) x 128 rows x 16 channels
 constexpr int NWR = 3, DW = 2;          // weight ring: stages, stages ahead
@@ -89,7 +90,12 @@ __device__ __forceinline__ void dma4k(const void* gbase, unsigned lane_off, unsi
 //   * every thread produces ONE quad of the next stage's V (tile tid & 31, channel quad (tid >> 5) & 3, position
 //     nu = tid >> 7): its position needs two patch columns only -- 4 reads, 12 adds, 1 store;
 //   * LDS, rings, DMA, barriers per stage: as above (8 waves share the copies: 4 KB of a weight stage, 2 halo instructions each).
+//   * TH = 4 (one 16-tile column block per wave, 64 accumulators): half the pixels per workgroup for launches with fewer 8 x 16
+//     tiles than CUs -- the same stage loop, weight ring and halo image (rows 6-9 of the image and tiles 16-31 of V are produced and
+//     never read), so a workgroup's serial time is what shrinks: at 31x56 an 8-image launch is 128 tiles of 8 x 16 or 256 of 4 x 16.
+template <int TH>
 __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
+    constexpr int HHT = TH + 2, NTB = TH / 4;
     __shared__ __attribute__((aligned(16))) float lds[2 * XBUFA + NWR * WSTAGE + 2 * VSTAGE + BMC_MAX_SRC * 8 + BN];
     float* const Xb = lds;
     float* const Wb = lds + 2 * XBUFA;
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     const int woff = (16 * wave + lj) * CK + qsw;                            // + nu * BN * CK
     const int voff = lj * CK + qsw;                                          // + nu * 32 * CK + tb * 16 * CK
 
-    f32x4 acc[16][2];
+    f32x4 acc[16][NTB];
     auto init_acc = [&]() {
         // (the lane's quad index is re-derived here, once per tile, from v_mbcnt: kept live across the stage loop the address was
         //  the one value the register allocator spilled, and its reload -- a scratch load -- waited, in order, for every DMA
@@ -260,13 +266,13 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
 #pragma unroll
         for (int p = 0; p < 16; ++p)
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) acc[p][tb] = p == 5 ? bq : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tb = 0; tb < NTB; ++tb) acc[p][tb] = p == 5 ? bq : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto pin_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 16; ++p)
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) asm volatile("" : "+a"(acc[p][tb]));
+            for (int tb = 0; tb < NTB; ++tb) asm volatile("" : "+a"(acc[p][tb]));
     };
 
     auto produce_load = [&](const float* xb, int xi, f32x4 (&d)[4]) __attribute__((always_inline)) {
@@ -297,32 +303,34 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     // stage's barrier -- so no MFMA ever waits for an LDS round trip that starts at a barrier, which is where all eight
     // waves of the workgroup would otherwise stall together (two waves per SIMD only cover each other when they are not in
     // lockstep).  The production of the next stage's V (4 reads, 12 adds, 1 store per thread) rides in the first half.
-    f32x4 ufA[2], vfA[2][2];
+    f32x4 ufA[2], vfA[2][NTB];
     auto load_first = [&](const float* vb, const float* wb) __attribute__((always_inline)) {
 #pragma unroll
         for (int nu = 0; nu < 2; ++nu) {
             if (BMC_WINO_ABL & 32) {
-                ufA[nu] = f32x4{1.f, 2.f, 3.f, 4.f}; vfA[nu][0] = vfA[nu][1] = f32x4{4.f, 3.f, 2.f, 1.f};
-                asm volatile("" : "+v"(ufA[nu]), "+v"(vfA[nu][0]), "+v"(vfA[nu][1]));
+                ufA[nu] = f32x4{1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+                for (int tb = 0; tb < NTB; ++tb) { vfA[nu][tb] = f32x4{4.f, 3.f, 2.f, 1.f}; asm volatile("" : "+v"(vfA[nu][tb])); }
+                asm volatile("" : "+v"(ufA[nu]));
                 continue;
             }
             ufA[nu] = *reinterpret_cast<const f32x4*>(wb + nu * BN * CK + woff);
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) vfA[nu][tb] = *reinterpret_cast<const f32x4*>(vb + nu * 32 * CK + tb * 16 * CK + voff);
+            for (int tb = 0; tb < NTB; ++tb) vfA[nu][tb] = *reinterpret_cast<const f32x4*>(vb + nu * 32 * CK + tb * 16 * CK + voff);
         }
     };
-    auto mfma8 = [&](f32x4 (&c)[2], const f32x4& u, const f32x4 (&v)[2]) __attribute__((always_inline)) {
+    auto mfma8 = [&](f32x4 (&c)[NTB], const f32x4& u, const f32x4 (&v)[NTB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
+            for (int tb = 0; tb < NTB; ++tb) {
                 if (BMC_WINO_ABL & 1) c[tb][m] += u[m] * v[tb][m];
                 else c[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[m], v[tb][m], c[tb], 0, 0, 0);
             }
     };
     // first half: everything before this stage's barrier
     auto stage_head = [&](const float* vb, const float* wb, int xi, const float* xb_n, float* vb_n, int xi_n, f32x4 (&ufB)[2],
-                          f32x4 (&vfB)[2][2]) __attribute__((always_inline)) {
+                          f32x4 (&vfB)[2][NTB]) __attribute__((always_inline)) {
         f32x4 d[4];
         if (!(BMC_WINO_ABL & 16)) produce_load(xb_n, xi_n, d);
         __builtin_amdgcn_sched_barrier(0);
@@ -334,13 +342,15 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
 #pragma unroll
         for (int nu = 0; nu < 2; ++nu) {
             if (BMC_WINO_ABL & 32) {
-                ufB[nu] = f32x4{1.f, 2.f, 3.f, 4.f}; vfB[nu][0] = vfB[nu][1] = f32x4{4.f, 3.f, 2.f, 1.f};
-                asm volatile("" : "+v"(ufB[nu]), "+v"(vfB[nu][0]), "+v"(vfB[nu][1]));
+                ufB[nu] = f32x4{1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+                for (int tb = 0; tb < NTB; ++tb) { vfB[nu][tb] = f32x4{4.f, 3.f, 2.f, 1.f}; asm volatile("" : "+v"(vfB[nu][tb])); }
+                asm volatile("" : "+v"(ufB[nu]));
                 continue;
             }
             ufB[nu] = *reinterpret_cast<const f32x4*>(wb + (2 + nu) * BN * CK + woff);
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) vfB[nu][tb] = *reinterpret_cast<const f32x4*>(vb + (2 + nu) * 32 * CK + tb * 16 * CK + voff);
+            for (int tb = 0; tb < NTB; ++tb) vfB[nu][tb] = *reinterpret_cast<const f32x4*>(vb + (2 + nu) * 32 * CK + tb * 16 * CK + voff);
         }
         __builtin_amdgcn_sched_barrier(0);
         mfma8(acc[4 * xi + 1], ufA[1], vfA[1]);
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     // (the DMA issue of the stage -- weights three stages ahead, after xi = 3 the halo two chunks ahead -- sits BETWEEN the two
     //  MFMA groups: scalar address work placed in front of a stage's first MFMA is matrix-pipe idle time, because the two
     //  waves of a SIMD leave the barrier together and reach it together)
-    auto stage_tail = [&](int xi, const float* vb_n, const float* wb_n, const f32x4 (&ufB)[2], const f32x4 (&vfB)[2][2], int xbuf) __attribute__((always_inline)) {
+    auto stage_tail = [&](int xi, const float* vb_n, const float* wb_n, const f32x4 (&ufB)[2], const f32x4 (&vfB)[2][NTB], int xbuf) __attribute__((always_inline)) {
         load_first(vb_n, wb_n);
         __builtin_amdgcn_sched_barrier(0);
         mfma8(acc[4 * xi + 2], ufB[0], vfB[0]);
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
     auto epilogue = [&](const TileIt& it) __attribute__((always_inline)) {
         pin_acc();
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
+        for (int tb = 0; tb < NTB; ++tb) {
             if (!(BMC_WINO_ABL & 128)) {
                 // Y = A^T M A on whole accumulator quads (the four output channels of a lane at once): packed adds
                 f32x4 ta[4], y[4];
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
         f32x4 bq = {0.f, 0.f, 0.f, 0.f};
         if (biasg && !bias_pre && cok) bq = ldg16(biasg + co);
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
+        for (int tb = 0; tb < NTB; ++tb) {
             const int t = 16 * tb + elj, tr = t >> 3, tc = t & 7;
             bool pok[4];
             int pix[4];
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void wino2_conv_kernel(const ConvK a) {
                     if (xi == 0) load_x((gc + 1) & 1);
                 }
                 const int nslot = rslot == NWR - 1 ? 0 : rslot + 1;
-                f32x4 ufB[2], vfB[2][2];
+                f32x4 ufB[2], vfB[2][NTB];
                 stage_head(Vb + (gs & 1) * VSTAGE, Wb + rslot * WSTAGE, xi, xi == 3 ? xbn : xb, Vb + ((gs + 1) & 1) * VSTAGE, (xi + 1) & 3,
                            ufB, vfB);
                 // everything but the newest DMA is complete: stage gs + 1's weights have landed (younger than them: the 4
@@ -570,11 +580,29 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, const int* __restr
 
 }  // namespace
 
+// Rows per workgroup tile for a launch of this geometry: 8, or 4 where the 8-row tiling leaves CUs without a tile (or with a
+// badly quantised last round) and the 4-row one does not.  A 4-row workgroup costs ~0.6 of an 8-row one (same stage loop and
+// weight stream, half the MFMAs).  bmc_hip/ops.py::wino_ok asks the same function (bmc_conv_wino_rows).
+static int wino_rows(int B, int H, int W, int ntn, int cus) {
+    const char* const e = getenv("BMC_WINO_TH");      // tests and experiments: 8 / 4 = always that tiling (read per launch: ~50 ns)
+    const int mode = e ? atoi(e) : 0;
+    if (mode == 8 || mode == 4) return mode;
+    const long long tx = (W + TW - 1) / TW;
+    const long long n8 = (long long)B * tx * ((H + 7) / 8) * ntn, n4 = (long long)B * tx * ((H + 3) / 4) * ntn;
+    const long long r8 = (n8 + cus - 1) / cus, r4 = (n4 + cus - 1) / cus;
+    return (r8 <= 2 && 6 * r4 < 10 * r8) ? 4 : 8;
+}
+
+extern "C" int bmc_conv_wino_rows(int B, int H, int W, int Coutpad, int cus) {
+    return wino_rows(B, H, W, Coutpad / BN, cus > 0 ? cus : 256);
+}
+
 // Called by bmc_conv (conv.hip) for math == BMC_MATH_FP32_WINO once the argument block is validated.
 int bmc_conv_wino_launch(ConvK k, int cus, hipStream_t st) {
-    k.tiles_x = (k.W + TW - 1) / TW;
-    k.tiles_y = (k.H + TH - 1) / TH;
     k.ntn = k.Coutpad / BN;
+    const int th = wino_rows(k.B, k.H, k.W, k.ntn, cus);
+    k.tiles_x = (k.W + TW - 1) / TW;
+    k.tiles_y = (k.H + th - 1) / th;
     const long long ntiles = (long long)k.B * k.tiles_x * k.tiles_y * k.ntn;
     if (ntiles >= (1ll << 31)) { bmc_set_error("bmc_conv (winograd): too many tiles"); return -1; }
     k.ntiles = (int)ntiles;
@@ -588,7 +616,8 @@ int bmc_conv_wino_launch(ConvK k, int cus, hipStream_t st) {
         return -1;
     }
     dim3 grid((unsigned)(ntiles < cus ? ntiles : cus));
-    hipLaunchKernelGGL(wino2_conv_kernel, grid, dim3(512), 0, st, k);
+    if (th == 4) hipLaunchKernelGGL(wino2_conv_kernel<4>, grid, dim3(512), 0, st, k);
+    else hipLaunchKernelGGL(wino2_conv_kernel<8>, grid, dim3(512), 0, st, k);
     return 0;
 }
 

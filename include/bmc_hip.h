@@ -170,6 +170,11 @@ int bmc_split_weight(const float* packed, void* out, long long nsteps, int Coutp
 int bmc_pack_weight_wino(const float* w, const int* kmap, int G, int Cout, int Cin, int Kpad, int Coutpad, int transposed,
                          int k0, int nk, float* out, bmc_stream_t s);
 
+/* Rows per workgroup tile (8 or 4) that bmc_conv with math = BMC_MATH_FP32_WINO uses for a launch of B images of H x W pixels and
+ * Coutpad output channels on a device of `cus` compute units (<= 0: 256): 4 where the 8 x 16-pixel tiling leaves CUs without a
+ * tile and the 4 x 16 one does not (small frames).  The host's routing rule (bmc_hip/ops.py::wino_ok) counts tiles with it. */
+int bmc_conv_wino_rows(int B, int H, int W, int Coutpad, int cus);
+
 /* The same for F(4x4, 3x3) (36 values per (co, ci) pair, made in double and rounded once; points 0, +-1, +-2, inf), in the
  * streaming order of bmc_conv with math = BMC_MATH_FP32_WINO4: [G][Coutpad/128][Kpad/16][8 (wave)][36 (position)][64 (lane)][4],
  * lane l of wave w = row 128 ntile + 16 w + (l & 15), channels 16 chunk + 4 (l >> 4) + 0..3 -- the MFMA A-operand image a wave

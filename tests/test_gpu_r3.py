@@ -371,14 +371,19 @@ def test_voxel_long_segments_are_sorted_cooperatively():
 
 
 # ------------------------------------------------------------------ Winograd F(2x2, 3x3) convolution kernel (csrc/wino.hip)
-@pytest.fixture
-def force_wino():
-    """Send every eligible 3x3 launch through the Winograd kernel, whatever its size (default: only launches that fill the chip)."""
+@pytest.fixture(params=[8, 4], ids=["rows8", "rows4"])
+def force_wino(request, monkeypatch):
+    """Send every eligible 3x3 launch through the Winograd kernel, whatever its size (default: only launches that fill the chip),
+    once with each of its two workgroup tilings (8 x 16 and 4 x 16 pixels: csrc/wino.hip::wino_rows picks by launch size)."""
     from bmc_hip import ops
     old = ops.WINO_MIN_TILES
     ops.WINO_MIN_TILES = 0
+    monkeypatch.setenv("BMC_WINO_TH", str(request.param))
+    ops._WINO_ROWS.clear()
     yield ops
     ops.WINO_MIN_TILES = old
+    monkeypatch.delenv("BMC_WINO_TH")
+    ops._WINO_ROWS.clear()
 
 
 @pytest.mark.parametrize("B,H,W,cins,cout,relu,res", [

@@ -23,7 +23,8 @@ bias = torch.randn(1, Cn, device=dev)
 flops = 2.0 * B * H * W * Cn * 9 * CIN
 ref = None
 ONLY4 = os.environ.get("W4_ONLY") == "1"          # ablation libraries (BMC_HIP_LIB=...libbmc_hip_w4ablN.so): results are wrong by design
-for name, wino in ((("F(4x4)", 4),) if ONLY4 else (("direct", 0), ("F(2x2)", 2), ("F(4x4)", 4))):
+KINDS = [int(v) for v in os.environ.get("KB_KINDS", "0,2,4").split(",")]      # KB_KINDS=0,2: small launches the F(4x4) kernel does not take
+for name, wino in ((("F(4x4)", 4),) if ONLY4 else tuple(kv for kv in (("direct", 0), ("F(2x2)", 2), ("F(4x4)", 4)) if kv[1] in KINDS)):
     wp = _packed_weight(w, spec, None, wino=wino)
     out = torch.empty(B, H, W, Cn, device=dev)
     for use_res in (False, True):
