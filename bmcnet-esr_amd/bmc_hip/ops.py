@@ -259,7 +259,7 @@ def stacked(owners, build, tag=""):
 # F(2x2, 3x3) (csrc/wino.hip: 16 instead of 36 multiplies per 2x2 output tile and channel pair, fp32 throughout; one
 # 256-accumulator workgroup per CU, so small problems stay on the direct kernel).  BMC_WINO=0 switches it off.
 WINO = os.environ.get("BMC_WINO", "1") != "0"
-WINO_MIN_TILES = int(os.environ.get("BMC_WINO_MIN_TILES", 200))   # >= ~1 tile per CU on most of the chip (31x56 at 4B: 256 tiles, +3.5 %)
+WINO_MIN_TILES = int(os.environ.get("BMC_WINO_MIN_TILES", 128))   # tiles (workgroups) from which the F(2x2) kernel beats the direct one: half the CUs (72x80 bs 2: 98.2 -> 94.2 ms against 200; a launch under one round costs one workgroup's serial time whatever its size)
 
 
 # Round 4: F(4x4, 3x3) (csrc/wino4.hip: 36 instead of 144 multiplies per 4x4 output tile and channel pair -- 1.78x fewer than
@@ -406,6 +406,7 @@ def wino_ok(B, H, W, Cout, taps, fwd=False, stride=0, rule=None):
 
 
 PAIR_SMALL = os.environ.get("BMC_PAIR_SMALL", "1") != "0"
+PAIR_BELOW_TILES = 200        # 8 x 16-pixel tiles of one block's launch under which the pair shares a launch
 
 
 def pair_small(B2, H, W):
@@ -415,7 +416,7 @@ def pair_small(B2, H, W):
     31x56, bs 4 the step's 3x3 convolutions were 128-tile launches at 86 TFLOP/s.  The price is one concatenation of the two
     inputs -- negligible at these sizes, which is why large frames keep the separate launches."""
     t = B2 * ((H + 7) // 8) * ((W + 15) // 16)
-    return PAIR_SMALL and WINO and MATH == 0 and t < WINO_MIN_TILES <= 2 * t      # (bf16 arithmetic, no Winograd: 72 -> 76 ms, not used)
+    return PAIR_SMALL and WINO and MATH == 0 and t < PAIR_BELOW_TILES <= 2 * t      # (bf16 arithmetic, no Winograd: 72 -> 76 ms, not used)
 
 
 def _packed_weight(w4: torch.Tensor, spec: ConvSpec, owner, wino=False):
