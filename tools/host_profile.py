@@ -43,3 +43,26 @@ step()
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+
+# ---- the backward pass runs on the autograd engine's device thread: profile it from inside (a hook on the loss enables a second
+# profiler on that thread, an end-of-pass callback disables it)
+import train_step as TS
+pr2 = cProfile.Profile()
+orig_backward = torch.Tensor.backward
+
+
+def backward_profiled(self, *a, **k):
+    def on(g):
+        pr2.enable()
+        torch.autograd.Variable._execution_engine.queue_callback(pr2.disable)
+        return g
+    self.register_hook(on)
+    return orig_backward(self, *a, **k)
+
+
+torch.Tensor.backward = backward_profiled
+step()
+torch.Tensor.backward = orig_backward
+torch.cuda.synchronize()
+print("==== backward pass, engine thread")
+pstats.Stats(pr2).sort_stats("tottime").print_stats(40)
