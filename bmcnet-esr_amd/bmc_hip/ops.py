@@ -406,6 +406,7 @@ def wino_ok(B, H, W, Cout, taps, fwd=False, stride=0, rule=None):
 
 
 PAIR_SMALL = os.environ.get("BMC_PAIR_SMALL", "1") != "0"
+PAIR_ALWAYS = os.environ.get("BMC_PAIR_SMALL") == "2"      # experiments: pair at every size
 PAIR_BELOW_TILES = 200        # 8 x 16-pixel tiles of one block's launch under which the pair shares a launch
 
 
@@ -416,7 +417,7 @@ def pair_small(B2, H, W):
     31x56, bs 4 the step's 3x3 convolutions were 128-tile launches at 86 TFLOP/s.  The price is one concatenation of the two
     inputs -- negligible at these sizes, which is why large frames keep the separate launches."""
     t = B2 * ((H + 7) // 8) * ((W + 15) // 16)
-    return PAIR_SMALL and WINO and MATH == 0 and t < PAIR_BELOW_TILES <= 2 * t      # (bf16 arithmetic, no Winograd: 72 -> 76 ms, not used)
+    return PAIR_SMALL and WINO and MATH == 0 and (PAIR_ALWAYS or t < PAIR_BELOW_TILES <= 2 * t)      # (bf16 arithmetic, no Winograd: 72 -> 76 ms, not used)
 
 
 def _packed_weight(w4: torch.Tensor, spec: ConvSpec, owner, wino=False):

@@ -43,6 +43,9 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef BMC_W4_PRIO
+#define BMC_W4_PRIO 0
+#endif
 #ifndef BMC_W4_XP
 #define BMC_W4_XP 0        // experiments (tools/ builds only; results are wrong by design): 2 waves w and w + 4 stream the SAME rows of
                            // U (does the CU's L1 serve the SIMD partner's copy?), 3 every second U request left out (half the stream)
@@ -646,6 +649,9 @@ __global__ __launch_bounds__(512, 2) void wino4_conv_kernel(const ConvK a) {
     const int t_first = xcd_map ? t_lo + xj : (int)blockIdx.x;
     const int t_stride = xcd_map ? per_x : (int)gridDim.x;
     if (t_first >= t_hi) return;
+#if BMC_W4_PRIO
+    if ((BMC_W4_PRIO >> wave) & 1) __builtin_amdgcn_s_setprio(1);      // experiment: static priority for a set of waves (bit w = wave w)
+#endif
     if (wave >= 8 - NLW) wino4_body<true>(a, lds, wave, t_first, t_hi, t_stride);
     else wino4_body<false>(a, lds, wave, t_first, t_hi, t_stride);
 #ifdef BMC_W4_STAMP
