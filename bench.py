@@ -216,18 +216,20 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
     peak = KERNEL_PEAK[math]
     total_ms = sum(v[2] for v in agg.values())
 
-    def row(kind, agg=agg):
+    def row(kind, agg=agg, with_situ=False):
+        """One kernel's figures over `agg`.  with_situ (the `kernels` list of a two-stream step): the unqualified fields are the
+        kernel BY ITSELF (the one-stream step), the in-situ-with-sharing ones stand under `in_situ_shared`."""
+        if with_situ and agg_alone is not None and kind in agg_alone:
+            r = row(kind, agg_alone)
+            rs = row(kind, agg)
+            r["in_situ_shared"] = {k: rs[k] for k in ("avg_launch_ms", "ms_per_step", "share_of_profiled_kernel_time", "executed_tflops", "frac", "hbm_frac")}
+            return r
         n, fl, ms, nb = agg[kind]
         total_ms = sum(v[2] for v in agg.values())
         alg = fl / (ms * 1e-3) / 1e12 if fl else None
         ex = alg * EXECUTED.get(kind, 1.0) if alg else None
-        hbm = nb / (ms * 1e-3) / 1e9 if nb else None          # algorithmic bytes (operands once, output once) over the in-situ time
-        alone = {}
-        if agg is not agg_alone and agg_alone is not None and kind in agg_alone:
-            ra = row(kind, agg_alone)
-            alone = {"avg_launch_ms_alone": ra["avg_launch_ms"], "frac_alone": ra["frac"], "hbm_frac_alone": ra["hbm_frac"],
-                     "ms_per_step_alone": ra["ms_per_step"]}
-        return {"kernel": kind, **alone, "hbm_algorithmic_GBps": round(hbm, 1) if hbm else None,
+        hbm = nb / (ms * 1e-3) / 1e9 if nb else None          # algorithmic bytes (operands once, output once) over the launch time
+        return {"kernel": kind, "hbm_algorithmic_GBps": round(hbm, 1) if hbm else None,
                 "hbm_frac": round(hbm / HBM_PEAK_GBPS, 4) if hbm else None, "launches": n, "avg_launch_ms": round(ms / n, 4), "ms_per_step": round(ms, 2),
                 "share_of_profiled_kernel_time": round(ms / total_ms, 4),
                 "achieved_algorithmic_tflops": round(alg, 2) if alg else None, "frac_algorithmic": round(alg / peak, 4) if alg else None,
@@ -275,8 +277,10 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
                {k: d_situ[k] for k in ("avg_launch_ms", "ms_per_step", "executed_tflops", "frac", "achieved_algorithmic_tflops")},
                note="the kernel's launches inside the timed two-stream step, CUs shared with the weight-gradient stream"),
            "alone_ms_per_step": None if agg_alone is None else round(sum(v[2] for v in agg_alone.values()), 1),
-           # every kernel kind with >= 4 % of the profiled kernel time, the same two rates each
-           "kernels": [row(k) for k in sorted(agg, key=lambda k: -agg[k][2]) if agg[k][2] >= 0.04 * total_ms],
+           # every kernel kind with >= 4 % of the profiled kernel time, the same two rates each -- by itself (one-stream step) when the
+           # timed step runs two streams, with the in-situ-with-sharing figures under `in_situ_shared`
+           "kernels": [row(k, with_situ=True) for k in sorted(agg_alone or agg, key=lambda k: -(agg_alone or agg)[k][2])
+                       if (agg_alone or agg)[k][2] >= 0.04 * sum(v[2] for v in (agg_alone or agg).values())],
            "profiled_kernel_ms_per_step": round(total_ms, 1)}
     if step_ms:
         # the whole step as a utilisation: executed matrix FLOPs of all profiled kernels over the step time
