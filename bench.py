@@ -177,7 +177,7 @@ KERNEL_LABEL = {"wino4_conv<9,128>": "wino4_conv_kernel [Winograd F(4x4,3x3) on 
                 "wino_conv<9,128>": "wino2_conv_kernel [Winograd F(2x2,3x3) on the fp32 MFMA, csrc/wino.hip]",
                 "wgrad_wino<9>": "wino_wgrad_kernel [Winograd F(2x2,3x3) weight gradient, csrc/wino_wgrad.hip]",
                 "wgrad_wino4<9>": "wino4_wgrad_kernel [Winograd F(4x4,3x3) weight gradient, csrc/wino4_wgrad.hip]"}
-PMC_NAME = {"wino4_conv<9,128>": "wino4_conv_kernel", "wino_conv<9,128>": "wino2_conv_kernel"}
+PMC_NAME = {"wino4_conv<9,128>": "wino4_conv_kernel", "wino_conv<9,128>": "wino2_conv_kernel<8>"}
 
 
 def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
