@@ -75,8 +75,20 @@ __device__ __forceinline__ const float* src_batch_ptr_tab(const SrcDev& s, int b
     }
     return src_batch_ptr(s, b);
 }
+// Compile-time selection: the table lookup is a compiler-visible vector-memory load, and one such load anywhere on a path into a
+// loop of hand-counted LDS-DMA makes the compiler wait for ALL outstanding vector-memory operations there (pgemm<1>: 245 -> 264 us
+// with the table path merely compiled in) -- so kernels exist once without it (TAB = false: every launch of a large frame) and once
+// with it (the merged small-frame launches).
+template <bool TAB>
+__device__ __forceinline__ const float* src_bp(const SrcDev& s, int b) {
+    if constexpr (TAB) return src_batch_ptr_tab(s, b);
+    else return src_batch_ptr(s, b);
+}
+static inline bool src_is_table(const SrcDev& s) { return s.batch_mod == BMC_SRC_TABLE; }
 // ... where descriptor and image are wave-uniform and the result feeds a scalar-base memory instruction
-__device__ __forceinline__ const float* src_batch_ptr_tab_uni(const SrcDev& s, int b) {
+template <bool TAB>
+__device__ __forceinline__ const float* src_bp_uni(const SrcDev& s, int b) {
+    if constexpr (!TAB) return src_batch_ptr(s, b);
     const unsigned long long v = reinterpret_cast<unsigned long long>(src_batch_ptr_tab(s, b));
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);

@@ -25,7 +25,7 @@ namespace {
 // are only reached by cutting the pixel axis into ~128 splits and every split writes a whole [taps][M][N] slab -- at
 // 31x56 the slab writes took as long as the MFMAs, and the reduction read 75 MB per weight gradient.  Three times the
 // workgroups per split = a third of the splits = a third of the slab bytes, for three times the (cheap) tile fills.
-template <int TAPS, int TG = TAPS>
+template <int TAPS, int TG = TAPS, bool TAB = false>
 __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
     constexpr int HWD = PT_W + 2, HHT = PT_H + 2;
     constexpr int NHALO = TAPS == 9 ? HWD * HHT : PT;                   // 108 halo pixels or 64 pixels
@@ -117,11 +117,11 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
             if (nx_tx >= a.tiles_x) { nx_tx -= a.tiles_x; ++nx_ty; }
             if (nx_ty >= a.tiles_y) { nx_ty -= a.tiles_y; ++nx_bb; }
         } else if (nx_tx >= a.tiles_per_img) { nx_tx -= a.tiles_per_img; ++nx_bb; }
-        const float* ab = src_batch_ptr_tab(a.a, b);
+        const float* ab = src_bp<TAB>(a.a, b);
         const bool interior = TAPS == 9 ? (y0 >= 1 && x0 >= 1 && y0 + PT_H + 1 <= a.H && x0 + PT_W + 1 <= a.W) : (p0 + PT <= HWp);
         if (interior && all_ch) {
             const float* const abt = ab + (TAPS == 9 ? (long long)y0 * a.W + x0 : (long long)p0) * a.a.pix_stride;
-            const float* const xbt = src_batch_ptr_tab(xs, b) +
+            const float* const xbt = src_bp<TAB>(xs, b) +
                                      (TAPS == 9 ? (long long)(y0 - 1) * a.W + (x0 - 1) : (long long)p0) * xs.pix_stride;
 #pragma unroll
             for (int i = 0; i < 4; ++i) dma(abt, (unsigned)a_off[i], lds + buf * BUF + (i * 512 + wave * 64) * 4);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
                 for (int si = 1; si < BMC_MAX_SRC; ++si)
                     if (s_i == si - 1 && ch >= tab[si - 1].nch && si < a.nsrc) { ch -= tab[si - 1].nch; s_i = si; }
                 const SrcDev S = tab[s_i];
-                src = src_batch_ptr_tab(S, b) + pix * S.pix_stride + ch;
+                src = src_bp<TAB>(S, b) + pix * S.pix_stride + ch;
             }
             dma16v(src, (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + (2 + buf) * BUF + (i * 512 + wave * 64) * 4));
         }
@@ -486,23 +486,27 @@ extern "C" int bmc_pgemm(const bmc_pgemm_args_t* h, bmc_stream_t stream) {
         }
         return bmc_pgemm_bf_launch(k, h->taps, h->math == BMC_MATH_BF16 ? 1 : 3, st);
     }
+    const bool tab = pgemm_uses_tables(k);
     if (h->taps == 9) {
         k.n_nblk = (k.Npad + 63) / 64;
         k.tiles_x = (h->W + PT_W - 1) / PT_W; k.tiles_y = (h->H + PT_H - 1) / PT_H;
         k.tiles_per_img = k.tiles_x * k.tiles_y;
         if (h->tap_groups == 3) {
             dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * 3 * k.nsplit));
-            hipLaunchKernelGGL((pgemm_dma_kernel<9, 3>), grid, dim3(512), 0, st, k);
+            if (tab) hipLaunchKernelGGL((pgemm_dma_kernel<9, 3, true>), grid, dim3(512), 0, st, k);
+            else hipLaunchKernelGGL((pgemm_dma_kernel<9, 3>), grid, dim3(512), 0, st, k);
         } else {
             dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * k.nsplit));
-            hipLaunchKernelGGL(pgemm_dma_kernel<9>, grid, dim3(512), 0, st, k);
+            if (tab) hipLaunchKernelGGL((pgemm_dma_kernel<9, 9, true>), grid, dim3(512), 0, st, k);
+            else hipLaunchKernelGGL(pgemm_dma_kernel<9>, grid, dim3(512), 0, st, k);
         }
     } else {
         k.n_nblk = (k.Npad + 127) / 128;
         k.tiles_x = k.tiles_y = 0;
         k.tiles_per_img = (h->H * h->W + PT - 1) / PT;
         dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * k.nsplit));
-        hipLaunchKernelGGL(pgemm_dma_kernel<1>, grid, dim3(512), 0, st, k);
+        if (tab) hipLaunchKernelGGL((pgemm_dma_kernel<1, 1, true>), grid, dim3(512), 0, st, k);
+        else hipLaunchKernelGGL(pgemm_dma_kernel<1>, grid, dim3(512), 0, st, k);
     }
     BMC_CHECK_LAUNCH("bmc_pgemm");
     return 0;

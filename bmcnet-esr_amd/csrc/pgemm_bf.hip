@@ -38,7 +38,7 @@ __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
-template <int TAPS, int NP>
+template <int TAPS, int NP, bool TAB = false>
 __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
     constexpr int HWD = PT_W + 2, HHT = PT_H + 2;
     constexpr int NHALO = TAPS == 9 ? HWD * HHT : PT;                   // 108 halo pixels or 64 pixels
@@ -121,11 +121,11 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
         int y0 = 0, x0 = 0, p0 = 0;
         if (TAPS == 9) { y0 = (tin / a.tiles_x) * PT_H; x0 = (tin % a.tiles_x) * PT_W; }
         else p0 = tin * PT;
-        const float* ab = src_batch_ptr_tab(a.a, b);
+        const float* ab = src_bp<TAB>(a.a, b);
         const bool interior = TAPS == 9 ? (y0 >= 1 && x0 >= 1 && y0 + PT_H + 1 <= a.H && x0 + PT_W + 1 <= a.W) : (p0 + PT <= HWp);
         if (interior && all_ch) {
             const char* const abt = uniform_ptr(ab + (TAPS == 9 ? (long long)y0 * a.W + x0 : (long long)p0) * a.a.pix_stride);
-            const char* const xbt = uniform_ptr(src_batch_ptr_tab(xs, b) +
+            const char* const xbt = uniform_ptr(src_bp<TAB>(xs, b) +
                                                 (TAPS == 9 ? (long long)(y0 - 1) * a.W + (x0 - 1) : (long long)p0) * xs.pix_stride);
 #pragma unroll
             for (int i = 0; i < NAL; ++i) ar[slot][i] = ldg16(abt + fa_off[i]);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
 #pragma unroll
             for (int si = 1; si < BMC_MAX_SRC; ++si)
                 if (ch >= S.nch && si < a.nsrc) { ch -= S.nch; S = a.src[si]; }
-            const float* src = ok ? src_batch_ptr_tab(S, b) + pix * S.pix_stride + ch : a.zeros;
+            const float* src = ok ? src_bp<TAB>(S, b) + pix * S.pix_stride + ch : a.zeros;
             xr[slot][i] = ldg16(src);
         }
     };
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(512, 1) void pgemm_bf_kernel(const PgemmK a) {
 // One barrier per tile; the producers' VALU / LDS-write / VMEM work runs beside the consumers' MFMAs.
 // LDS: A image [64 px][128 ch] bf16 in 256-byte rows, 64-byte chunks XOR-swizzled by (row & 3) (no padding, so that two
 // images fit); X image [108 halo px][32 ch] in 64-byte rows.
+template <bool TAB>
 __global__ __launch_bounds__(768, 1) void pgemm_bf9x3_kernel(const PgemmK a) {
     constexpr int NP = 3, HWD = PT_W + 2, HHT = PT_H + 2, NHALO = HWD * HHT, XCH = 32, XQ = XCH / 4;
     constexpr int AST = 256, XST = 64, APL = PT * AST, XPL = NHALO * XST, STAGE = NP * (APL + XPL);
@@ -392,10 +393,10 @@ __global__ __launch_bounds__(768, 1) void pgemm_bf9x3_kernel(const PgemmK a) {
             if (nx_ty >= a.tiles_y) { nx_ty -= a.tiles_y; ++nx_bb; }
             const bool interior = t.y0 >= 1 && t.x0 >= 1 && t.y0 + PT_H + 1 <= a.H && t.x0 + PT_W + 1 <= a.W;   // halo inside the image
             t.fast = t.live && interior && all_ch;
-            t.ab = src_batch_ptr_tab_uni(a.a, b) + ((long long)t.y0 * a.W + t.x0) * a.a.pix_stride;
+            t.ab = src_bp_uni<TAB>(a.a, b) + ((long long)t.y0 * a.W + t.x0) * a.a.pix_stride;
 #pragma unroll
             for (int si = 0; si < BMC_MAX_SRC; ++si)
-                t.xb[si] = src_batch_ptr_tab_uni(a.src[si], b) + ((long long)(t.y0 - 1) * a.W + (t.x0 - 1)) * a.src[si].pix_stride;
+                t.xb[si] = src_bp_uni<TAB>(a.src[si], b) + ((long long)(t.y0 - 1) * a.W + (t.x0 - 1)) * a.src[si].pix_stride;
             return t;
         };
         // Loads are inline asm, waited for by hand (the compiler cannot count vmcnt across this loop).  Hazard of the
@@ -604,11 +605,14 @@ int bmc_pgemm_cols(int taps, int math) {   // columns of C per workgroup (the ho
 int bmc_pgemm_bf_launch(const PgemmK& k, int taps, int planes, hipStream_t st) {
     const int tgs = (taps == 9 && planes == 1 && k.tap_groups == 3) ? 3 : 1;
     dim3 grid((unsigned)((long long)k.G * k.n_mblk * k.n_nblk * tgs * k.nsplit)), block(512);
+    const bool tab = pgemm_uses_tables(k);
     if (taps == 9) {
-        if (planes == 3) hipLaunchKernelGGL(pgemm_bf9x3_kernel, grid, dim3(768), 0, st, k);
+        if (planes == 3) { if (tab) hipLaunchKernelGGL(pgemm_bf9x3_kernel<true>, grid, dim3(768), 0, st, k); else hipLaunchKernelGGL(pgemm_bf9x3_kernel<false>, grid, dim3(768), 0, st, k); }
+        else if (tab) hipLaunchKernelGGL((pgemm_bf_kernel<9, 1, true>), grid, block, 0, st, k);
         else hipLaunchKernelGGL((pgemm_bf_kernel<9, 1>), grid, block, 0, st, k);
     } else {
-        if (planes == 3) hipLaunchKernelGGL((pgemm_bf_kernel<1, 3>), grid, block, 0, st, k);
+        if (planes == 3) { if (tab) hipLaunchKernelGGL((pgemm_bf_kernel<1, 3, true>), grid, block, 0, st, k); else hipLaunchKernelGGL((pgemm_bf_kernel<1, 3>), grid, block, 0, st, k); }
+        else if (tab) hipLaunchKernelGGL((pgemm_bf_kernel<1, 1, true>), grid, block, 0, st, k);
         else hipLaunchKernelGGL((pgemm_bf_kernel<1, 1>), grid, block, 0, st, k);
     }
     BMC_CHECK_LAUNCH("bmc_pgemm (bf16 planes)");

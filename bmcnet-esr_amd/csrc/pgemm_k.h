@@ -20,6 +20,14 @@ struct PgemmK {
     int tap_groups;      // 3: one tap row per workgroup (bmc_pgemm_args_t.tap_groups), else all taps
 };
 
+// Does any operand of the launch name its images through a pointer table (BMC_SRC_TABLE)?  Such launches take the kernels' TAB
+// instantiations (bmc_common.h, src_bp).
+static inline bool pgemm_uses_tables(const PgemmK& k) {
+    bool t = src_is_table(k.a);
+    for (int i = 0; i < k.nsrc; ++i) t = t || src_is_table(k.src[i]);
+    return t;
+}
+
 // pgemm_bf.hip: bf16-plane variant (planes = 1: bf16 operands; 3: exact 3-way split, six plane products).
 int bmc_pgemm_cols(int taps, int math);   // columns of C per workgroup for (taps, math mode)
 int bmc_pgemm_bf_launch(const PgemmK& k, int taps, int planes, hipStream_t st);
