@@ -30,14 +30,16 @@ def _kernels(path):
         m = re.match(r"^(_Z\w+):", ln)
         if m:
             cur = m.group(1)
-            body = out[cur] = {"flat": 0, "m0": 0, "scratch_in_loop": 0, "max_mfma_per_block": 0, "_mfma": 0}
+            body = out[cur] = {"flat": 0, "m0": 0, "scratch_in_loop": 0, "max_mfma_per_block": 0, "_mfma": 0, "_vm0": 0, "vm0_in_mfma_blocks": 0}
             in_asm = in_loop = False
             continue
         if body is None:
             continue
         if re.match(r"^\.LBB\d+_\d+:", ln):            # the compiler annotates the blocks of a loop ("in Loop: Header=..." / "Loop Header")
             in_loop = "Loop" in ln
-            body["_mfma"] = 0
+            if body["_mfma"] >= 8:
+                body["vm0_in_mfma_blocks"] += body["_vm0"]
+            body["_mfma"] = body["_vm0"] = 0
         elif ln.lstrip().startswith(";") and "Loop" in ln and ("Header" in ln):
             in_loop = True
         if in_loop and re.search(r"\bscratch_(load|store)", ln.split(";")[0]):
@@ -50,6 +52,8 @@ def _kernels(path):
         if "v_mfma" in code:
             body["_mfma"] += 1
             body["max_mfma_per_block"] = max(body["max_mfma_per_block"], body["_mfma"])
+        if re.search(r"s_waitcnt.*vmcnt\(0\)", code):
+            body["_vm0"] += 1
         if re.search(r"\bflat_(load|store|atomic)", code):
             body["flat"] += 1
         if not in_asm and re.search(r"\bm0\b", code):
@@ -58,6 +62,8 @@ def _kernels(path):
         if m:
             body[m.group(1)] = int(m.group(2))
             if m.group(1) == "Occupancy":
+                if body["_mfma"] >= 8:
+                    body["vm0_in_mfma_blocks"] += body["_vm0"]
                 body = None
     return out
 
@@ -144,3 +150,22 @@ def test_wino4_pair_loop_is_expanded_at_compile_time(isa):
     for n, k in hits:
         assert k["max_mfma_per_block"] == 144, (n, k["max_mfma_per_block"])
         assert k["ScratchSize"] == 0 and k["scratch_in_loop"] == 0, (n, k)
+
+
+def test_dma_pipelined_loops_hold_no_full_vector_memory_wait(isa):
+    """The kernels whose operands arrive by hand-counted LDS-DMA / register rings (`s_waitcnt vmcnt(N)` written by hand) must not
+    hold an `s_waitcnt vmcnt(0)` in a basic block with MFMAs: one compiler-visible vector-memory load on a path into such a loop
+    makes the compiler wait for EVERYTHING in flight there.  Round 5's pointer-table lookup did exactly that to every launch of the
+    pixel-reduction GEMMs (pgemm<1> 245 -> 264 us, the C2 step +10 ms) until it became its own instantiation (`src_bp<TAB>`);
+    round 4 met the same in the F(4x4) kernel (a generic-pointer atomic).  The TAB instantiations (merged small-frame launches)
+    are the documented exception."""
+    frags = ["pgemm_dma_kernelILi1ELi1ELb0E", "pgemm_dma_kernelILi9ELi9ELb0E", "pgemm_dma_kernelILi9ELi3ELb0E", "wino4_conv_kernel",
+             "wino2_conv_kernel", "wino_wgrad_kernel", "conv1p_kernel", "pgemm_bf_kernelILi1ELi1ELb0E", "pgemm_bf9x3_kernelILb0E"]
+    for frag in frags:
+        hits = [(n, k) for _, n, k in _all(isa) if frag in n]
+        assert hits, frag
+        for n, k in hits:
+            assert k["vm0_in_mfma_blocks"] == 0, (n, k["vm0_in_mfma_blocks"])
+    # ... and the instantiation with the table lookup does hold one (the check has teeth)
+    tab = [k for _, n, k in _all(isa) if "pgemm_dma_kernelILi1ELi1ELb1E" in n]
+    assert tab and tab[0]["vm0_in_mfma_blocks"] >= 1
