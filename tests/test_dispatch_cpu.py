@@ -68,3 +68,15 @@ def test_sink_route_recognises_reducer_hooks_by_id():
     assert not (ids & p._bmc_sink_hooks)
     p.register_post_accumulate_grad_hook(lambda t: None)
     assert not ops.is_sink(p)
+
+
+def test_wino_rows_rule_matches_the_host_side_tile_count():
+    """csrc/wino.hip::wino_rows (exported as bmc_conv_wino_rows, a host-only function): 4-row tiles where the 8-row tiling
+    needs at most two rounds of the 256 CUs and the 4-row one 0.6 x the rounds fewer; ops.wino_tiles counts with it."""
+    from bmc_hip import lib, ops
+    ops._WINO_ROWS.clear()
+    for (B, H, W), th in {(8, 31, 56): 4, (16, 31, 56): 8, (4, 45, 80): 4, (8, 45, 80): 8, (8, 64, 96): 4, (8, 90, 120): 8,
+                          (8, 180, 240): 8, (2, 80, 80): 4, (4, 72, 80): 8}.items():
+        assert lib._wino_rows(B, H, W, 128, 0) == th, (B, H, W)
+        assert ops.wino_tiles(B, H, W, 128) == (B * ((H + th - 1) // th) * ((W + 15) // 16), th)
+    assert lib._wino_rows(8, 31, 56, 256, 0) == 8              # two channel tiles double the count: one round of 8-row tiles
