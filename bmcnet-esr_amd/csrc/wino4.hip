@@ -46,6 +46,9 @@
 #ifndef BMC_W4_PRIO
 #define BMC_W4_PRIO 0
 #endif
+#ifndef BMC_W4_DPRIO
+#define BMC_W4_DPRIO 5       // wave priority by position in the chunk (below: the chunk's pair loop); 0 = none, other values: the variants measured in NOTEBOOK.md R5.11
+#endif
 #ifndef BMC_W4_XP
 #define BMC_W4_XP 0        // experiments (tools/ builds only; results are wrong by design): 2 waves w and w + 4 stream the SAME rows of
                            // U (does the CU's L1 serve the SIMD partner's copy?), 3 every second U request left out (half the stream)
@@ -407,6 +410,37 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
             const int p0 = 2 * pp, p1 = p0 + 1, s0 = p0 % D, s1 = p1 % D;
             // U(p0), U(p1) have landed: younger are the D - 2 requests behind them and, on a loader wave, the halo pieces
             // issued since (behind the requests of pairs pp - D / 2 .. pp - 1: xyounger)
+#if BMC_W4_DPRIO
+            // Priority follows the wave's position in its chunk: 3, 2, 1, 0 by quarters of the pair loop.  The two waves of a SIMD share
+            // its matrix pipe and its issue slots, arbitrated by priority, then age -- at equal priority the older wave wins every
+            // conflict, finishes its 144 MFMAs in ~9.2 k cycles and waits ~3 k at the chunk's barrier while its partner works through
+            // what it was denied (round 4's stamps).  With the priority falling along the chunk, whichever wave is BEHIND holds the
+            // higher one: the pair stays in step and the pipe busy to the end of the chunk.  -1.3 % per launch (0.3225 -> 0.3182 ms);
+            // static sets of waves at priority 1 measured nothing (R5.7).  Other values of the macro: the variants of NOTEBOOK.md R5.11
+            // (1: high in the first half; 2: high in the second half; 3: first third; 4: first sixth; 6: first third at 3; 7-9: other break points)
+            if (BMC_W4_DPRIO <= 3) {
+                if (pp == 0) __builtin_amdgcn_s_setprio(BMC_W4_DPRIO == 2 ? 0 : 1);
+                if (pp == (BMC_W4_DPRIO == 3 ? NPOS / 6 : NPOS / 4)) __builtin_amdgcn_s_setprio(BMC_W4_DPRIO == 2 ? 1 : 0);
+            } else if (BMC_W4_DPRIO == 4) {
+                if (pp == 0) __builtin_amdgcn_s_setprio(1);
+                if (pp == 3) __builtin_amdgcn_s_setprio(0);
+            } else if (BMC_W4_DPRIO == 5) {
+                if (pp == 0) __builtin_amdgcn_s_setprio(3);
+                if (pp == 4) __builtin_amdgcn_s_setprio(2);
+                if (pp == 9) __builtin_amdgcn_s_setprio(1);
+                if (pp == 13) __builtin_amdgcn_s_setprio(0);
+            } else if (BMC_W4_DPRIO == 7 || BMC_W4_DPRIO == 8 || BMC_W4_DPRIO == 9) {
+                constexpr int e1 = BMC_W4_DPRIO == 7 ? 3 : (BMC_W4_DPRIO == 8 ? 6 : 2), e2 = BMC_W4_DPRIO == 7 ? 7 : (BMC_W4_DPRIO == 8 ? 10 : 5),
+                              e3 = BMC_W4_DPRIO == 7 ? 12 : (BMC_W4_DPRIO == 8 ? 14 : 9);
+                if (pp == 0) __builtin_amdgcn_s_setprio(3);
+                if (pp == e1) __builtin_amdgcn_s_setprio(2);
+                if (pp == e2) __builtin_amdgcn_s_setprio(1);
+                if (pp == e3) __builtin_amdgcn_s_setprio(0);
+            } else if (BMC_W4_DPRIO == 6) {
+                if (pp == 0) __builtin_amdgcn_s_setprio(3);
+                if (pp == 6) __builtin_amdgcn_s_setprio(0);
+            }
+#endif
             if (LOADER) uwait_n(D - 2 + xyounger(pp), ur[s0], ur[s1]); else uwait<D - 2>(ur[s0], ur[s1]);
             if (LOADER && pp == XLAST + D / 2 + 1) zero_x(gbuf);     // (the wait above was the first behind the strip's last piece: it has landed)
             __builtin_amdgcn_sched_barrier(0);
