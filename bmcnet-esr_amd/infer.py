@@ -15,13 +15,39 @@ class StreamingSR:
     parameter values it was captured with (the packed weight images are baked into it): a different input shape raises,
     a parameter update (load_state_dict, optimizer step, in-place edit -- anything that bumps a parameter's version
     counter) makes the next step() capture afresh; edits through `.data` bypass the counters -- call reset() or
-    invalidate() after them."""
+    invalidate() after them.
 
-    def __init__(self, model, n_c=128, scale=4, plain=False, graph=False):
+    state_dtype=torch.bfloat16: the recurrent FEATURE state (the n_c-channel tensors h, h_p, h_n: 3 x n_c x H x W floats per
+    sequence, 66 MB at 180x240 -- what a server multiplexing many sequences through one model keeps resident per sequence) is
+    carried in bf16 between windows: rounded to nearest-even when a window hands it over, widened back (exactly) when the next
+    one reads it.  The previous HR prediction stays fp32 (it is the caller's output).  Contract: the reference's recurrence
+    with round_bf16 applied to the three feature states between windows -- oracle/bmc_oracle.py::round_bf16, pinned by
+    tests/test_gpu_r5.py::test_streaming_state_in_bf16_vs_oracle_with_state_rounding; the arithmetic inside a window is unchanged."""
+
+    def __init__(self, model, n_c=128, scale=4, plain=False, graph=False, state_dtype=None):
+        if state_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("StreamingSR: state_dtype must be None / torch.float32 / torch.bfloat16 (got %r)" % (state_dtype,))
         self.model = model.eval()
         self.n_c, self.scale, self.plain = n_c, scale, plain
         self.use_graph = graph
+        self.state_dtype = None if state_dtype is torch.float32 else state_dtype
         self.reset()
+
+    def _pack(self, out):
+        """Model outputs (feature states ..., prediction) -> the carried state: features in state_dtype, prediction fp32."""
+        if self.state_dtype is None:
+            return tuple(out)
+        return tuple(t.to(self.state_dtype) for t in out[:-1]) + (out[-1],)
+
+    def _unpack(self, state):
+        """The carried state -> what the model reads (fp32; bf16 -> fp32 is exact)."""
+        if self.state_dtype is None:
+            return tuple(state)
+        return tuple(t.float() for t in state[:-1]) + (state[-1],)
+
+    def state_bytes(self):
+        """Bytes of recurrent state carried for the current sequence (0 before the first window)."""
+        return 0 if self.state is None else sum(t.numel() * t.element_size() for t in self.state)
 
     def reset(self):
         """Forget the recurrent state, the timings and the captured graph with its static buffers."""
@@ -46,14 +72,14 @@ class StreamingSR:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up on a side stream, as the capture protocol asks
-            self.model(self._x_static, *self._state_static, False)
+            self.model(self._x_static, *self._unpack(self._state_static), False)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = self.model(self._x_static, *self._state_static, False)
+            out = self.model(self._x_static, *self._unpack(self._state_static), False)
             for dst, src in zip(self._state_static, out):
-                dst.copy_(src)
+                dst.copy_(src)                              # (a bf16 static buffer: copy_ rounds to nearest-even, as _pack does)
         self._graph = g
         self._stamp = self._weights_stamp()
 
@@ -76,7 +102,7 @@ class StreamingSR:
                 out = self.model(x, z(self.n_c), z(2 * self.scale ** 2), True)
             else:
                 out = self.model(x, z(self.n_c), z(self.n_c), z(self.n_c), z(2 * self.scale ** 2), True)
-            self.state = tuple(out)
+            self.state = self._pack(out)
             pred = out[-1]
         elif self.use_graph and self._calls >= 3:
             if self._graph is not None and self._stamp != self._weights_stamp():
@@ -91,8 +117,8 @@ class StreamingSR:
             self.state = tuple(self._state_static)
             pred = self._state_static[-1].clone()           # the caller's own copy: the next replay rewrites the buffer
         else:
-            out = self.model(x, *self.state, False)
-            self.state = tuple(out)
+            out = self.model(x, *self._unpack(self.state), False)
+            self.state = self._pack(out)
             pred = out[-1]
         if timed:
             end.record()

@@ -411,3 +411,57 @@ def test_dispatch_thresholds_both_sides_meet_the_oracle(name, below, above):
         n0 = sum(v for k, v in k0.items() if "conv" in k and "9" in k)
         n1 = sum(v for k, v in k1.items() if "conv" in k and "9" in k)
         assert n0 < n1, (k0, k1)
+
+
+# ------------------------------------------------------------------ streaming inference with the recurrent state carried in bf16
+@pytest.mark.parametrize("graph", [False, True])
+def test_streaming_state_in_bf16_vs_oracle_with_state_rounding(graph):
+    """infer.StreamingSR(state_dtype=torch.bfloat16) ("persistent recurrent state in bf16"; the reference
+    carries it in fp32, infer_BMCNet.py:44-68): the three feature states are rounded to bf16 (nearest-even) between windows, the
+    arithmetic of a window is unchanged.  Pinned against the CPU oracle running the SAME recurrence -- oracle.round_bf16 on the
+    feature states between windows -- at fp32 bars; the price of the storage format (against the fp32-state run) is measured
+    and held under a stated bar; the carried bytes are half the fp32 ones for the features."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from infer import StreamingSR
+    from models.BMCNet import BMCNet
+    from oracle import bmc_oracle as O
+    ops.set_math("fp32")
+    scale, n_c, n_b, B, H, W, NW = 4, 32, 2, 2, 24, 40, 6
+    torch.manual_seed(541)
+    m = BMCNet(scale, n_c, n_b)
+    scaled_init(m, 2.0)
+    params = oracle_params(m)
+    g = torch.Generator().manual_seed(542)
+    frames = torch.poisson(torch.full((B, NW + 2, 2, H, W), 0.3), generator=g)
+    xs = [frames[:, i:i + 3].transpose(1, 2).contiguous() for i in range(NW)]
+    # the oracle's recurrence with the storage rounding between windows
+    z = lambda c: torch.zeros(B, c, H, W)
+    st = (z(n_c), z(n_c), z(n_c), z(2 * scale * scale))
+    ref = []
+    with torch.no_grad():
+        for i in range(NW):
+            h, hp, hn, pred = O.bmcnet_forward(params, xs[i], *st, i == 0, scale)
+            st = (O.round_bf16(h), O.round_bf16(hp), O.round_bf16(hn), pred)
+            ref.append(pred)
+    m.to(dev)
+    sr = StreamingSR(m, n_c=n_c, scale=scale, graph=graph, state_dtype=torch.bfloat16)
+    sr32 = StreamingSR(m, n_c=n_c, scale=scale, graph=graph)
+    worst, price = 0.0, 0.0
+    for i in range(NW):
+        p = sr.step(xs[i].to(dev))
+        p32 = sr32.step(xs[i].to(dev))
+        assert p.dtype == torch.float32
+        worst = max(worst, rel_l2(p, ref[i]))
+        price = max(price, rel_l2(p, p32))
+    assert [t.dtype for t in sr.state] == [torch.bfloat16] * 3 + [torch.float32]
+    feat32 = 3 * B * n_c * H * W * 4
+    assert sr.state_bytes() == feat32 // 2 + B * 2 * (scale * H) * (scale * W) * 4 and sr32.state_bytes() == feat32 + B * 2 * (scale * H) * (scale * W) * 4
+    if graph:
+        assert sr._graph is not None
+    print("state in bf16 (%s): worst SR vs the oracle with the same storage rounding %.1e; against the fp32-state run %.1e" % (
+        "graph replay" if graph else "eager", worst, price))
+    within(worst, 1e-5, CONTRACT_SR, "streaming inference, state in bf16, vs the oracle with state rounding")
+    assert 0 < price < 2e-2                                    # what the storage format costs over 6 windows (stated bar)
+    with pytest.raises(ValueError):
+        StreamingSR(m, state_dtype=torch.float16)
