@@ -465,3 +465,40 @@ def test_streaming_state_in_bf16_vs_oracle_with_state_rounding(graph):
     assert 0 < price < 2e-2                                    # what the storage format costs over 6 windows (stated bar)
     with pytest.raises(ValueError):
         StreamingSR(m, state_dtype=torch.float16)
+
+
+# ------------------------------------------------------------------ F(2x2) convolution, both workgroup tilings, random geometries
+@pytest.mark.parametrize("rows", [8, 4])
+def test_winograd2_geometry_fuzz_vs_direct_kernel(rows, monkeypatch):
+    """Random image sizes through wino2_conv_kernel<8> and <4> (csrc/wino.hip: 8 x 16- and 4 x 16-pixel workgroup tiles), against
+    the direct kernel: images narrower than a tile, fewer rows than a tile, partial last tiles in both directions, more tiles than
+    CUs (the persistent walk and the loaders' hand-over between tiles), one tile per workgroup (small frames); the output sits
+    inside a larger buffer whose other bytes must stay untouched."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from bmc_hip.ops import _packed_weight, _src, conv_raw, coutpad, ConvSpec
+    monkeypatch.setenv("BMC_WINO_TH", str(rows))
+    ops._WINO_ROWS.clear()
+    g = torch.Generator().manual_seed(405 + rows)
+    Cn = 128
+    spec = ConvSpec.dense(Cn)
+    cp = coutpad(Cn)
+    w = (torch.randn(1, Cn, Cn, 9, generator=g) * 0.03).to(dev)
+    bias = torch.randn(1, Cn, generator=g).to(dev)
+    shapes = [(1, 1, 1), (1, 3, 5), (2, 4, 16), (1, 5, 17), (3, 7, 23), (8, 31, 56), (4, 45, 80), (16, 31, 56), (2, 64, 96), (1, 180, 240)]
+    try:
+        for B, H, W in shapes + [(int(torch.randint(1, 5, (1,), generator=g)), int(torch.randint(1, 70, (1,), generator=g)),
+                                  int(torch.randint(1, 90, (1,), generator=g))) for _ in range(14)]:
+            x = torch.randn(B, H, W, Cn, generator=g).to(dev)
+            res = torch.randn(B, H, W, Cn, generator=g).to(dev)
+            outs = []
+            for wino in (2, 0):
+                wp = _packed_weight(w, spec, None, wino=wino)
+                buf = torch.full((B * H * W * Cn + 512,), 7.0, device=dev)
+                conv_raw([_src(x, 0, Cn, 0, None, 0, B)], wp, spec.kpad * 9 * cp, bias, Cn, buf.data_ptr() + 4 * 256, H * W * Cn, Cn, B, H, W, Cn, 9,
+                         relu=True, residual=_src(res, 0, Cn, 0, None, 0, B), bpg=B, wino=wino)
+                assert torch.equal(buf[:256], torch.full_like(buf[:256], 7.0)) and torch.equal(buf[-256:], torch.full_like(buf[-256:], 7.0)), (B, H, W, wino)
+                outs.append(buf[256:-256])
+            assert rel_l2(outs[0], outs[1]) < 3e-6, (rows, B, H, W, rel_l2(outs[0], outs[1]))
+    finally:
+        ops._WINO_ROWS.clear()
