@@ -678,18 +678,33 @@ def flush_wgrads():
             _launch_merged(q)
 
 
-def _table_src(srcs, batches, table, slot, btot):
+_TABLES = {}      # (stream, image pointers) -> device table holding exactly those pointers
+
+
+def _table_src(srcs, batches, btot, dev):
     """One operand of a merged pixel-reduction launch: the images of `srcs` (one lib.Src per use, batches[i] images each) behind
-    ONE descriptor in BMC_SRC_TABLE mode -- slot `slot` of the device pointer table (btot entries per slot)."""
+    ONE descriptor in BMC_SRC_TABLE mode.  A device table is a pure function of the pointers it holds, and in steady-state training
+    the caching allocator hands out the same addresses step after step: tables are memoised by (stream, pointers) -- the stream
+    because a table is written by a kernel, and only launches of the same stream are ordered behind that write -- so that from the
+    second step on a merged launch costs no `bmc_ptr_table` launch (31x56: 130 launches per step in fp32, 298 in bf16)."""
     ptrs = []
     for s_, nb in zip(srcs, batches):
         mod = s_.batch_mod if s_.batch_mod >= 1 else 1
         ptrs.extend(s_.ptr + 4 * (((i + s_.batch_shift) % mod) * s_.batch_stride) for i in range(nb))
-    lib.call(lib._ptr_table, "bmc_ptr_table", (C.c_ulonglong * btot)(*ptrs), btot, table.data_ptr() + 8 * slot * btot, _stream())
+    st = _stream()
+    key = (dev.index, st.value if hasattr(st, "value") else st, tuple(ptrs))
+    table = _TABLES.get(key)
+    if table is None:
+        if len(_TABLES) >= 8192:
+            _TABLES.clear()
+        table = torch.empty(btot, device=dev, dtype=torch.int64)
+        lib.call(lib._ptr_table, "bmc_ptr_table", (C.c_ulonglong * btot)(*ptrs), btot, table.data_ptr(), st)
+        if not torch.cuda.is_current_stream_capturing():      # (a table made during a graph capture belongs to that graph's pool)
+            _TABLES[key] = table
     t = lib.Src()
-    t.ptr = table.data_ptr() + 8 * slot * btot
+    t.ptr = table.data_ptr()
     t.batch_stride, t.pix_stride, t.nch, t.batch_shift, t.batch_mod = 0, srcs[0].pix_stride, srcs[0].nch, 0, -1      # BMC_SRC_TABLE
-    return t
+    return t, table
 
 
 def _launch_merged(q):
@@ -702,10 +717,10 @@ def _launch_merged(q):
         btot = sum(batches)
         nx = len(items[0][1])
         with wgrad_side(npx, [q.w_param, q.b_param] if q.want_bias else [q.w_param], keep):
-            table = torch.empty((nx + 1) * btot, device=q.dev, dtype=torch.int64)
-            _on_side(table)
-            a_t = _table_src([it[0] for it in items], batches, table, 0, btot)
-            x_t = [_table_src([it[1][k] for it in items], batches, table, k + 1, btot) for k in range(nx)]
+            a_t, tab_a = _table_src([it[0] for it in items], batches, btot, q.dev)
+            x_tt = [_table_src([it[1][k] for it in items], batches, btot, q.dev) for k in range(nx)]
+            x_t = [t for t, _ in x_tt]
+            _on_side(tab_a, *[tb for _, tb in x_tt])
             r = pgemm_raw(a_t, x_t, btot, q.H, q.W, taps, btot, Cout, q.spec.kpad, q.dev,
                           flops=2.0 * btot * q.H * q.W * Cout * taps * q.spec.kreal, want_bias=q.want_bias)
             reduce_wgrad(r[0], r[1], 1, taps, Cout, q.spec, q.dev, r[3] if q.want_bias else None, q.w_param,
