@@ -445,6 +445,14 @@ def extra_infer(dev, windows=24):
             ms = sr.latency_ms(skip=6)
             rec["graph_replay" if graph else "eager"] = round(ms, 3)
         rec["frac_of_fp32_mfma_peak_graph"] = round(FLOP_PER_LRPX_FWD * H * W / (rec["graph_replay"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+        rec["state_bytes_per_sequence"] = sr.state_bytes()
+        # the recurrent feature state carried in bf16 between windows (StreamingSR(state_dtype=torch.bfloat16): half the resident
+        # bytes per sequence; a storage format -- the kernels read and write fp32)
+        sr = StreamingSR(m, 128, 4, state_dtype=torch.bfloat16)
+        for i in range(windows):
+            sr.step(frames[:, i:i + 3].transpose(1, 2))
+        rec["eager_state_bf16"] = round(sr.latency_ms(skip=6), 3)
+        rec["state_bytes_per_sequence_bf16"] = sr.state_bytes()
         out["%dx%d->%dx%d" % (H, W, 4 * H, 4 * W)] = rec
     del m
     torch.cuda.empty_cache()
