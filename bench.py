@@ -84,7 +84,8 @@ def cpu_baseline(dev=None, budget_hw=(180, 240), threads=16):
       (i)  events_to_channels on one 180x240 LR frame (24 576 events) and one 720x960 HR frame (393 216 events), numpy
            restatement, one thread -- with the GPU scatter kernel's time for the same frames beside it.
     16 threads is the measured optimum of torch-CPU on the GPU box's host for this network (8: 1.08 s, 16: 0.67 s, 32: 1.08 s,
-    64: 2.3 s, 128: 8.6 s per quarter frame).  Reported only; never the thing optimised."""
+    64: 2.3 s, 128: 8.6 s per quarter frame); `all_host_cores` carries the same window on every logical CPU of the box beside it.
+    Reported only; never the thing optimised."""
     import numpy as np
     import torch.nn.functional as F
     from models.BMCNet import BMCNet
@@ -111,6 +112,31 @@ def cpu_baseline(dev=None, budget_hw=(180, 240), threads=16):
             p.grad = None
     t = _median(times[2:])
     frames = (H * W) / (180.0 * 240.0)
+    # SURVEY 8(d) asks for the host's cores with the count stated: the same window on ALL logical CPUs of the box beside the
+    # measured optimum (torch-CPU's intra-op pool loses to its own synchronisation on this network from 32 threads up).  A quarter
+    # frame (90x120), 1 warm-up + 2 timed iterations: at 128+ threads a full frame would not fit the bounded-sample budget.
+    all_cores = None
+    ncpu = os.cpu_count() or 1
+    if ncpu > torch.get_num_threads():
+        used = torch.get_num_threads()
+        torch.set_num_threads(ncpu)
+        hq, wq = H // 2, W // 2
+        xq = torch.poisson(torch.full((1, 2, 2, hq, wq), 0.284))
+        gq = torch.poisson(torch.full((1, 2, scale * hq, scale * wq), 0.284))
+        zq = lambda c: torch.zeros(1, c, hq, wq)
+        tq = []
+        for it in range(3):
+            t0 = time.perf_counter()
+            _, _, _, pred = O.bmcnet_forward(params, xq, zq(n_c), zq(n_c), zq(n_c), zq(32), True, scale)
+            F.mse_loss(pred, gq).backward()
+            tq.append(time.perf_counter() - t0)
+            for p in seen.values():
+                p.grad = None
+        tqm = min(tq[1:])
+        all_cores = {"value": round((hq * wq) / (180.0 * 240.0) / tqm, 5), "unit": "LR-voxel-frames/s", "cores": ncpu,
+                     "sample": "the same window on a quarter frame (%dx%d), 1 warm-up + 2 timed (best %.2fs; all three: %s), %d torch threads = every "
+                               "logical CPU of the host" % (hq, wq, tqm, " ".join("%.2f" % v for v in tq), ncpu)}
+        torch.set_num_threads(used)
     # (iii) the reference's own LR frame (45x80, config/train_nfs.yml): one window forward+backward, and the FULL training-loop
     # body of train.py:202-237 -- 8 recurrent windows forward, summed MSE, one backward through all of them -- at B = 1.
     # (At 180x240 the 8-window BPTT of the CPU path keeps ~62 GB of activations -- SURVEY Appendix A.11 -- and takes > 60 s per
@@ -163,6 +189,7 @@ def cpu_baseline(dev=None, budget_hw=(180, 240), threads=16):
             "sample": "oracle/bmc_oracle.py BMCNet(4,128,5) 1 window fwd+bwd, B=1, LR %dx%d (%.2f of a 180x240 frame), "
                       "2 warm-up + 3 timed (median %.2fs; all five: %s), %d torch threads" %
                       (H, W, frames, t, " ".join("%.2f" % v for v in times), torch.get_num_threads()),
+            "all_host_cores": all_cores,
             "other_samples": legs,
             "events_to_channels": dict(ev, note="numpy restatement (oracle.events_to_channels_np), 1 thread, 2 warm-up + 3 timed "
                                                 "(median); gpu = bmc_events_to_channels, ONE frame per launch (the step batches 36 frames per launch)")}
@@ -381,6 +408,38 @@ class Workload:
         return {"H": self.H, "W": self.W, "B": self.B, "L": self.L, "n_c": self.n_c, "n_b": self.n_b}
 
 
+def pin_rank_to_cores(local_rank, world):
+    """One rank's host threads on their own share of the box's cores, BEFORE anything touches the GPU: the small-frame steps are
+    host-issue-bound (NOTEBOOK R5.9: ~15 us of Python per launch), and eight ranks whose launch threads, autograd threads and
+    OpenMP pools float over the same cores contend.  Physical cores (with their SMT siblings) are dealt out in contiguous runs --
+    contiguous core ids share a socket / NUMA node on the EPYC hosts of this pool; BMC_BENCH_PIN=0 leaves the affinity alone."""
+    if world <= 1 or os.environ.get("BMC_BENCH_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    cores, seen = [], set()
+    for c in allowed:
+        if c in seen:
+            continue
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+            ids = set()
+            for part in sib.split(","):
+                lo, _, hi = part.partition("-")
+                ids.update(range(int(lo), int(hi or lo) + 1))
+        except (OSError, ValueError):
+            ids = {c}
+        ids &= set(allowed)
+        seen |= ids
+        cores.append(sorted(ids))
+    per = len(cores) // world
+    if per < 1:
+        return None
+    mine = [c for grp in cores[local_rank * per:(local_rank + 1) * per] for c in grp]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(per, 16)))
+    return {"physical_cores": per, "logical_cpus": len(mine), "first": mine[0], "last": mine[-1]}
+
+
 def timed(fn, warmup, steps, use_dist, dev):
     """W untimed + exactly K timed steps between barrier + synchronize pairs; max over ranks."""
     loss = None
@@ -506,17 +565,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
+    pinned = pin_rank_to_cores(local_rank, world)          # (before the first GPU call of this process)
+    # Dry run of the multi-rank path on a box with ONE GPU (tests/test_gpu_r6.py): every rank on cuda:0, collectives over gloo
+    # (RCCL refuses two ranks on one device).  Never the measured configuration: the JSON line says which backend ran.
+    one_gpu = os.environ.get("BMC_BENCH_ONE_GPU") == "1"
+    backend = os.environ.get("BMC_BENCH_BACKEND", "nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the BMCNet HIP path has no CPU fallback")
-    if torch.cuda.device_count() < world:
+    if torch.cuda.device_count() < world and not one_gpu:
         raise SystemExit("bench.py: %d ranks requested but only %d GPUs visible" % (world, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or bool(os.environ.get("BMC_FORCE_DIST"))      # BMC_FORCE_DIST: exercise RCCL with 1 rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus or os.environ.get("BMC_FORCE_DIST")
     if args.graph and use_dist:
         raise SystemExit("--graph is single-GPU only")
@@ -526,8 +594,12 @@ def main():
     dist1_group = False
     if (world == 1 and not use_dist and "dist1" in args.also.split(",") and not args.graph
             and (args.batch, args.height, args.width, args.seql, args.n_c, args.n_b) == (4, 180, 240, 9, 128, 5)):
+        import socket
+        with socket.socket() as sk:              # (a free port: two bench runs on one box must not meet on a fixed one)
+            sk.bind(("127.0.0.1", 0))
+            free_port = sk.getsockname()[1]
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("MASTER_PORT", str(free_port))
         try:
             dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
             dist.barrier()
@@ -549,6 +621,8 @@ def main():
         with torch.no_grad():
             ck = torch.stack([torch.cat([p.detach().double().reshape(-1) for p in wl.model.parameters()]).sum(),
                               torch.cat([p.detach().double().abs().reshape(-1) for p in wl.model.parameters()]).sum()])
+        if backend != "nccl":
+            ck = ck.cpu()                        # (gloo gathers host tensors)
         allck = [torch.zeros_like(ck) for _ in range(dist.get_world_size())]
         dist.all_gather(allck, ck)
         lockstep = all(torch.equal(allck[0], c) for c in allck)
@@ -585,7 +659,9 @@ def main():
             "config": {"workload": workload_string(n_c, n_b, H, W, B, L, args.math, dist_on=use_dist, recompute=args.recompute, graph=args.graph),
                        "global_batch": world * B, "frames_per_step": frames_per_step,
                        "parallelism": "dp%d" % world, "rccl_ranks": dist.get_world_size() if use_dist else 1,
-                       "ranks_in_lock_step": lockstep,
+                       "collective_backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend + " [dry run, not a measurement]") if use_dist else None,
+                       "ranks_in_lock_step": lockstep, "rank_cpu_pinning": pinned,
+                       "rccl_initialised_before_headline_run": bool(dist1_group) or (use_dist and backend == "nccl"),
                        "peak_mem_GiB": round(peak_mem, 1),
                        "final_loss": round(float(loss), 6)},
             "roofline": roof,

@@ -662,20 +662,33 @@ class _MergeQueue:
             spec, dev, w_param, b_param, want_bias, k0, full, H, W, window, pg      # pg: (taps, Cout, w_shape) of a pixel-reduction queue
 
 
-_MERGE = {}                  # (id(w_param), k0, H, W, want_bias) -> _MergeQueue
-_MERGE_TASK = [-1]           # the autograd graph task whose end-of-pass flush is queued
-_MERGE_OWNER = [-1]          # the graph task that queued what is in _MERGE
+# Queues belong to the autograd graph task (backward pass) that filled them: a nested pass -- torch.utils.checkpoint(use_reentrant=True),
+# a Function whose backward calls autograd.backward -- has its own task id, its own queues and its own end-of-pass flush, and neither
+# launches nor drops what the pass around it has queued.  Queues of a pass that RAISED (it never flushes) are dropped by wgrad_join()
+# once no backward pass is running.
+_MERGE = {}                  # graph task id -> {(id(w_param), k0, H, W, want_bias) -> _MergeQueue}
+_FLUSH_QUEUED = set()        # graph tasks whose end-of-pass flush is queued
+PTR_TABLE_MAX = 256          # csrc/stream_ops.hip: bmc_ptr_table takes its pointers by value in the argument block
 
 
-def flush_wgrads():
-    """Launch every queued weight gradient (idempotent)."""
-    if not _MERGE:
+def flush_wgrads(task=None):
+    """Launch every weight gradient queued by the graph task `task` (default: the running one); idempotent."""
+    if task is None:
+        task = torch._C._current_graph_task_id()
+    _FLUSH_QUEUED.discard(task)
+    qs = _MERGE.pop(task, None)
+    if not qs:
         return
-    qs = list(_MERGE.values())
-    _MERGE.clear()
-    for q in qs:
+    for q in list(qs.values()):
         if q.items:
             _launch_merged(q)
+
+
+def _queue_flush(task):
+    """The end-of-pass flush of graph task `task`, queued once (the engine runs a task's callbacks in the order they were queued)."""
+    if task not in _FLUSH_QUEUED:
+        _FLUSH_QUEUED.add(task)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_wgrads(task))
 
 
 _TABLES = {}      # (stream, image pointers) -> device table holding exactly those pointers
@@ -733,16 +746,16 @@ def _launch_merged(q):
 
 def _queue_use(key, make_queue, item, task, npx):
     """Append one use to its merge queue (created by make_queue() if new / stale) and launch the queue when it is full."""
-    q = _MERGE.get(key)
+    qs = _MERGE.setdefault(task, {})
+    q = qs.get(key)
     if q is None or q.w_param is not item[4] or q.window != item[5]:       # (another window's uses: the old queue leaves first)
         if q is not None and q.items:
             _launch_merged(q)
-        q = _MERGE[key] = make_queue()
-    if _MERGE_TASK[0] != task:       # the first queued use of this backward pass: flush what is left when the pass ends
-        _MERGE_TASK[0] = task
-        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+        q = qs[key] = make_queue()
+    if q.pg is not None and q.items and sum(it[2] for it in q.items) + item[2] > PTR_TABLE_MAX:
+        _launch_merged(q)            # (a pointer table holds PTR_TABLE_MAX images: what is queued leaves before this use joins)
+    _queue_flush(task)               # the first queued use of this backward pass: flush what is left when the pass ends
     _side_arm(npx)                   # (the pass's side-stream decision is made by its first USE, as without the queue)
-    _MERGE_OWNER[0] = task
     q.items.append(item[:4])
     if len(q.items) >= WGRAD_MERGE:
         _launch_merged(q)
@@ -750,8 +763,6 @@ def _queue_use(key, make_queue, item, task, npx):
 
 def _mergeable(B, H, W, w_param, b_param, want_bias, keep, window):
     task = torch._C._current_graph_task_id()
-    if task >= 0 and _MERGE and _MERGE_OWNER[0] != task:
-        _MERGE.clear()                   # uses queued by a backward pass that raised (a pass that ends flushes its own): dropped
     ok = (WGRAD_MERGE > 1 and window is not None and B * H * W <= WGRAD_MERGE_MAX_PIXELS and task >= 0 and w_param is not None
           and not isinstance(w_param, (tuple, list)) and is_sink(w_param) and (not want_bias or is_sink(b_param)) and keep
           and not torch.cuda.is_current_stream_capturing())
@@ -764,7 +775,7 @@ def wgrad_pgemm(a_src, x_srcs, B, H, W, taps, Cout, spec, dev, w_param, b_param,
     per-image pointer tables (bmc_src_t BMC_SRC_TABLE; bmc_ptr_table)."""
     if G == 1:
         ok, task = _mergeable(B, H, W, w_param, b_param, want_bias, keep, window)
-        if ok and all(x.batch_mod != -1 for x in x_srcs) and a_src.batch_mod != -1:
+        if ok and B <= PTR_TABLE_MAX and all(x.batch_mod != -1 for x in x_srcs) and a_src.batch_mod != -1:
             key = (id(w_param), "pg", taps, len(x_srcs), H, W, bool(want_bias))
             _queue_use(key, lambda: _MergeQueue(spec, dev, w_param, b_param, want_bias, None, spec.covers_all, H, W, window,
                                                 pg=(taps, Cout, w_shape)),
@@ -1063,6 +1074,8 @@ def wgrad_join():
         # its own queues).  Its gradients are undefined anyway; launching them NOW would add them to whatever .grad holds after
         # the caller's zero_grad -- they are dropped
         _MERGE.clear()
+    if cur < 0:
+        _FLUSH_QUEUED.clear()
     for st in _SIDE.values():
         if st.armed and (cur < 0 or st.task != cur):      # (a forward recomputed INSIDE the pass that armed it: nothing to join)
             st.join()
@@ -1132,9 +1145,7 @@ def _side_arm(npx):
         #  82.3 ms eager and 88 ms for the one-stream graph; "1" forces it)
         st.side = WGRAD_SIDE == "1" or (MATH == 0 and npx >= WGRAD_SIDE_MIN_PIXELS and not torch.cuda.is_current_stream_capturing())
         # (end-of-pass callbacks run in the order they were queued: what is left in the merge queues leaves BEFORE the join)
-        if _MERGE_TASK[0] != task:
-            _MERGE_TASK[0] = task
-            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+        _queue_flush(task)
         torch.autograd.Variable._execution_engine.queue_callback(st.join)
         st.armed = True
     return st

@@ -46,11 +46,16 @@ class GradAllReducer:
         self.seen = set()            # parameters whose hook fired since the last finish()
         self.deferred = False        # a second backward before step() was detected (gradient accumulation)
         self.cuda = dev.type == "cuda"
+        self.dev = dev               # named in every current_stream() below: hooks run on autograd's device threads, whose
+                                     # current device need not be the model's on a multi-GPU process
         self.side = torch.cuda.Stream(device=dev) if self.cuda else None
         # gloo with device buckets (the world-size-2 test of the HIP path on ONE GPU; RCCL refuses two ranks on one device):
         # the bucket travels through host memory -- independent of whether this gloo build takes device tensors
         self.host_stage = self.cuda and dist.is_initialized() and dist.get_backend(group) == "gloo"
         self._handles = []
+        # The parameters (and the optimizer's pre-step hook) hold the reducer through these hooks: it lives as long as the model
+        # does, whether or not the caller keeps a reference -- `GradAllReducer(model, opt)` as a bare statement is a complete
+        # set-up.  Dropping the caller's reference therefore does NOT end it: detach() does.
         for p in self.params:
             # bmc_hip.ops.is_sink: OUR hook does not need the autograd route (finish() stages sink gradients) -- but somebody
             # else's hook on the parameter (clipping, logging, a second reducer) does: such a parameter keeps the autograd
@@ -66,7 +71,8 @@ class GradAllReducer:
 
     def detach(self):
         """Undo the constructor: hooks removed, the parameters no longer marked for the kernels' sink route on this reducer's
-        behalf (a model that outlives its reducer must not keep bypassing autograd for hooks registered later)."""
+        behalf (a model that outlives its reducer must not keep bypassing autograd for hooks registered later).  The ONLY way to
+        end a reducer: its hooks keep it alive as long as the model lives (see the constructor), so `del reducer` changes nothing."""
         for p, h in zip(self.params, self._handles):
             getattr(p, "_bmc_sink_hooks", set()).discard(h.id)
             h.remove()
@@ -74,14 +80,6 @@ class GradAllReducer:
         if self._step_hook is not None:
             self._step_hook.remove()
             self._step_hook = None
-
-    def __del__(self):
-        # a reducer that is dropped without detach(): its hook ids must not keep vouching for whatever hook is registered next
-        try:
-            for p, h in zip(self.params, self._handles):
-                getattr(p, "_bmc_sink_hooks", set()).discard(h.id)
-        except Exception:
-            pass
 
     # -- called by autograd once per parameter per backward, after all its uses have been accumulated
     def _on_grad(self, p):
@@ -111,7 +109,7 @@ class GradAllReducer:
                 w.wait()
                 self.works[i] = None
         if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.side)
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
 
     def _launch(self, bi):
         if not dist.is_initialized():
@@ -122,7 +120,7 @@ class GradAllReducer:
             self.flat[bi].copy_(host)
             return
         if self.cuda:
-            self.side.wait_stream(torch.cuda.current_stream())
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(self.side):
                 self.works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
@@ -152,7 +150,7 @@ class GradAllReducer:
             if w is not None:
                 w.wait(); self.works[bi] = None
             if launched and self.cuda:
-                torch.cuda.current_stream().wait_stream(self.side)
+                torch.cuda.current_stream(self.dev).wait_stream(self.side)
             for p in self.buckets[bi]:
                 o = self.slot[p][1]
                 dst = self.flat[bi][o:o + p.numel()]

@@ -49,6 +49,11 @@
 #ifndef BMC_W4_DPRIO
 #define BMC_W4_DPRIO 5       // wave priority by position in the chunk (below: the chunk's pair loop); 0 = none, other values: the variants measured in NOTEBOOK.md R5.11
 #endif
+#ifndef BMC_W4_IL
+#define BMC_W4_IL 1        // 1: the pair loop issues its side work (LDS reads, U requests, halo pieces, producer arithmetic) BETWEEN the pair's
+                           // eight MFMAs, one or two instructions per MFMA gap (round 6); 0: round 4/5's form -- reads, eight MFMAs back to back,
+                           // then requests and arithmetic
+#endif
 #ifndef BMC_W4_XP
 #define BMC_W4_XP 0        // experiments (tools/ builds only; results are wrong by design): 2 waves w and w + 4 stream the SAME rows of
                            // U (does the CU's L1 serve the SIMD partner's copy?), 3 every second U request left out (half the stream)
@@ -58,12 +63,20 @@
                            // 16 no V production, 32 no V fragment reads, 64 no barriers, 128 no output transform
 #endif
 
+#ifdef BMC_W4_CLK        // diagnostic build (tools/ only): ONLY the two stamps around the whole kernel (cycles and wall time of every
+#define BMC_W4_STAMP     // workgroup -> the clock the chip holds under this kernel), nothing inside the loops
+#endif
 #ifdef BMC_W4_STAMP      // diagnostic build (tools/ only): per-workgroup cycle stamps, read back with bmc_w4_read_stamps
 __device__ unsigned long long g_w4_stamp[1024][16];
-#define W4_STAMP(i) do { if (threadIdx.x == 0 && (i) < 14) g_w4_stamp[blockIdx.x][(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 // per-wave stamps of workgroup 8 (an XCD-0 workgroup), first 24 chunks: [wave][chunk][k]
 __device__ unsigned long long g_w4_wstamp[8][24][8];
+#ifdef BMC_W4_CLK
+#define W4_STAMP(i) do { } while (0)
+#define W4_WSTAMP(chunk, k) do { } while (0)
+#else
+#define W4_STAMP(i) do { if (threadIdx.x == 0 && (i) < 14) g_w4_stamp[blockIdx.x][(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define W4_WSTAMP(chunk, k) do { if (blockIdx.x == 8 && (threadIdx.x & 63) == 0 && (chunk) < 24) g_w4_wstamp[threadIdx.x >> 6][(chunk)][(k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #else
 #define W4_STAMP(i) do { } while (0)
 #define W4_WSTAMP(chunk, k) do { } while (0)
@@ -134,13 +147,19 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
 #ifndef BMC_W4_DP
 #define BMC_W4_DP 6
 #endif
-    constexpr int D = LOADER ? 12 : BMC_W4_DP;        // positions of U in flight
+#ifndef BMC_W4_DL
+#define BMC_W4_DL 12       // (a ring depth must divide the 36 positions of a chunk: position p lives in slot p % D across chunks)
+#endif
+    constexpr int D = LOADER ? BMC_W4_DL : BMC_W4_DP;        // positions of U in flight
     constexpr int XLAST = (PPW - 1) / 2;      // the pairs 0 .. XLAST of a chunk issue the halo pieces 2 pp, 2 pp + 1
     static_assert(2 * (NPOS / 2 - XLAST - 1) >= PPW && XLAST + D / 2 + 1 < NPOS / 2, "table rebuild / landing fit behind the pieces");
-    // halo pieces issued behind the requests of the pairs pp - D / 2 .. pp - 1 (pair indices modulo the chunk)
+    static_assert(NPOS % D == 0 && D % 2 == 0, "position p of every chunk lives in ring slot p % D");
+    // halo pieces issued behind the requests of the pairs pp - D / 2 .. pp - 1 (pair indices modulo the chunk).  (Interleaved form:
+    // a pair issues its pieces IN FRONT of its requests -- gaps 4-5, then 6-7 -- so the pieces of pair pp - D / 2 are older than
+    // its requests and do not count.)
     auto xyounger = [](int pp) {
         int n = 0;
-        for (int j = pp - D / 2; j < pp; ++j) {
+        for (int j = pp - D / 2 + (BMC_W4_IL ? 1 : 0); j < pp; ++j) {
             const int jj = (j + NPOS / 2) % (NPOS / 2);
             n += jj > XLAST ? 0 : (2 * jj + 1 < PPW ? 2 : 1);
         }
@@ -245,21 +264,33 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     // offsets live in registers and change only with the tile or the source (pixel stride): recomputed from the table then,
     // at the top of a chunk (read from LDS per piece, each piece paid an LDS round trip + address arithmetic in front of its
     // DMA: ~400 cycles per piece, stamps)
-    unsigned xoff[PPW];
+    // (interleaved form: the LAST PPW - KREG offsets are not kept -- with a halo piece issued in the middle of a pair, all 17 beside
+    //  144 accumulators, 12 ring slots and both V fragment buffers are 4 registers too many, and a scratch reload in front of a
+    //  piece waits for every request in flight.  Those pieces take their offset from the table one pair ahead: xoj_*)
+    constexpr int KREG = BMC_W4_IL ? 12 : PPW;
+    unsigned xoff[KREG];
     bool xl_newoff = true;
     auto offsets_from_table = [&]() {
         const int l = lane_now();
 #pragma unroll
-        for (int k = 0; k < PPW; ++k) {
+        for (int k = 0; k < KREG; ++k) {
             const int e = xtab[(wl * PPW + k) * 64 + l];
             xoff[k] = __umul24((unsigned)(e >> 2), (unsigned)x_stride4) + (unsigned)(e & 3) * 16u;
         }
         xl_newoff = false;
     };
+    int xoj_e[2] = {0, 0};                            // table entries of the two pieces the NEXT pair issues (k >= KREG)
+    auto xoj_fetch = [&](int k, int slot) __attribute__((always_inline)) {
+        const int l = lane_now();
+        xoj_e[slot] = xtab[(wl * PPW + k) * 64 + l];
+    };
     auto load_x_piece = [&](int k) __attribute__((always_inline)) {
         const unsigned la = xb_lds + (unsigned)((xl_buf * XBUFA + (wl * PPW + k) * 256) * 4);
+        unsigned off;
+        if (k < KREG) off = xoff[k < KREG ? k : 0];
+        else { const int e = xoj_e[k & 1]; off = __umul24((unsigned)(e >> 2), (unsigned)x_stride4) + (unsigned)(e & 3) * 16u; }
         if (!(BMC_W4_ABL & 4))
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(xoff[k]), "s"(sbase + c_in), "s"(la) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(sbase + c_in), "s"(la) : "memory");
     };
     auto load_x_begin = [&]() {
         if (xl_rebuild) { xzm = xzm_next; xl_rebuild = false; }
@@ -286,7 +317,10 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     auto load_x_all = [&]() {                         // prologue: a whole strip at once
         load_x_begin();
 #pragma unroll
-        for (int k = 0; k < PPW; ++k) load_x_piece(k);
+        for (int k = 0; k < PPW; ++k) {
+            if (k >= KREG) xoj_fetch(k, k & 1);
+            load_x_piece(k);
+        }
         load_x_advance();
         if (xl_rebuild) {
 #pragma unroll 1
@@ -334,6 +368,12 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
 #pragma unroll
         for (int k = 0; k < 4; ++k) d[k] = *reinterpret_cast<const f32x2p*>(xb + prow[k] + c * RS + 2 * h);
     };
+    auto prod_ld = [&](const float* xb, int h, int c, int k, f32x2p (&d)[4]) __attribute__((always_inline)) {
+        d[k] = *reinterpret_cast<const f32x2p*>(xb + prow[k] + c * RS + 2 * h);
+    };
+    // (an `asm volatile` that rewrites a value in place fixes WHERE the arithmetic producing it is emitted: instruction selection
+    //  otherwise sinks pure arithmetic to its first use, across every sched_barrier)
+    auto pin2 = [](f32x2p& x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); };
     auto prod_fma = [&](int c, const f32x2p (&d)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) pt[c][e] = __builtin_fmaf(pk3, d[3][e], __builtin_fmaf(pk2, d[2][e], __builtin_fmaf(pk1, d[1][e], pk0 * d[0][e])));
@@ -358,6 +398,49 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
             pt[3][e] = __builtin_fmaf(2.f, te[e], tc[e]);
             pt[4][e] = __builtin_fmaf(-2.f, te[e], tc[e]);
         }
+    };
+    // the same in pieces (interleaved form: one piece per MFMA gap); the order of the operations -- and so every rounding -- is prod_fma's
+    auto prod_fma_a = [&](int c, const f32x2p (&d)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) pt[c][e] = __builtin_fmaf(pk1, d[1][e], pk0 * d[0][e]);
+    };
+    auto prod_fma_b = [&](int c, const f32x2p (&d)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) pt[c][e] = __builtin_fmaf(pk3, d[3][e], __builtin_fmaf(pk2, d[2][e], pt[c][e]));
+    };
+    auto prod_row_a1 = [&](f32x2p& ta, f32x2p& tb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { ta[e] = __builtin_fmaf(-4.f, pt[2][e], pt[4][e]); tb[e] = __builtin_fmaf(-4.f, pt[1][e], pt[3][e]); }
+    };
+    auto prod_row_a2 = [&](f32x2p& tc, f32x2p& te) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { tc[e] = pt[4][e] - pt[2][e]; te[e] = pt[3][e] - pt[1][e]; }
+    };
+    auto prod_row_a3 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) pt[0][e] = __builtin_fmaf(4.f, pt[0][e], __builtin_fmaf(-5.f, pt[2][e], pt[4][e]));
+    };
+    auto prod_row_a4 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) pt[5][e] = __builtin_fmaf(4.f, pt[1][e], __builtin_fmaf(-5.f, pt[3][e], pt[5][e]));
+    };
+    auto prod_row_b1 = [&](const f32x2p& ta, const f32x2p& tb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { pt[1][e] = ta[e] + tb[e]; pt[2][e] = ta[e] - tb[e]; }
+    };
+    auto prod_row_b2 = [&](const f32x2p& tc, const f32x2p& te) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { pt[3][e] = __builtin_fmaf(2.f, te[e], tc[e]); pt[4][e] = __builtin_fmaf(-2.f, te[e], tc[e]); }
+    };
+    auto prod_addr = [&]() __attribute__((always_inline)) {
+        const int l = lane_now();
+        int vst = xi * 6 * NT * CK + (l >> 2) * CK + (((l & 3) ^ swz(l >> 2)) * 4);
+        asm volatile("" : "+v"(vst));
+        return vst;
+    };
+    auto prod_store_at = [&](float* vb, int vst, int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x2p*>(vb + vst + nu * NT * CK + 2 * h) = pt[nu];
     };
     auto prod_store = [&](float* vb, int h) __attribute__((always_inline)) {
         const int l = lane_now();
@@ -386,7 +469,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
             v[i] = *reinterpret_cast<const f32x4*>(vb + (2 * pair + i) * NT * CK + voff);
         }
     };
-    auto mfma8 = [&](f32x4& c0, f32x4& c1, const f32x4& u0, const f32x4& u1, const f32x4 (&v)[2]) __attribute__((always_inline)) {
+    [[maybe_unused]] auto mfma8 = [&](f32x4& c0, f32x4& c1, const f32x4& u0, const f32x4& u1, const f32x4 (&v)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             if (BMC_W4_ABL & 1) { c0[m] += u0[m] * v[0][m]; c1[m] += u1[m] * v[1][m]; continue; }
@@ -407,6 +490,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
             constexpr int pp = decltype(ic)::value;
             constexpr int ph = pp >= PH0 + 8 ? 1 : 0, ps = pp - PH0 - 8 * ph;      // half, step within it (valid for PH0 <= pp < PH0 + 16)
             const bool pact = !LOADER && !(BMC_W4_ABL & 16) && pp >= PH0 && pp < PH0 + 16;
+            constexpr int psc = ps < 0 ? 0 : (ps > 5 ? 5 : ps);        // (ps where it names a patch column; dead code otherwise)
             const int p0 = 2 * pp, p1 = p0 + 1, s0 = p0 % D, s1 = p1 % D;
             // U(p0), U(p1) have landed: younger are the D - 2 requests behind them and, on a loader wave, the halo pieces
             // issued since (behind the requests of pairs pp - D / 2 .. pp - 1: xyounger)
@@ -443,6 +527,95 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
 #endif
             if (LOADER) uwait_n(D - 2 + xyounger(pp), ur[s0], ur[s1]); else uwait<D - 2>(ur[s0], ur[s1]);
             if (LOADER && pp == XLAST + D / 2 + 1) zero_x(gbuf);     // (the wait above was the first behind the strip's last piece: it has landed)
+#if BMC_W4_IL
+            // ---- interleaved form.  A wave issues in order: behind eight back-to-back MFMAs its requests, LDS reads and arithmetic
+            // run with NO matrix instruction of its own in the pipe, so whenever the SIMD partner is not multiplying at that moment
+            // (it is parked at the barrier, waits for U, or has reached the same point of the same program) the pipe idles.  Here
+            // every MFMA is followed by one or two of those instructions (an MFMA holds the SIMD's issue for 8 of its 32 cycles):
+            // a wave keeps the pipe busy by itself.  Gaps 0-1: the producer's patch reads; 2-3: the next pair's V fragments;
+            // 4-5: the loaders' halo pieces; 6-7: the U requests into the two ring slots this pair has just consumed, and the
+            // producer's arithmetic on what gaps 0-1 read.
+            if (pp == NPOS / 2 - 1) {
+                // the chunk's barrier sits in front of its LAST pair (see the other form)
+                W4_WSTAMP(gcx, 4);
+                if (BMC_W4_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else ring_publish();
+                W4_WSTAMP(gcx, 5);
+            }
+            if (pp == 0) W4_WSTAMP(gcx, 0);
+            if (pp == 1) W4_WSTAMP(gcx, 1);
+            if (pp == 7) W4_WSTAMP(gcx, 2);
+            if (pp == 12) W4_WSTAMP(gcx, 3);
+            if (LOADER && pp == 0) load_x_begin();      // (may branch: a new tile's or source's offsets)
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const f32x4 (&v)[2] = vf[pp & 1];
+                f32x4 (&vn)[2] = vf[(pp + 1) & 1];
+                const float* const vnb = pp < NPOS / 2 - 1 ? vb + (2 * pp + 2) * NT * CK + voff : vbn + voff;
+                const bool vread = !(BMC_W4_ABL & 32);
+                auto mf = [&](f32x4& c, float u, float x) __attribute__((always_inline)) {
+                    if (BMC_W4_ABL & 1) c[0] += u * x; else c = __builtin_amdgcn_mfma_f32_16x16x4f32(u, x, c, 0, 0, 0);
+                };
+                const int q0 = p0 + D;
+                const float* const ub = q0 < NPOS ? ucur + (q0 / 4) * 1024 : unx + ((q0 - NPOS) / 4) * 1024;
+                const bool lo = (q0 % NPOS) % 4 == 0;
+                // gap 0
+                mf(acc[p0], ur[s0][0], v[0][0]);
+                if (pact && ps < 6) { prod_ld(xbn, ph, psc, 0, pd); prod_ld(xbn, ph, psc, 1, pd); }
+                if (pact && ps == 6) { prod_row_a1(ta, tb); pin2(ta); pin2(tb); }
+                if (pact && ps == 7) { prod_row_b1(ta, tb); pin2(pt[1]); pin2(pt[2]); }
+                __builtin_amdgcn_sched_barrier(0);
+                // gap 1
+                mf(acc[p1], ur[s1][0], v[1][0]);
+                if (pact && ps < 6) { prod_ld(xbn, ph, psc, 2, pd); prod_ld(xbn, ph, psc, 3, pd); }
+                if (pact && ps == 6) { prod_row_a2(tc, te); pin2(tc); pin2(te); }
+                if (pact && ps == 7) { prod_row_b2(tc, te); pin2(pt[3]); pin2(pt[4]); }
+                __builtin_amdgcn_sched_barrier(0);
+                // gap 2
+                mf(acc[p0], ur[s0][1], v[0][1]);
+                if (vread) vn[0] = *reinterpret_cast<const f32x4*>(vnb);
+                else { vn[0] = f32x4{4.f, 3.f, 2.f, 1.f}; asm volatile("" : "+v"(vn[0])); }
+                if (pact && ps == 6) { prod_row_a3(); pin2(pt[0]); }
+                __builtin_amdgcn_sched_barrier(0);
+                // gap 3
+                mf(acc[p1], ur[s1][1], v[1][1]);
+                if (vread) vn[1] = *reinterpret_cast<const f32x4*>(vnb + NT * CK);
+                else { vn[1] = f32x4{4.f, 3.f, 2.f, 1.f}; asm volatile("" : "+v"(vn[1])); }
+                if (pact && ps == 6) { prod_row_a4(); pin2(pt[5]); }
+                __builtin_amdgcn_sched_barrier(0);
+                // gap 4
+                mf(acc[p0], ur[s0][2], v[0][2]);
+                if (LOADER && pp <= XLAST) load_x_piece(2 * pp);
+                int vst = 0;
+                if (pact && ps == 7) vst = prod_addr();
+                __builtin_amdgcn_sched_barrier(0);
+                // gap 5
+                mf(acc[p1], ur[s1][2], v[1][2]);
+                if (LOADER && pp <= XLAST && 2 * pp + 1 < PPW) load_x_piece(2 * pp + 1);
+                if (pact && ps == 7) prod_store_at(vbn, vst, ph);
+                __builtin_amdgcn_sched_barrier(0);
+                // gap 6
+                mf(acc[p0], ur[s0][3], v[0][3]);
+                if (lo) uload<0>(ur[s0], ub, uvoff); else uload<2048>(ur[s0], ub, uvoff);
+                // (the table entries of the NEXT pair's two pieces, behind this pair's: one slot each)
+                if (LOADER && pp + 1 <= XLAST && 2 * (pp + 1) >= KREG) xoj_fetch(2 * (pp + 1), 0);
+                if (pact && ps < 6) { prod_fma_a(psc, pd); pin2(pt[psc]); }
+                __builtin_amdgcn_sched_barrier(0);
+                // gap 7
+                mf(acc[p1], ur[s1][3], v[1][3]);
+                if (BMC_W4_XP != 3) { if (lo) uload<1024>(ur[s1], ub, uvoff); else uload<3072>(ur[s1], ub, uvoff); }
+                if (LOADER && pp + 1 <= XLAST && 2 * (pp + 1) + 1 >= KREG && 2 * (pp + 1) + 1 < PPW) xoj_fetch(2 * (pp + 1) + 1, 1);
+                if (pact && ps < 6) { prod_fma_b(psc, pd); pin2(pt[psc]); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (LOADER) {
+                    if (pp == XLAST + 1) load_x_advance();
+                    if (pp > XLAST && xl_rebuild) {       // a new tile: its table, two pieces per pair
+                        const int k = 2 * (pp - XLAST - 1);
+                        if (k < PPW) table_piece(k);
+                        if (k + 1 < PPW) table_piece(k + 1);
+                    }
+                }
+            }
+#else
             __builtin_amdgcn_sched_barrier(0);
             if (pp < NPOS / 2 - 1) read_v(vb, pp + 1, vf[(pp + 1) & 1]);
             if (pact && ps < 6) prod_col(xbn, ph, ps, pd);
@@ -505,6 +678,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
                 if (ps == 6) prod_row_a(ta, tb, tc, te);
                 if (ps == 7) { prod_row_b(ta, tb, tc, te); prod_store(vbn, ph); }
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -638,7 +812,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     init_acc();
     read_v(Vb, 0, vf[0]);
     W4_STAMP(1);
-    int stamp_i = 2;
+    [[maybe_unused]] int stamp_i = 2;
 
     // ---------------------------------------------------------------- main loop
     // The streams never stop: past the workgroup's last tile the loaders and the producers work on that tile again (valid

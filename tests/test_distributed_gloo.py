@@ -400,3 +400,31 @@ def test_hooked_parameters_keep_the_autograd_route():
     net2.c.register_post_accumulate_grad_hook(lambda p: None)
     assert not ops.is_sink(net2.c)
     red3.detach()
+
+
+def test_reducer_lives_with_the_model_until_detach():
+    """round 5's `__del__` claimed to clean up after a reducer dropped without detach(); it never ran, because the
+    parameters hold the reducer through its hooks.  That lifetime is the contract now (a bare `GradAllReducer(model, opt)` statement
+    is a complete set-up -- _worker above relies on it): dropping the caller's reference changes nothing, detach() ends it."""
+    import gc
+    import weakref
+    sys.path.insert(0, os.path.join(ROOT, "bmcnet-esr_amd"))
+    from bmc_hip import ops
+    from bmc_hip.parallel import GradAllReducer
+    ops.set_accumulate_param_grads(True)
+    net = SinkNet()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    red = GradAllReducer(net, opt)
+    assert not hasattr(GradAllReducer, "__del__")
+    wr = weakref.ref(red)
+    del red
+    gc.collect()
+    assert wr() is not None                                           # the model's hooks keep it
+    assert all(len(p._bmc_sink_hooks) == 1 and len(p._post_accumulate_grad_hooks) == 1 for p in net.parameters())
+    net(torch.randn(4, 8)).sum().backward()
+    opt.step()                                                        # finish() ran from the pre-step hook
+    assert not wr().seen
+    wr().detach()
+    gc.collect()
+    assert wr() is None
+    assert all(not p._bmc_sink_hooks and not p._post_accumulate_grad_hooks for p in net.parameters())
