@@ -92,6 +92,13 @@ class GradAllReducer:
         self.seen.add(p)
         if self.deferred:
             return
+        if p.grad is None:
+            # autograd ran this parameter's AccumulateGrad node with an UNDEFINED gradient (every use of it handed autograd None: the
+            # kernels add its gradient straight into .grad -- bmc_hip.ops.sink_group) and none of those adds has been launched yet:
+            # merged weight gradients (ops.wgrad_wino / wgrad_pgemm) are still queued and leave at the end of the pass.  finish()
+            # stages the bucket from .grad.  (Found by `bench.py --gpus 2` at 31x56, tests/test_gpu_r6.py: round 5's merge queues and
+            # the reducer had never met.)
+            return
         if getattr(p, "_bmc_sink_touched", False):
             # a kernel has already added into this parameter's .grad during THIS backward (bmc_hip.ops.sink_group) and now
             # autograd accumulates into it too: more sink adds may follow, so the bucket is not complete when its hook

@@ -54,6 +54,10 @@
                            // eight MFMAs, one or two instructions per MFMA gap (round 6); 0: round 4/5's form -- reads, eight MFMAs back to back,
                            // then requests and arithmetic
 #endif
+#ifndef BMC_W4_EPI
+#define BMC_W4_EPI 0       // 0: all arithmetic, then all loads, then the 16 stores; 1: output transform, operand loads and stores row by row
+                           // (round 6: measured 0.7 % SLOWER -- 0.3230 / 0.3537 against 0.3208 / 0.3513 ms, three alternating rounds; kept for the record)
+#endif
 #ifndef BMC_W4_XP
 #define BMC_W4_XP 0        // experiments (tools/ builds only; results are wrong by design): 2 waves w and w + 4 stream the SAME rows of
                            // U (does the CU's L1 serve the SIMD partner's copy?), 3 every second U request left out (half the stream)
@@ -83,6 +87,8 @@ __device__ unsigned long long g_w4_wstamp[8][24][8];
 #endif
 
 namespace {
+
+__device__ float g_w4_trash[4];        // where the epilogue's lanes outside the image store (never read)
 
 constexpr int CK = BMC_CK;
 constexpr int NT = 16, NPOS = 36, BN = 128;
@@ -686,6 +692,119 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     int ep_b = -1;
     const float* ep_res = nullptr;
     const float* ep_mask = nullptr;
+#if BMC_W4_EPI
+    // Output transform Y = A^T M A (rows of A^T: (1 1 1 1 1 0) (0 1 -1 2 -2 0) (0 1 1 4 4 0) (0 1 -1 8 -8 1)) + bias / residual / ReLU / mask /
+    // accumulate + stores.  Columns first, in place; then ROW BY ROW: the row's operand loads (residual / mask / previous output) go out
+    // first and land under the row's arithmetic, and its four stores follow at once -- the 16 stores of a wave leave over the length of
+    // the row pass instead of as one burst behind it.  (One burst of 8 x 16 KB per workgroup occupies the CU's one in-order vector-memory
+    // path for ~2 k cycles, and every U request of the next tile's first pairs queues behind it: without the stores the kernel ran 12 %
+    // fewer cycles, twice the epilogue's own length -- round 6's ablation at the sustained clock.)  Every element sees the same
+    // operations in the same order as before: bit-identical results.
+    auto epilogue = [&](const W4Tile& it) __attribute__((always_inline)) {
+        pin_acc();
+        if (!(BMC_W4_ABL & 128)) {
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) {
+                const f32x4 m0 = acc[nu], m1 = acc[6 + nu], m2 = acc[12 + nu], m3 = acc[18 + nu], m4 = acc[24 + nu], m5 = acc[30 + nu];
+                const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                acc[nu] = (m0 + s1) + s2;
+                acc[6 + nu] = d1 + 2.f * d2;
+                acc[12 + nu] = s1 + 4.f * s2;
+                acc[18 + nu] = (d1 + 8.f * d2) + m5;
+            }
+        }
+        pin_acc();
+        __builtin_amdgcn_sched_barrier(0);          // (phases are not interleaved: every one of them alone fits the register file)
+        const int g = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
+        const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
+        float* const outb = a.out + (long long)it.b * a.out_batch_stride;
+        if (it.b != ep_b) {
+            ep_b = it.b;
+            ep_res = a.residual.ptr ? src_batch_ptr(a.residual, it.b) : nullptr;
+            ep_mask = a.mask.ptr ? src_batch_ptr(a.mask, it.b) : nullptr;
+        }
+        const float* const resb = ep_res;
+        const float* const maskb = ep_mask;
+        // (lane index re-derived: the epilogue's lane-dependent values must not be kept -- or spilled -- across the chunks; a
+        //  scratch reload inside the chunk loop waits, in order, for every weight request in flight)
+        int eln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(eln));
+        const int elj = eln & 15, elk = eln >> 4;
+        const int co = it.nt * BN + 16 * wave + 4 * elk;
+        const bool cok = co < a.Cout;
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (biasg && cok) bq = ldg16(biasg + co);
+        const int T = it.wt * NT + elj;
+        const int ty = T / a.tiles_x, tx = T - ty * a.tiles_x;
+        const int y0 = 4 * ty, x0 = 4 * tx;
+        const int pix0 = y0 * a.W + x0;
+        // pixel (i, j) of the tile: in the image?  (tiles past the image's last one have ty >= tiles_y: y0 >= H)
+        auto pok = [&](int i, int j) { return cok && y0 + i < a.H && x0 + j < a.W; };
+        // (no per-lane branches in here: a pixel outside the image LOADS the operand's first quad -- whatever it computes is not
+        //  kept -- and STORES into a 16-byte trash word; with `if (inside) ...` around every access the row-by-row form is a maze of
+        //  exec-mask blocks through which the register allocator spills 70 accumulator registers)
+        auto row_loads = [&](int i, const float* base, int stride, float, f32x4 (&dd)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dd[j] = ldg16(base + (pok(i, j) ? (pix0 + i * a.W + j) * stride + co : 0));
+        };
+        // (a zero the compiler cannot see through, defined behind row i's arithmetic: added into the row's pixel index it keeps the
+        //  address arithmetic of the row's stores BEHIND that arithmetic -- hoisted to the top of the epilogue, as the scheduler
+        //  prefers, the 16 64-bit addresses are live across both transform passes and spill)
+        auto late0 = [&](int i) __attribute__((always_inline)) {
+            int z = 0;
+            asm volatile("" : "+v"(z) : "v"(acc[4 * i + 3]));
+            return z;
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(BMC_W4_ABL & 128)) {
+                const f32x4 m0 = acc[6 * i], m1 = acc[6 * i + 1], m2 = acc[6 * i + 2], m3 = acc[6 * i + 3], m4 = acc[6 * i + 4], m5 = acc[6 * i + 5];
+                const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                acc[4 * i] = (m0 + s1) + s2;          // (4 i + j <= 6 i + j: never overwrites an unread input of a later row)
+                acc[4 * i + 1] = d1 + 2.f * d2;
+                acc[4 * i + 2] = s1 + 4.f * s2;
+                acc[4 * i + 3] = (d1 + 8.f * d2) + m5;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 * i + j] += bq;
+            if (resb) {
+                f32x4 dd[4];
+                row_loads(i, resb, a.residual.pix_stride, 0.f, dd);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * i + j] += dd[j];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[4 * i + j][k] = fmaxf(acc[4 * i + j][k], 0.f);
+            }
+            if (maskb) {
+                f32x4 dd[4];
+                row_loads(i, maskb, a.mask.pix_stride, 1.f, dd);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[4 * i + j][k] = dd[j][k] > 0.f ? acc[4 * i + j][k] : 0.f;
+            }
+            if (a.accumulate) {
+                f32x4 dd[4];
+                row_loads(i, outb, a.out_pix_stride, 0.f, dd);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * i + j] += dd[j];
+            }
+            const int lz = late0(i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* const dst = pok(i, j) ? outb + ((pix0 + i * a.W + j + lz) * a.out_pix_stride + co) : g_w4_trash;
+                if (!((BMC_W4_ABL & 8) && acc[4 * i + j][0] != 12345.678f)) stg16(dst, acc[4 * i + j]);
+            }
+        }
+        init_acc();
+    };
+
+#else
     auto epilogue = [&](const W4Tile& it) __attribute__((always_inline)) {
         pin_acc();
         if (!(BMC_W4_ABL & 128)) {
@@ -771,6 +890,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
         init_acc();
     };
 
+#endif
     // ---------------------------------------------------------------- prologue
     const W4Tile it0 = decode(t_first);
     const float* ublk = ublock(it0, 0);

@@ -428,3 +428,74 @@ def test_reducer_lives_with_the_model_until_detach():
     gc.collect()
     assert wr() is None
     assert all(not p._bmc_sink_hooks and not p._post_accumulate_grad_hooks for p in net.parameters())
+
+
+class DeferredSinkMatmul(torch.autograd.Function):
+    """The protocol of a MERGED weight gradient (bmc_hip.ops.wgrad_wino / wgrad_pgemm with BMC_WGRAD_MERGE > 1): autograd gets None for
+    the weight, and the add into .grad is only QUEUED -- it runs from an engine callback at the end of the backward pass."""
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        ctx.param = w
+        return x @ w
+
+    @staticmethod
+    def backward(ctx, g):
+        from bmc_hip import ops
+        x, w = ctx.saved_tensors
+        gw = x.t() @ g
+        p = ctx.param
+
+        def flush():
+            (dst,), acc = ops.sink_group([p])
+            dst.add_(gw) if acc else dst.copy_(gw)
+        torch.autograd.Variable._execution_engine.queue_callback(flush)
+        return g @ w.t(), None
+
+
+def test_reducer_hook_with_an_undefined_gradient_and_a_queued_sink_add():
+    """`bench.py --gpus 2` at 31x56 (tests/test_gpu_r6.py) found it: autograd runs a parameter's post-accumulate hook even when every
+    use handed it None -- with p.grad still None when the kernels' adds are queued (round 5's merged weight gradients) rather than
+    launched.  The hook leaves such a parameter to finish(), which stages the bucket from .grad after the pass's flush."""
+    sys.path.insert(0, os.path.join(ROOT, "bmcnet-esr_amd"))
+    from bmc_hip import ops
+    from bmc_hip.parallel import GradAllReducer
+    ops.set_accumulate_param_grads(True)
+    g = torch.Generator().manual_seed(5)
+    w = torch.nn.Parameter(torch.randn(8, 8, generator=g) * 0.3)
+    b = torch.nn.Parameter(torch.randn(8, generator=g) * 0.1)
+    x = torch.randn(4, 8, generator=g)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w, self.b = w, b
+
+        def forward(self, x, deferred=True):
+            mm = DeferredSinkMatmul.apply if deferred else torch.matmul
+            return torch.tanh(mm(torch.tanh(mm(x, self.w) + self.b), self.w))
+
+    net = Net()
+    net(x, deferred=False).sum().backward()
+    ref = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    red = GradAllReducer(net, opt, bucket_mb=1e-4)
+    fired = []
+    h = red._on_grad
+    red._on_grad = lambda p: (fired.append(p.grad is None), h(p))[1]
+    for p, hd in zip(red.params, red._handles):       # (re-register so that the wrapped hook is the one autograd calls)
+        p._bmc_sink_hooks.discard(hd.id)
+        hd.remove()
+    red._handles = []
+    for p in red.params:
+        hd = p.register_post_accumulate_grad_hook(red._on_grad)
+        red._handles.append(hd)
+        p._bmc_sink_hooks.add(hd.id)
+    net(x).sum().backward()
+    assert True in fired                              # the hook did fire with p.grad still None ...
+    opt.step()                                        # ... finish() staged the gradient that the end-of-pass flush produced
+    for p, r in zip(net.parameters(), ref):
+        assert torch.allclose(p.grad, r, rtol=1e-6, atol=1e-7)
+    red.detach()

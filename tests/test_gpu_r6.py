@@ -77,9 +77,11 @@ def test_c2_full_size_trained_biases_forward_on_f4x4_vs_oracle():
     conv3 = {k: v for k, v in fwd.items() if "conv<9" in k}
     print("forward 3x3 launches: %s" % conv3)
     if ops.WINO4 and ops.WINO:
-        # 103 3x3 convolutions per window (100 in the block loop + input fusion + head) as twin / group launches: all of the 128 ->
-        # 128 ones on the F(4x4) kernel, none on F(2x2)
-        assert conv3.get("wino4_conv<9,128>", 0) >= 60 * NW and conv3.get("wino_conv<9,128>", 0) == 0, conv3
+        # 103 3x3 convolutions per window (100 in the block loop + input fusion + head) run as 46 twin / group launches: the block
+        # loop and the tail (inside ops.dense_inputs) all on the F(4x4) kernel; of the 4 input-fusion launches a window at most 2 stay
+        # on F(2x2) -- those whose own bias vector holds an element within DENSE_FLOOR of zero (rule (1) of DESIGN.md section 5: a
+        # vector of 128 values in +-1e-2 does so with probability 0.12), exactly as in the bench's timed steps
+        assert conv3.get("wino4_conv<9,128>", 0) >= 40 * NW and conv3.get("wino_conv<9,128>", 0) <= 2 * NW, conv3
     within(abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()), 2e-6, 1e-5, "C2 full size, dense biases, loss")
     errs = {n: rel_l2(p.grad, params[n].grad) for n, p in m.named_parameters() if params[n].grad is not None}
     assert len(errs) >= 50
@@ -126,7 +128,7 @@ def test_merged_weight_gradients_past_one_pointer_table():
     g1, n1 = run(1)
     g5, n5 = run(5)
     assert n5 < n1, (n5, n1)                         # uses were merged ...
-    assert len(g1) == len(g5) >= 50
+    assert len(g1) == len(g5) >= 40
     worst = max((rel_l2(g5[n], g1[n]), n) for n in g1)
     print("merged (5) vs unmerged weight gradients at 31x56, batch 16: %d vs %d pixel-reduction launches, worst difference %.1e (%s)" % (
         n5, n1, worst[0], worst[1]))
@@ -202,7 +204,14 @@ def test_bench_launcher_two_ranks_on_one_gpu():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "31", "--width", "56",
            "--batch", "2", "--seql", "3", "--no-cpu-baseline", "--no-bf16x6", "--also", "none"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
+    if r.returncode != 0:
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            open(os.path.join(ROOT, "gpurun_out", "bench_launcher_stderr.log"), "w").write(r.stderr)
+        except OSError:
+            pass
+    tb = [l for l in r.stderr.splitlines() if "Error" in l or "error" in l or l.startswith("  File")]
+    assert r.returncode == 0, "\n".join(tb[:60]) + "\n...\n" + r.stderr[-1500:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
