@@ -19,6 +19,9 @@
 #include "dma_ring.h"
 #include <stdlib.h>
 
+#ifndef BMC_C1P_EPF
+#define BMC_C1P_EPF 1     // K = 256 instantiation: epilogue operands requested in front of the tile's MFMAs (round 6); 0: behind them
+#endif
 #ifndef BMC_C1P_ABL
 #define BMC_C1P_ABL 0     // ablation builds (tools/): 1 no MFMA, 2 no stores, 4 no pixel DMA, 8 no fragment reads
 #endif
@@ -177,6 +180,45 @@ __global__ __launch_bounds__(512, (NCH == 8 && DEPTH == 1) ? 4 : 2) void conv1p_
         }
         if (grp != w_grp || it.nt != w_nt) load_w(grp, it.nt);
 
+        const int co = it.nt * 128 + 16 * wave + 4 * lk;
+        const bool cok = co < a.Cout;
+        int pix[4];
+        bool ok[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            pix[pb] = it.pt * PX + pb * 16 + li;
+            ok[pb] = pix[pb] < HW && cok;
+        }
+        // ---- epilogue operands.  K = 256 (one workgroup per CU, two waves per SIMD, 256 registers each): requested HERE, in front
+        //      of the tile's 256 MFMAs, so that they land under them -- fetched behind the MFMAs (round 3-5) every wave of the CU
+        //      sat through one memory round trip per tile with the matrix pipes idle (both SIMD partners reach their epilogues
+        //      together: one barrier per tile keeps them in step).  K = 128 (four waves per SIMD, 128 registers): behind the MFMAs as
+        //      before, one operand at a time -- the other workgroup's waves cover the round trip.
+        constexpr bool EPF = BMC_C1P_EPF && NCH == 16;
+        f32x4 rv[4], mv[4], ov[4];
+        auto ep_load = [&](const float* base, int stride, float fill, f32x4 (&v)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                v[pb] = f32x4{fill, fill, fill, fill};
+                if (ok[pb]) v[pb] = ldg16(base + (long long)pix[pb] * stride + co);
+            }
+        };
+        // (requests the compiler does not track, waited for by count where they are used -- a tracked load at the top of the tile
+        //  makes it wait vmcnt(0) THERE, for the previous tile's stores: its registers might still be the target of an older load.
+        //  Lanes beyond the image or the channel count read a valid element nobody keeps: their results are never stored.)
+        auto ep_request = [&](const float* base, int stride, f32x4 (&v)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const float* const q = base + (long long)(pix[pb] < HW ? pix[pb] : HW - 1) * stride + (cok ? co : 0);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[pb]) : "v"(q) : "memory");
+            }
+        };
+        if (EPF) {
+            if (resb) ep_request(resb, a.residual.pix_stride, rv);
+            if (maskb) ep_request(maskb, a.mask.pix_stride, mv);
+            if (a.accumulate) ep_request(outb, a.out_pix_stride, ov);
+        }
+
         // ---- the tile's MFMAs: chunk c's pixel fragments are read while chunk c - 1 is multiplied
         const float* const xb = lds + (n % NS) * SLOT;
         f32x4 acc[4];
@@ -208,24 +250,16 @@ __global__ __launch_bounds__(512, (NCH == 8 && DEPTH == 1) ? 4 : 2) void conv1p_
                 }
         }
 
-        const int co = it.nt * 128 + 16 * wave + 4 * lk;
-        const bool cok = co < a.Cout;
-        int pix[4];
-        bool ok[4];
+        // ---- epilogue
+        if (EPF && (resb || maskb || a.accumulate)) {
+            // younger than the requests: the next tile's pixel DMA (NCH / 2 instructions), if it was issued
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NCH / 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int pb = 0; pb < 4; ++pb) {
-            pix[pb] = it.pt * PX + pb * 16 + li;
-            ok[pb] = pix[pb] < HW && cok;
+            for (int pb = 0; pb < 4; ++pb) asm volatile("" : "+v"(rv[pb]), "+v"(mv[pb]), "+v"(ov[pb]));
         }
-        // ---- epilogue (operands fetched after the MFMAs, one at a time: 16 registers instead of 48 across the MFMA loop; with
-        //      four waves per SIMD the other waves cover the round trip)
         if (resb) {
-            f32x4 rv[4];
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {
-                rv[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ok[pb]) rv[pb] = ldg16(resb + (long long)pix[pb] * a.residual.pix_stride + co);
-            }
+            if (!EPF) ep_load(resb, a.residual.pix_stride, 0.f, rv);
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) acc[pb] += rv[pb];
         }
@@ -236,24 +270,14 @@ __global__ __launch_bounds__(512, (NCH == 8 && DEPTH == 1) ? 4 : 2) void conv1p_
                 for (int k = 0; k < 4; ++k) acc[pb][k] = fmaxf(acc[pb][k], 0.f);
         }
         if (maskb) {
-            f32x4 mv[4];
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {
-                mv[pb] = f32x4{1.f, 1.f, 1.f, 1.f};
-                if (ok[pb]) mv[pb] = ldg16(maskb + (long long)pix[pb] * a.mask.pix_stride + co);
-            }
+            if (!EPF) ep_load(maskb, a.mask.pix_stride, 1.f, mv);
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc[pb][k] = mv[pb][k] > 0.f ? acc[pb][k] : 0.f;
         }
         if (a.accumulate) {
-            f32x4 ov[4];
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {
-                ov[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ok[pb]) ov[pb] = ldg16(outb + (long long)pix[pb] * a.out_pix_stride + co);
-            }
+            if (!EPF) ep_load(outb, a.out_pix_stride, 0.f, ov);
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) acc[pb] += ov[pb];
         }

@@ -54,6 +54,10 @@
                            // eight MFMAs, one or two instructions per MFMA gap (round 6); 0: round 4/5's form -- reads, eight MFMAs back to back,
                            // then requests and arithmetic
 #endif
+#ifndef BMC_W4_HSWAP
+#define BMC_W4_HSWAP 1     // 1: the producer lanes of tiles 4-7 / 12-15 make the two channel halves of their item in the opposite order, which
+                           // takes the 2-way bank conflict out of every patch read (round 6); 0: round 4/5's order
+#endif
 #ifndef BMC_W4_EPI
 #define BMC_W4_EPI 0       // 0: all arithmetic, then all loads, then the 16 stores; 1: output transform, operand loads and stores row by row
                            // (round 6: measured 0.7 % SLOWER -- 0.3230 / 0.3537 against 0.3208 / 0.3513 ms, three alternating rounds; kept for the record)
@@ -366,6 +370,19 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
         prow[2] = pr2 * XROWF + slot * RS + pq * 4;
         prow[3] = pr3 * XROWF + slot * RS + pq * 4;
     };
+    // Bank conflicts of the patch reads.  A ds_read_b64 is served in two groups of 32 lanes = 8 tiles x 4 channel quads; a tile's slots
+    // lie 4 * RS = 80 floats = 16 banks (mod 64) apart, so tiles t and t + 4 of a group met on the same banks: a 2-way conflict on
+    // every one of the 48 patch reads of a chunk (PMC: 0.29 of the LDS cycles).  The eight bytes a lane reads are one HALF of its
+    // 16-byte quad, and the other half's banks are free in that very instruction: the lanes of tiles 4-7 (12-15) read -- and later
+    // store -- the halves in the opposite order (half h ^ 1 in pass h).  Every element of V ends up where it was.
+    // hx = 2 floats for those lanes, 0 for the others; prow is shifted by +hx in front of pass 0, by -2 hx in front of pass 1 (whose
+    // reads carry the immediate + 2), and back by +hx behind it.
+    auto prow_shift = [&](int d) __attribute__((always_inline)) {
+        if (!BMC_W4_HSWAP) return;
+        const int hx = (lane_now() >> 3) & 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) prow[k] += d * hx;
+    };
     // An item = row xi of (tile, channel quad) is made in two halves of two channels each (h = 0, 1): 6 + 4 + 4 register
     // pairs live instead of quads -- with 144 accumulators, the U ring and the V fragments the quads did not fit (90 spills)
     typedef float f32x2p __attribute__((ext_vector_type(2)));
@@ -438,22 +455,17 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
 #pragma unroll
         for (int e = 0; e < 2; ++e) { pt[3][e] = __builtin_fmaf(2.f, te[e], tc[e]); pt[4][e] = __builtin_fmaf(-2.f, te[e], tc[e]); }
     };
-    auto prod_addr = [&]() __attribute__((always_inline)) {
+    auto prod_addr = [&](int h) __attribute__((always_inline)) {          // (the half of its quad this lane writes in pass h included)
         const int l = lane_now();
-        int vst = xi * 6 * NT * CK + (l >> 2) * CK + (((l & 3) ^ swz(l >> 2)) * 4);
+        int vst = xi * 6 * NT * CK + (l >> 2) * CK + (((l & 3) ^ swz(l >> 2)) * 4) + (BMC_W4_HSWAP ? (2 * h) ^ ((l >> 3) & 2) : 2 * h);
         asm volatile("" : "+v"(vst));
         return vst;
     };
-    auto prod_store_at = [&](float* vb, int vst, int h) __attribute__((always_inline)) {
+    auto prod_store_at = [&](float* vb, int vst) __attribute__((always_inline)) {
 #pragma unroll
-        for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x2p*>(vb + vst + nu * NT * CK + 2 * h) = pt[nu];
+        for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x2p*>(vb + vst + nu * NT * CK) = pt[nu];
     };
-    auto prod_store = [&](float* vb, int h) __attribute__((always_inline)) {
-        const int l = lane_now();
-        const int vst = xi * 6 * NT * CK + (l >> 2) * CK + (((l & 3) ^ swz(l >> 2)) * 4);          // + nu * NT * CK
-#pragma unroll
-        for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x2p*>(vb + vst + nu * NT * CK + 2 * h) = pt[nu];
-    };
+    auto prod_store = [&](float* vb, int h) __attribute__((always_inline)) { prod_store_at(vb, prod_addr(h)); };
 
     // ---------------------------------------------------------------- MFMA side
     const int voff = lj * CK + ((lk ^ swz(lj)) * 4);                                  // + pos * NT * CK
@@ -592,12 +604,12 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
                 mf(acc[p0], ur[s0][2], v[0][2]);
                 if (LOADER && pp <= XLAST) load_x_piece(2 * pp);
                 int vst = 0;
-                if (pact && ps == 7) vst = prod_addr();
+                if (pact && ps == 7) vst = prod_addr(ph);
                 __builtin_amdgcn_sched_barrier(0);
                 // gap 5
                 mf(acc[p1], ur[s1][2], v[1][2]);
                 if (LOADER && pp <= XLAST && 2 * pp + 1 < PPW) load_x_piece(2 * pp + 1);
-                if (pact && ps == 7) prod_store_at(vbn, vst, ph);
+                if (pact && ps == 7) prod_store_at(vbn, vst);
                 __builtin_amdgcn_sched_barrier(0);
                 // gap 6
                 mf(acc[p0], ur[s0][3], v[0][3]);
@@ -611,6 +623,12 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
                 if (BMC_W4_XP != 3) { if (lo) uload<1024>(ur[s1], ub, uvoff); else uload<3072>(ur[s1], ub, uvoff); }
                 if (LOADER && pp + 1 <= XLAST && 2 * (pp + 1) + 1 >= KREG && 2 * (pp + 1) + 1 < PPW) xoj_fetch(2 * (pp + 1) + 1, 1);
                 if (pact && ps < 6) { prod_fma_b(psc, pd); pin2(pt[psc]); }
+                // (the patch reads of tiles 4-7 / 12-15 take the other half of their quads: prow_shift)
+                if (!LOADER && !(BMC_W4_ABL & 16)) {
+                    if (pp == PH0 - 1) prow_shift(1);
+                    if (pp == PH0 + 7) prow_shift(-2);
+                    if (pp == PH0 + 15) prow_shift(1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (LOADER) {
                     if (pp == XLAST + 1) load_x_advance();
@@ -683,6 +701,11 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
                 if (ps < 6) prod_fma(ps, pd);
                 if (ps == 6) prod_row_a(ta, tb, tc, te);
                 if (ps == 7) { prod_row_b(ta, tb, tc, te); prod_store(vbn, ph); }
+            }
+            if (!LOADER && !(BMC_W4_ABL & 16)) {
+                if (pp == PH0 - 1) prow_shift(1);
+                if (pp == PH0 + 7) prow_shift(-2);
+                if (pp == PH0 + 15) prow_shift(1);
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
@@ -917,12 +940,14 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
             f32x2p pd[4], ta, tb, tc, te;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                prow_shift(h == 0 ? 1 : -2);
 #pragma unroll
                 for (int c = 0; c < 6; ++c) { prod_col(Xb, h, c, pd); prod_fma(c, pd); }
                 prod_row_a(ta, tb, tc, te);
                 prod_row_b(ta, tb, tc, te);
                 prod_store(Vb, h);
             }
+            prow_shift(1);
         }
     } else {
         dma_wait<0>();

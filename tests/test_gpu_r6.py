@@ -218,4 +218,4 @@ def test_bench_launcher_two_ranks_on_one_gpu():
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
     assert rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["higher_is_better"] is True
     assert rec["config"]["ranks_in_lock_step"] is True and rec["config"]["rccl_ranks"] == 2, rec["config"]
-    assert rec["cpu_baseline"] is None or isinstance(rec["cpu_baseline"], dict)
+    assert rec["config"]["collective_backend"].startswith("gloo") and rec["config"]["rank_cpu_pinning"] is not None

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Isolated-kernel timing at the C2 shapes (batch 2B = 8, 180x240, n_c = 128); HIP events on torch's stream.
-usage: python tools/kbench.py [case ...]   cases: conv3 wgrad3 conv1 conv1x256 wgrad1 gram apply relu ln"""
+usage: python tools/kbench.py [case ...]   cases: conv3 wgrad3 conv1 conv1x256 conv1x256res wgrad1 gram apply relu ln"""
 import os
 import sys
 
@@ -54,6 +54,11 @@ with torch.no_grad():
     if "conv1x256" in cases:
         w = torch.randn(Cn, 2 * Cn, 1, 1, device=dev) * 0.1; b = torch.zeros(Cn, device=dev)
         timeit(lambda: ops.conv([View(x), View(x2)], w, b, s2), 2.0 * npx * Cn * 2 * Cn, "conv1x1 256->128 fwd")
+    if "conv1x256res" in cases:      # the K = 256 1x1 launch with a residual operand (BIE unclustering): conv1p_kernel<16> with an epilogue load
+        w = torch.randn(Cn, 2 * Cn, 1, 1, device=dev) * 0.1; b = torch.zeros(Cn, device=dev)
+        x3 = torch.randn_like(x)
+        timeit(lambda: ops.conv([View(x), View(x2)], w, b, s2, residual=View(x3)), 2.0 * npx * Cn * 2 * Cn, "conv1x1 256->128 + residual")
+        timeit(lambda: ops.conv([View(x), View(x2)], w, b, s2, residual=View(x3), relu=True), 2.0 * npx * Cn * 2 * Cn, "conv1x1 256->128 + residual + relu")
     if "wgrad1" in cases:
         def f():
             ops.pgemm_raw(ops._src(g, 0, Cn, 0, None, 0, B), [ops._src(x, 0, Cn, 0, None, 0, B)], B, H, W, 1, B, Cn, Cn, dev)
