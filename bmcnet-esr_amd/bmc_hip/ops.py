@@ -280,10 +280,15 @@ WINO4_MIN_TILES = int(os.environ.get("BMC_WINO4_MIN_TILES", 300))    # workgroup
 #       a bias-free launch that adds a residual the bias inside that residual: `rule`) is at least DENSE_FLOOR away from zero: no
 #       output of the launch is decided by the residue (bias_dense).
 #   (2) dense inputs.  A launch whose input has NO empty receptive field cannot meet the hazard whatever its bias.  The models
-#       prove that where they can and say so with the dense_inputs() context: once the input-fusion convolutions -- ReLU layers,
-#       evaluated under (1) -- have a bias element >= DENSE_FLOOR each (bias_positive), every pixel of their outputs carries a
-#       positive channel, and residual blocks (y = x + ...), LayerNorm2d, 1x1 convolutions and per-pixel attention keep a non-zero
-#       pixel non-zero: the whole block loop and the tail of that window run inside the context.
+#       ARGUE that where they can and say so with the dense_inputs() context: once the input-fusion convolutions -- ReLU layers,
+#       evaluated under (1) -- have a bias element >= DENSE_FLOOR each (bias_positive), every pixel of their outputs whose
+#       receptive field is EMPTY carries a positive channel, and residual blocks (y = x + ...), LayerNorm2d, 1x1 convolutions
+#       and per-pixel attention generically keep a non-zero pixel non-zero: the whole block loop and the tail of that window run
+#       inside the context.  This is a HEURISTIC, not a proof: at an OCCUPIED pixel the ReLU can still zero every
+#       channel, and LayerNorm2d with a zero beta or a cancellation in x + conv(x) can produce an all-zero pixel, so F(4x4) can
+#       still meet an empty 3x3 field with a zero-bias layer inside the block loop.  What it costs then is the coin flip of a few
+#       ReLU gates (measured bound: test_sparse_recording_bias_gradients_vs_oracle[trained] 1.3e-4 against the oracle's own
+#       float32 floor of 1.2e-4); exact_zero_inputs() / BMC_WINO4=0 are the exact alternatives.
 # As `initialize_weights` leaves the biases (zero) every forward launch keeps F(2x2); one optimizer step moves every bias by
 # about the learning rate, (2) holds from then on, and only the 4 input-fusion launches of a window depend on (1) -- biases
 # cross zero now and then in early training (measured: 8 of 27 vectors had an element within 1e-6 of zero after step 3).  Data

@@ -54,8 +54,11 @@
                            // eight MFMAs, one or two instructions per MFMA gap (round 6); 0: round 4/5's form -- reads, eight MFMAs back to back,
                            // then requests and arithmetic
 #endif
+#ifndef BMC_W4_EPF
+#define BMC_W4_EPF 1       // N > 0: N tile rows of the first epilogue operand of a launch is requested between the two passes of the output transform (round 6); 0: behind them
+#endif
 #ifndef BMC_W4_HSWAP
-#define BMC_W4_HSWAP 1     // 1: the producer lanes of tiles 4-7 / 12-15 make the two channel halves of their item in the opposite order, which
+#define BMC_W4_HSWAP 0     // 1: the producer lanes of tiles 4-7 / 12-15 make the two channel halves of their item in the opposite order, which
                            // takes the 2-way bank conflict out of every patch read (round 6); 0: round 4/5's order
 #endif
 #ifndef BMC_W4_EPI
@@ -202,11 +205,37 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
         it.b = t / wpi;
         return it;
     };
+    // A workgroup visits the tiles t_first, t_first + t_stride, ...: (nt, wt, b) advance by the digits of t_stride with carries.  No
+    // integer division stays in the tile loop (three decodes per tile and wave were ~120 vector instructions, and the two reciprocals
+    // they keep in registers were what the allocator spilled once the epilogue prefetched its operand: round 6).
+    // tiles_x as a divisor the compiler cannot hoist: the per-tile divisions below recompute their reciprocal (~25 instructions per
+    // tile) instead of keeping it in a vector register across the chunk loops, where every register is spoken for
+    auto opaque = [](int v) __attribute__((always_inline)) {
+        asm volatile("" : "+s"(v));
+        return v;
+    };
+    auto tiles_x_now = [&]() __attribute__((always_inline)) { return opaque(a.tiles_x); };
+    // (the same for the other per-tile divisions by launch constants: weight / bias group of an image, batch maps of the epilogue operands)
+    auto group_of = [&](int b) __attribute__((always_inline)) { return a.batch_per_group >= a.B ? 0 : b / opaque(a.batch_per_group); };
+    auto batch_ptr = [&](const SrcDev& sd, int b) __attribute__((always_inline)) {
+        int bs = b + sd.batch_shift;
+        if (sd.batch_mod > 0) bs %= opaque(sd.batch_mod);
+        return sd.ptr + (long long)bs * sd.batch_stride;
+    };
+    const W4Tile stp = decode(t_stride);
+    auto advance = [&](W4Tile it) {
+        it.nt += stp.nt;
+        if (it.nt >= a.ntn) { it.nt -= a.ntn; ++it.wt; }
+        it.wt += stp.wt;
+        if (it.wt >= wpi) { it.wt -= wpi; ++it.b; }
+        it.b += stp.b;
+        return it;
+    };
 
     // ---------------------------------------------------------------- U stream (every wave: its own 16 rows)
     const unsigned uvoff = (unsigned)(lane * 16);
     auto ublock = [&](const W4Tile& it, int chunk) -> const float* {
-        const int grp = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
+        const int grp = group_of(it.b);
         const float* p = static_cast<const float*>(a.w) + (long long)grp * a.w_group_stride + (long long)it.nt * nchunks * UCH +
                          (long long)chunk * UCH + (BMC_W4_XP == 2 ? (wave & 3) : wave) * UBLK;
         const unsigned long long pv = reinterpret_cast<unsigned long long>(p);
@@ -226,7 +255,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     // once per tile: pixel index / channel quad / zero flag of every quad this wave copies
     auto table_setup = [&]() {
         const int T0 = xl_it.wt * NT;
-        tb_ty0 = T0 / a.tiles_x; tb_tx0 = T0 - tb_ty0 * a.tiles_x;
+        tb_ty0 = T0 / tiles_x_now(); tb_tx0 = T0 - tb_ty0 * a.tiles_x;
         // segments g = 0..3: the tiles of tile row ty0 + g, n_g of them from tile column (g == 0 ? tx0 : 0), pixel slots
         // [st_g, st_g + 4 n_g + 2): neighbours in a row share two columns, every row break starts a fresh 6-column patch
         int n = a.tiles_x - tb_tx0; n = n < NT ? n : NT;
@@ -312,7 +341,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
         c_in += CK;
         if (++xl_chunk == nchunks) {
             xl_tile += t_stride;
-            if (xl_tile < t_hi) xl_it = decode(xl_tile);      // (past the last tile: the same tile again -- valid addresses, nobody reads it)
+            if (xl_tile < t_hi) xl_it = advance(xl_it);       // (past the last tile: the same tile again -- valid addresses, nobody reads it)
             s_idx = 0; c_in = 0; xl_chunk = 0;
             table_setup();
             src_select();
@@ -356,14 +385,14 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     const float pk2 = (xi == 0 || xi == 5 || xi == 1) ? 1.f : (xi == 2 ? -1.f : (xi == 3 ? 2.f : -2.f));
     const float pk3 = (xi == 0 || xi == 5) ? 0.f : 1.f;
     int prow[4];                                      // float offsets of (patch row k, this lane's tile, channel quad) in an X buffer
-    auto prod_setup = [&](int t) {                    // geometry of the tile whose chunks the producer is working on
-        const W4Tile it = decode(t);
+    auto prod_setup = [&](const W4Tile& it) {         // geometry of the tile whose chunks the producer is working on
         int pln;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(pln));
         const int ptile = pln >> 2, pq = pln & 3;
         const int T0 = it.wt * NT;
-        const int ty0 = T0 / a.tiles_x;
-        const int ty = (T0 + ptile) / a.tiles_x;
+        const int txn = tiles_x_now();
+        const int ty0 = T0 / txn;
+        const int ty = (T0 + ptile) / txn;
         const int slot = 4 * ptile + 2 * (ty - ty0);
         prow[0] = pr0 * XROWF + slot * RS + pq * 4;
         prow[1] = pr1 * XROWF + slot * RS + pq * 4;
@@ -541,6 +570,16 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
             } else if (BMC_W4_DPRIO == 6) {
                 if (pp == 0) __builtin_amdgcn_s_setprio(3);
                 if (pp == 6) __builtin_amdgcn_s_setprio(0);
+            } else if (BMC_W4_DPRIO == 10) {
+                // (round 6 experiment: the SIMD partners w / w + 4 take turns pair by pair)
+                if (((pp + (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+            } else if (BMC_W4_DPRIO == 11) {
+                // (... on top of the priority that falls along the chunk)
+                constexpr int qb = pp < 4 ? 2 : (pp < 9 ? 2 : (pp < 13 ? 1 : 0));
+                if (((pp + (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(qb + 1); else __builtin_amdgcn_s_setprio(qb);
+            } else if (BMC_W4_DPRIO == 12) {
+                // (... in blocks of three pairs = one row of the position grid)
+                if ((((pp / 3) + (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
             }
 #endif
             if (LOADER) uwait_n(D - 2 + xyounger(pp), ur[s0], ur[s1]); else uwait<D - 2>(ur[s0], ur[s1]);
@@ -738,13 +777,13 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
         }
         pin_acc();
         __builtin_amdgcn_sched_barrier(0);          // (phases are not interleaved: every one of them alone fits the register file)
-        const int g = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
+        const int g = group_of(it.b);
         const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
         float* const outb = a.out + (long long)it.b * a.out_batch_stride;
         if (it.b != ep_b) {
             ep_b = it.b;
-            ep_res = a.residual.ptr ? src_batch_ptr(a.residual, it.b) : nullptr;
-            ep_mask = a.mask.ptr ? src_batch_ptr(a.mask, it.b) : nullptr;
+            ep_res = a.residual.ptr ? batch_ptr(a.residual, it.b) : nullptr;
+            ep_mask = a.mask.ptr ? batch_ptr(a.mask, it.b) : nullptr;
         }
         const float* const resb = ep_res;
         const float* const maskb = ep_mask;
@@ -758,7 +797,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
         f32x4 bq = {0.f, 0.f, 0.f, 0.f};
         if (biasg && cok) bq = ldg16(biasg + co);
         const int T = it.wt * NT + elj;
-        const int ty = T / a.tiles_x, tx = T - ty * a.tiles_x;
+        const int ty = T / tiles_x_now(), tx = T - ty * a.tiles_x;
         const int y0 = 4 * ty, x0 = 4 * tx;
         const int pix0 = y0 * a.W + x0;
         // pixel (i, j) of the tile: in the image?  (tiles past the image's last one have ty >= tiles_y: y0 >= H)
@@ -828,10 +867,15 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     };
 
 #else
+    // Y = A^T M A (rows of A^T: (1 1 1 1 1 0) (0 1 -1 2 -2 0) (0 1 1 4 4 0) (0 1 -1 8 -8 1)), columns first, in place: that frees the
+    // accumulators of the grid rows xi = 4, 5 -- and the FIRST of the launch's epilogue operands (residual, else mask, else previous
+    // output) is requested right there, all 16 quads, to land under the ~400 vector instructions of the row pass.  (Rounds 4-5 fetched
+    // it behind the arithmetic, four loads at a time: four memory round trips per tile with both waves of every SIMD waiting -- the
+    // residual form of the 2B launch took 0.351 ms against 0.321 for the plain one.)  Pixels outside the image read the operand's
+    // first quad; nothing computed from it is stored.  Same operations in the same order per element: bit-identical results.
     auto epilogue = [&](const W4Tile& it) __attribute__((always_inline)) {
         pin_acc();
         if (!(BMC_W4_ABL & 128)) {
-            // Y = A^T M A, rows of A^T: (1 1 1 1 1 0) (0 1 -1 2 -2 0) (0 1 1 4 4 0) (0 1 -1 8 -8 1); columns first, in place
 #pragma unroll
             for (int nu = 0; nu < 6; ++nu) {
                 const f32x4 m0 = acc[nu], m1 = acc[6 + nu], m2 = acc[12 + nu], m3 = acc[18 + nu], m4 = acc[24 + nu], m5 = acc[30 + nu];
@@ -841,23 +885,14 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
                 acc[12 + nu] = s1 + 4.f * s2;
                 acc[18 + nu] = (d1 + 8.f * d2) + m5;
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 m0 = acc[6 * i], m1 = acc[6 * i + 1], m2 = acc[6 * i + 2], m3 = acc[6 * i + 3], m4 = acc[6 * i + 4], m5 = acc[6 * i + 5];
-                const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-                acc[4 * i] = (m0 + s1) + s2;          // (4 i + j <= 6 i + j: never overwrites an unread input of a later row)
-                acc[4 * i + 1] = d1 + 2.f * d2;
-                acc[4 * i + 2] = s1 + 4.f * s2;
-                acc[4 * i + 3] = (d1 + 8.f * d2) + m5;
-            }
         }
-        const int g = a.batch_per_group >= a.B ? 0 : it.b / a.batch_per_group;
+        const int g = group_of(it.b);
         const float* const biasg = a.bias ? a.bias + (long long)g * a.bias_group_stride : nullptr;
         float* const outb = a.out + (long long)it.b * a.out_batch_stride;
         if (it.b != ep_b) {
             ep_b = it.b;
-            ep_res = a.residual.ptr ? src_batch_ptr(a.residual, it.b) : nullptr;
-            ep_mask = a.mask.ptr ? src_batch_ptr(a.mask, it.b) : nullptr;
+            ep_res = a.residual.ptr ? batch_ptr(a.residual, it.b) : nullptr;
+            ep_mask = a.mask.ptr ? batch_ptr(a.mask, it.b) : nullptr;
         }
         const float* const resb = ep_res;
         const float* const maskb = ep_mask;
@@ -871,15 +906,41 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
         f32x4 bq = {0.f, 0.f, 0.f, 0.f};
         if (biasg && cok) bq = ldg16(biasg + co);
         const int T = it.wt * NT + elj;
-        const int ty = T / a.tiles_x, tx = T - ty * a.tiles_x;
+        const int ty = T / tiles_x_now(), tx = T - ty * a.tiles_x;
         const int y0 = 4 * ty, x0 = 4 * tx;
         const int pix0 = y0 * a.W + x0;
         // pixel (i, j) of the tile: in the image?  (tiles past the image's last one have ty >= tiles_y: y0 >= H)
         auto pok = [&](int i, int j) { return cok && y0 + i < a.H && x0 + j < a.W; };
-        auto fetch = [&](const float* base, int stride, float fill, auto&& apply) __attribute__((always_inline)) {
-            // one tile row at a time: 4 loads, then their use (16 registers in flight)
+        const bool lead_any = BMC_W4_EPF && (resb || maskb || a.accumulate);
+        const float* const lbase = resb ? resb : (maskb ? maskb : outb);
+        const int lstride = resb ? a.residual.pix_stride : (maskb ? a.mask.pix_stride : a.out_pix_stride);
+        // (loader waves: the 12 halo offsets they keep in registers are recomputed from the table at the END of this epilogue instead
+        //  of living through it -- 12 LDS reads per tile for 12 registers here; the table and the source stride are those the
+        //  stream's next chunk uses)
+        constexpr int NPF = BMC_W4_EPF;                 // tile rows of the lead operand requested ahead (their registers: the freed accumulators)
+        f32x4 pf[4 * (NPF > 0 ? NPF : 1)];
+        if (lead_any) {
+#pragma unroll
+            for (int i = 0; i < NPF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pf[4 * i + j] = ldg16(lbase + (pok(i, j) ? (pix0 + i * a.W + j) * lstride + co : 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(BMC_W4_ABL & 128)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                const f32x4 m0 = acc[6 * i], m1 = acc[6 * i + 1], m2 = acc[6 * i + 2], m3 = acc[6 * i + 3], m4 = acc[6 * i + 4], m5 = acc[6 * i + 5];
+                const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                acc[4 * i] = (m0 + s1) + s2;          // (4 i + j <= 6 i + j: never overwrites an unread input of a later row)
+                acc[4 * i + 1] = d1 + 2.f * d2;
+                acc[4 * i + 2] = s1 + 4.f * s2;
+                acc[4 * i + 3] = (d1 + 8.f * d2) + m5;
+            }
+        }
+        auto fetch = [&](int i0, const float* base, int stride, float fill, auto&& apply) __attribute__((always_inline)) {
+            // one tile row at a time: 4 loads, then their use (16 registers in flight)
+#pragma unroll
+            for (int i = i0; i < 4; ++i) {
                 f32x4 dd[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -890,20 +951,37 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
                 for (int j = 0; j < 4; ++j) apply(acc[4 * i + j], dd[j]);
             }
         };
+        auto add_to = [](f32x4& v, const f32x4& d) { v += d; };
+        auto mask_by = [](f32x4& v, const f32x4& d) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = d[k] > 0.f ? v[k] : 0.f;
+        };
+        // the lead operand: rows 0 .. NPF - 1 from the registers requested ahead, the rest as before
+        auto lead_apply = [&](const float* base, int stride, float fill, auto&& apply) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = 0; p < 4 * NPF; ++p) apply(acc[p], pf[p]);
+            fetch(NPF, base, stride, fill, apply);
+        };
 #pragma unroll
         for (int p = 0; p < 16; ++p) acc[p] += bq;
-        if (resb) fetch(resb, a.residual.pix_stride, 0.f, [](f32x4& v, const f32x4& d) { v += d; });
+        if (resb) {
+            if (lead_any) lead_apply(resb, a.residual.pix_stride, 0.f, add_to);
+            else fetch(0, resb, a.residual.pix_stride, 0.f, add_to);
+        }
         if (a.relu) {
 #pragma unroll
             for (int p = 0; p < 16; ++p)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc[p][k] = fmaxf(acc[p][k], 0.f);
         }
-        if (maskb) fetch(maskb, a.mask.pix_stride, 1.f, [](f32x4& v, const f32x4& d) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = d[k] > 0.f ? v[k] : 0.f;
-        });
-        if (a.accumulate) fetch(outb, a.out_pix_stride, 0.f, [](f32x4& v, const f32x4& d) { v += d; });
+        if (maskb) {
+            if (lead_any && !resb) lead_apply(maskb, a.mask.pix_stride, 1.f, mask_by);
+            else fetch(0, maskb, a.mask.pix_stride, 1.f, mask_by);
+        }
+        if (a.accumulate) {
+            if (lead_any && !resb && !maskb) lead_apply(outb, a.out_pix_stride, 0.f, add_to);
+            else fetch(0, outb, a.out_pix_stride, 0.f, add_to);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -911,6 +989,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
                 if (pok(i, j) && !((BMC_W4_ABL & 8) && acc[4 * i + j][0] != 12345.678f))
                     stg16(outb + ((pix0 + i * a.W + j) * a.out_pix_stride + co), acc[4 * i + j]);
         init_acc();
+        if (LOADER && BMC_W4_EPF) offsets_from_table();
     };
 
 #endif
@@ -935,7 +1014,7 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     }
     __syncthreads();
     if (!LOADER) {
-        prod_setup(t_first);
+        prod_setup(it0);
         if (!(BMC_W4_ABL & 16)) {
             f32x2p pd[4], ta, tb, tc, te;
 #pragma unroll
@@ -963,20 +1042,21 @@ __device__ __forceinline__ void wino4_body(const ConvK& a, float* lds, const int
     // The streams never stop: past the workgroup's last tile the loaders and the producers work on that tile again (valid
     // addresses, buffers nobody reads), so no pair carries an "is there a next one" branch and every wait is a constant.
     int gc = 0;
+    W4Tile it = it0;
     for (int tile = t_first; tile < t_hi; tile += t_stride) {
-        const W4Tile it = decode(tile);
-        const int tile_n = tile + t_stride < t_hi ? tile + t_stride : tile;
+        const W4Tile it_n = tile + t_stride < t_hi ? advance(it) : it;
         for (int c = 0; c < nchunks; ++c, ++gc) {
             const float* unx;
             if (c + 1 < nchunks) unx = ublk + UCH;
-            else unx = ublock(decode(tile_n), 0);
-            if (!LOADER && c == nchunks - 1) prod_setup(tile_n);         // the producer moves on to the next tile's first chunk
+            else unx = ublock(it_n, 0);
+            if (!LOADER && c == nchunks - 1) prod_setup(it_n);           // the producer moves on to the next tile's first chunk
             chunk(ublk, unx, Vb + (gc & 1) * VBUF, Xb + ((gc + 1) & 1) * XBUFA, Vb + ((gc + 1) & 1) * VBUF, gc & 1, gc);
             ublk = unx;
         }
         W4_STAMP(stamp_i); ++stamp_i;
         epilogue(it);
         W4_STAMP(stamp_i); ++stamp_i;
+        it = it_n;
     }
     dma_wait<0>();
 }

@@ -35,7 +35,9 @@ def _kernels(path):
             continue
         if body is None:
             continue
-        if re.match(r"^\.LBB\d+_\d+:", ln):            # the compiler annotates the blocks of a loop ("in Loop: Header=..." / "Loop Header")
+        # a basic block starts at a label or, where the previous block falls through into it, at the compiler's "; %bb.N:" comment
+        # (a wait behind a conditional branch at the end of an MFMA block is NOT in that block: conv1p's rare `last tile` path)
+        if re.match(r"^\.LBB\d+_\d+:", ln) or re.match(r"^; %bb\.\d+:", ln):      # the compiler annotates the blocks of a loop ("in Loop: Header=..." / "Loop Header")
             in_loop = "Loop" in ln
             if body["_mfma"] >= 8:
                 body["vm0_in_mfma_blocks"] += body["_vm0"]
