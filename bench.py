@@ -45,7 +45,7 @@ HBM_PEAK_GBPS = 8000.0                   # MI355X_MICROARCH.md: HBM3E spec peak 
 KERNEL_PEAK = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16": PEAK_BF16_MFMA_TFLOPS}
 KERNEL_NAME = {"fp32": "conv_kernel<9,128>", "bf16x6": "conv_bf_kernel<9,128,8,3>", "bf16": "conv_bf_kernel<9,128,8,1>"}
 PMC_KERNEL = {"fp32": "conv_kernel<9,128,8>", "bf16x6": "conv_bf_kernel<9,128,8,3>", "bf16": "conv_bf_kernel<9,128,8,1>"}
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")
 DTYPE = {"fp32": "f32", "bf16x6": "f32 (3xbf16 split, 6 products)", "bf16": "bf16"}
 ARITH = {"fp32": "fp32 (native fp32 MFMA; 3x3 convolutions through Winograd F(4x4,3x3) / F(2x2,3x3) transforms in fp32)", "bf16x6": "fp32-equivalent (3 bf16 planes, 6 products, fp32 accumulate)",
          "bf16": "bf16 operands, fp32 accumulate and storage"}
@@ -291,10 +291,10 @@ def dominant_kernel_roofline(step_fn, iso, math, shape_key, step_ms=None):
                    "fp32 MFMA peak -- a utilisation; the algorithmic rate (2 x 9 x Cin x Cout FLOP per pixel, what the metric counts) is "
                    "achieved_algorithmic.%s" % (EXECUTED.get(dom, 1.0),
                    "  In the timed step the weight-gradient kernels run CONCURRENTLY on a second stream: a launch's in-situ duration "
-                   "(`in_situ_shared`, and rocprofv3 --stats of this command: profiles/r05_bench_fp32_kernel_stats.csv) contains CUs "
+                   "(`in_situ_shared`, and rocprofv3 --stats of this command: profiles/r06_bench_fp32_kernel_stats.csv) contains CUs "
                    "shared with them and the kernel times add up to more than the step.  The headline figures (achieved, frac, "
                    "avg_launch_ms) are therefore the kernel BY ITSELF: the same step once more on one stream (BMC_WGRAD_STREAM=0; "
-                   "rocprofv3 --stats of that command: profiles/r05_bench_fp32_onestream_kernel_stats.csv).  `step_frac_executed` is the "
+                   "rocprofv3 --stats of that command: profiles/r06_bench_fp32_onestream_kernel_stats.csv).  `step_frac_executed` is the "
                    "whole two-stream step as one utilisation, `mfma_floor_ms` what its executed matrix FLOPs cost at the dense peak." if concurrent else ""),
            "traffic": traffic, "traffic_static": traffic is not None,
            "avg_launch_ms": d["avg_launch_ms"], "flop_per_launch": fl / n, "launches_per_step": n,

@@ -1,5 +1,8 @@
-cd $GRAFT_REPO_ROOT; L=$PWD/bmcnet-esr_amd/csrc; O=$PWD/gpurun_out; mkdir -p $O
+cd $GRAFT_REPO_ROOT; O=$PWD/gpurun_out; mkdir -p $O
 {
-for r in 1 2; do for s in hip hip_w4dprio10 hip_w4dprio11 hip_w4dprio12; do echo "== $r $s: $(W4_ONLY=1 KB_ITERS=300 BMC_HIP_LIB=$L/libbmc_$s.so timeout 200 python tools/time_wino4.py 2>&1 | grep 'F(4x4)' | sed 's/algorithmic.*executed//' | tr '\n' ' ')"; done; done
-} > $O/r06k.log 2>&1
-tail -40 $O/r06k.log
+for m in 1 2 3 1 2; do
+  BMC_WGRAD_MERGE=$m BMC_WGRAD_MERGE_MAX_PIXELS=4000000 timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-bf16x6 --also none > $O/r06l_merge$m.json 2> $O/r06l_merge$m.err
+  echo "merge $m: $(grep -o '"ms_per_step": [0-9.]*' $O/r06l_merge$m.json | head -1)"
+done
+} > $O/r06l.log 2>&1
+cat $O/r06l.log
