@@ -113,30 +113,51 @@ def cpu_baseline(dev=None, budget_hw=(180, 240), threads=16):
     t = _median(times[2:])
     frames = (H * W) / (180.0 * 240.0)
     # SURVEY 8(d) asks for the host's cores with the count stated: the same window on ALL logical CPUs of the box beside the
-    # measured optimum (torch-CPU's intra-op pool loses to its own synchronisation on this network from 32 threads up).  A quarter
-    # frame (90x120), 1 warm-up + 2 timed iterations: at 128+ threads a full frame would not fit the bounded-sample budget.
+    # measured optimum (torch-CPU's intra-op pool loses to its own synchronisation on this network from 32 threads up: 128 threads
+    # took 8.6 s per quarter frame, and 256 threads did not finish a quarter frame in 20 minutes on the EPYC 9575F host of round 6).
+    # So: the reference's own 45x80 frame, in a CHILD process with a hard 90 s limit -- a leg that does not finish says so instead of
+    # taking the bench line with it.
     all_cores = None
-    ncpu = os.cpu_count() or 1
+    # (one thread per PHYSICAL core: with one per logical CPU -- 256 on the EPYC 9575F host -- not one 45x80 window finished in 90 s)
+    ncpu = host_info().get("physical_cores") or os.cpu_count() or 1
     if ncpu > torch.get_num_threads():
-        used = torch.get_num_threads()
-        torch.set_num_threads(ncpu)
-        hq, wq = H // 2, W // 2
-        xq = torch.poisson(torch.full((1, 2, 2, hq, wq), 0.284))
-        gq = torch.poisson(torch.full((1, 2, scale * hq, scale * wq), 0.284))
-        zq = lambda c: torch.zeros(1, c, hq, wq)
-        tq = []
-        for it in range(3):
-            t0 = time.perf_counter()
-            _, _, _, pred = O.bmcnet_forward(params, xq, zq(n_c), zq(n_c), zq(n_c), zq(32), True, scale)
-            F.mse_loss(pred, gq).backward()
-            tq.append(time.perf_counter() - t0)
-            for p in seen.values():
-                p.grad = None
-        tqm = min(tq[1:])
-        all_cores = {"value": round((hq * wq) / (180.0 * 240.0) / tqm, 5), "unit": "LR-voxel-frames/s", "cores": ncpu,
-                     "sample": "the same window on a quarter frame (%dx%d), 1 warm-up + 2 timed (best %.2fs; all three: %s), %d torch threads = every "
-                               "logical CPU of the host" % (hq, wq, tqm, " ".join("%.2f" % v for v in tq), ncpu)}
-        torch.set_num_threads(used)
+        import subprocess
+        code = (
+            "import json, os, sys, time\n"
+            "sys.path[:0] = [%r, %r]\n"
+            "import torch, torch.nn.functional as F\n"
+            "from models.BMCNet import BMCNet\n"
+            "from oracle import bmc_oracle as O\n"
+            "torch.manual_seed(3407); torch.set_num_threads(%d)\n"
+            "m = BMCNet(4, 128, 5); params, seen = {}, {}\n"
+            "for k, v in m.state_dict().items(): params[k] = seen.setdefault(v.data_ptr(), v.clone().requires_grad_())\n"
+            "h, w = 45, 80\n"
+            "x = torch.poisson(torch.full((1, 2, 2, h, w), 0.284)); gt = torch.poisson(torch.full((1, 2, 4 * h, 4 * w), 0.284))\n"
+            "z = lambda c: torch.zeros(1, c, h, w); ts = []\n"
+            "for it in range(3):\n"
+            "    t0 = time.perf_counter()\n"
+            "    _, _, _, pred = O.bmcnet_forward(params, x, z(128), z(128), z(128), z(32), True, 4)\n"
+            "    F.mse_loss(pred, gt).backward(); ts.append(time.perf_counter() - t0)\n"
+            "    for p in seen.values(): p.grad = None\n"
+            "    print(json.dumps(ts), flush=True)\n"
+        ) % (ROOT, os.path.join(ROOT, "bmcnet-esr_amd"), ncpu)
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(ncpu))
+        sample = "one 45x80 window fwd+bwd (the reference's LR frame), B = 1, %d torch threads = one per physical core of the host (%d logical CPUs), child process" % (ncpu, os.cpu_count() or 1)
+        try:
+            r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=90)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("[")]
+            ts = json.loads(lines[-1]) if lines else []
+        except subprocess.TimeoutExpired as e:
+            out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+            lines = [l for l in out.splitlines() if l.startswith("[")]
+            ts = json.loads(lines[-1]) if lines else []
+            sample += "; stopped at the 90 s limit after %d of 3 iterations" % len(ts)
+        if ts:
+            tq = min(ts[1:]) if len(ts) > 1 else ts[0]
+            all_cores = {"value": round((45 * 80) / (180.0 * 240.0) / tq, 5), "unit": "LR-voxel-frames/s", "cores": ncpu,
+                         "sample": sample + " (seconds per iteration: %s; the 16-thread figure for the same window is other_samples.one_window_45x80)" % " ".join("%.2f" % v for v in ts)}
+        else:
+            all_cores = {"value": None, "unit": "LR-voxel-frames/s", "cores": ncpu, "sample": sample + ": no iteration finished"}
     # (iii) the reference's own LR frame (45x80, config/train_nfs.yml): one window forward+backward, and the FULL training-loop
     # body of train.py:202-237 -- 8 recurrent windows forward, summed MSE, one backward through all of them -- at B = 1.
     # (At 180x240 the 8-window BPTT of the CPU path keeps ~62 GB of activations -- SURVEY Appendix A.11 -- and takes > 60 s per
