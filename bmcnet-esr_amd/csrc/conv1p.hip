@@ -22,6 +22,9 @@
 #ifndef BMC_C1P_EPF
 #define BMC_C1P_EPF 1     // K = 256 instantiation: epilogue operands requested in front of the tile's MFMAs (round 6); 0: behind them
 #endif
+#ifndef BMC_C1P_SPREAD
+#define BMC_C1P_SPREAD 1  // the next tile's DMA pieces dealt out over the MFMA groups of the tile's first half (round 6); 0: one burst behind the first group
+#endif
 #ifndef BMC_C1P_ABL
 #define BMC_C1P_ABL 0     // ablation builds (tools/): 1 no MFMA, 2 no stores, 4 no pixel DMA, 8 no fragment reads
 #endif
@@ -101,16 +104,18 @@ __global__ __launch_bounds__(512, (NCH == 8 && DEPTH == 1) ? 4 : 2) void conv1p_
         }
         xl_b = b;
     };
-    auto issue_x = [&](const TileIt& it, int slot) {
+    // pieces j0 .. j1 - 1 of this wave's NCH / 2 DMA instructions for one tile
+    auto issue_x_part = [&](const TileIt& it, int slot, int j0, int j1) __attribute__((always_inline)) {
         if (BMC_C1P_ABL & 4) return;
         if (it.b != xl_b) loader_image(it.b);
         int p = it.pt * PX + lpx;
         p = p < HW ? p : HW - 1;
 #pragma unroll
-        for (int j = 0; j < NCH / 2; ++j)
+        for (int j = j0; j < j1; ++j)
             dma16(xbase[j], (unsigned)p * xstride[j] + lq * 4u,
                   x_lds + (unsigned)((slot * SLOT + ((wave >> 2) + 2 * j) * CHF + (wave & 3) * 256) * 4));
     };
+    auto issue_x = [&](const TileIt& it, int slot) { issue_x_part(it, slot, 0, NCH / 2); };
 
     // ---- this wave's weight slice: A fragments of output channels [nt * 128 + 16 w, + 16), k-steps = the 4 floats of a quad
     f32x4 wreg[NCH];
@@ -237,10 +242,22 @@ __global__ __launch_bounds__(512, (NCH == 8 && DEPTH == 1) ? 4 : 2) void conv1p_
                     else acc[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][j], xfA[pb][j], acc[pb], 0, 0, 0);
                 }
             if (c + 2 < NCH) read_x(xb, c + 2, xfA);
+#if BMC_C1P_SPREAD
+            // tile n + DEPTH into the buffer tile n - 1 was read from (before the previous barrier): requested between the MFMA
+            // groups of the tile's FIRST HALF, NCH / 8 pieces per group -- as one burst behind the first group (rounds 3-5) the
+            // eight pieces (~100 cycles each: two readfirstlanes, m0, the wait states) held every wave of the CU off the matrix pipe at
+            // the same moment
+            if (more && c < NCH / 2) {
+                constexpr int PER = (NCH / 2) / (NCH / 4);          // pieces per group: NCH / 2 pieces over NCH / 4 groups
+                issue_x_part(itl, nl % NS, (c / 2) * PER, (c / 2 + 1) * PER);
+                if (c == NCH / 2 - 2) { itl = advance(itl); tl += t_stride; ++nl; }
+            }
+#else
             if (c == 0 && more) {      // tile n + DEPTH into the buffer tile n - 1 was read from (before the previous barrier); requested
                                        // here, between MFMA groups, not in front of the tile's first MFMA
                 issue_x(itl, nl % NS); itl = advance(itl); tl += t_stride; ++nl;
             }
+#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll

@@ -1,6 +1,7 @@
-cd $GRAFT_REPO_ROOT; O=$PWD/gpurun_out; mkdir -p $O
+cd $GRAFT_REPO_ROOT; L=$PWD/bmcnet-esr_amd/csrc; O=$PWD/gpurun_out; mkdir -p $O
 {
-bash tools/gpu_run.sh r06 bench
-python3 -c "import json;d=json.load(open('$O/r06_bench.json'));print(d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['roofline']['pmc'], d['cpu_baseline']['all_host_cores']['value'])"
-} > $O/r06p.log 2>&1
-tail -5 $O/r06p.log | cut -c1-600
+for r in 1 2; do for s in hip hip_c1pspread0; do echo "== $r $s"; BMC_HIP_LIB=$L/libbmc_$s.so timeout 300 python tools/kbench.py conv1x256 conv1x256res conv1 apply 2>&1 | grep -v amdgpu.ids; done; done
+timeout 900 python -m pytest tests/test_gpu_r2.py tests/test_gpu_parity.py tests/test_gpu_r3.py -x -q -m gpu -k "bie or conv1 or golden or attn or chain or fuzz" 2>&1 | tail -3
+for s in hip hip_c1pspread0 hip hip_c1pspread0; do BMC_HIP_LIB=$L/libbmc_$s.so timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-bf16x6 --also none > $O/r06q_$s.json 2> $O/r06q_$s.err; echo "$s: $(grep -o '"ms_per_step": [0-9.]*' $O/r06q_$s.json | head -1)"; done
+} > $O/r06q.log 2>&1
+tail -40 $O/r06q.log
