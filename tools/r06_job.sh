@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT; L=$PWD/bmcnet-esr_amd/csrc; O=$PWD/gpurun_out; mkdir -p $O
 {
-for r in 1 2; do for s in hip hip_c1pspread0; do echo "== $r $s"; BMC_HIP_LIB=$L/libbmc_$s.so timeout 300 python tools/kbench.py conv1x256 conv1x256res conv1 apply 2>&1 | grep -v amdgpu.ids; done; done
-timeout 900 python -m pytest tests/test_gpu_r2.py tests/test_gpu_parity.py tests/test_gpu_r3.py -x -q -m gpu -k "bie or conv1 or golden or attn or chain or fuzz" 2>&1 | tail -3
-for s in hip hip_c1pspread0 hip hip_c1pspread0; do BMC_HIP_LIB=$L/libbmc_$s.so timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-bf16x6 --also none > $O/r06q_$s.json 2> $O/r06q_$s.err; echo "$s: $(grep -o '"ms_per_step": [0-9.]*' $O/r06q_$s.json | head -1)"; done
-} > $O/r06q.log 2>&1
-tail -40 $O/r06q.log
+for r in 1 2; do for s in hip hip_pgspread0; do echo "== $r $s: $(BMC_HIP_LIB=$L/libbmc_$s.so timeout 200 python tools/time_pgemm1.py 2>&1 | tail -1)"; BMC_HIP_LIB=$L/libbmc_$s.so timeout 300 python tools/kbench.py wgrad1 gram 2>&1 | grep -v amdgpu.ids; done; done
+timeout 1200 python -m pytest tests/test_gpu_r2.py tests/test_gpu_parity.py tests/test_gpu_r3.py tests/test_gpu_r5.py -x -q -m gpu -k "bie or pgemm or golden or attn or chain or fuzz or gram or wgrad or merge" 2>&1 | tail -3
+for s in hip hip_pgspread0 hip hip_pgspread0; do BMC_HIP_LIB=$L/libbmc_$s.so timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-bf16x6 --also none > $O/r06r_$s.json 2> $O/r06r_$s.err; echo "$s: $(grep -o '"ms_per_step": [0-9.]*' $O/r06r_$s.json | head -1)"; done
+} > $O/r06r.log 2>&1
+tail -40 $O/r06r.log
