@@ -11,10 +11,6 @@
 #include "pgemm_k.h"
 #include "dma_ring.h"
 
-#ifndef BMC_PG_SPREAD
-#define BMC_PG_SPREAD 1   // 1x1 instantiations: an interior tile's DMA pieces dealt out over the first four MFMA batches of the tile before it (round 6)
-#endif
-
 namespace {
 
 
@@ -111,17 +107,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
         //  hazard recognizer.  m0 is reserved and cannot be named as a clobber; nothing else in this kernel uses it.)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(la) : "memory");
     };
-    // defer = true: an interior tile's pieces are NOT issued here -- the function returns true and the caller issues them with
-    // issue_piece(0 .. 7) between its MFMA batches.  (All eight at the top of the tile, behind the barrier, held every wave of the CU
-    // off the matrix pipe at the same moment: ~100 cycles per piece -- three readfirstlanes, m0, the wait states.)
-    const float* df_a = nullptr;
-    const float* df_x = nullptr;
-    int df_buf = 0;
-    auto issue_piece = [&](int i) __attribute__((always_inline)) {
-        if (i < 4) dma(df_a, (unsigned)a_off[i], lds + df_buf * BUF + (i * 512 + wave * 64) * 4);
-        else dma(df_x, (unsigned)x_off[i - 4], lds + (2 + df_buf) * BUF + ((i - 4) * 512 + wave * 64) * 4);
-    };
-    auto issue = [&](int tile, int buf, bool defer = false) -> bool {      // must be called for tiles split, split + nsplit, ... in order
+    auto issue = [&](int tile, int buf) {      // must be called for tiles split, split + nsplit, ... in order
         const int b = g * a.batch_per_group + nx_bb;
         int y0 = 0, x0 = 0, p0 = 0;
         if (TAPS == 9) { y0 = nx_ty * PT_H; x0 = nx_tx * PT_W; }
@@ -137,15 +123,11 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
             const float* const abt = ab + (TAPS == 9 ? (long long)y0 * a.W + x0 : (long long)p0) * a.a.pix_stride;
             const float* const xbt = src_bp<TAB>(xs, b) +
                                      (TAPS == 9 ? (long long)(y0 - 1) * a.W + (x0 - 1) : (long long)p0) * xs.pix_stride;
-            if (defer) {           // the caller deals the eight pieces out over its MFMA batches (issue_piece)
-                df_a = abt; df_x = xbt; df_buf = buf;
-                return true;
-            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) dma(abt, (unsigned)a_off[i], lds + buf * BUF + (i * 512 + wave * 64) * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) dma(xbt, (unsigned)x_off[i], lds + (2 + buf) * BUF + (i * 512 + wave * 64) * 4);
-            return false;
+            return;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {            // A tile: [64 px][128 ch]
@@ -190,7 +172,6 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
             }
             dma16v(src, (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + (2 + buf) * BUF + (i * 512 + wave * 64) * 4));
         }
-        return false;
     };
 
     if (split < ntiles) issue(split, 0);
@@ -204,8 +185,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
     for (int tile = split; tile < ntiles; tile += a.nsplit, ++it) {
         const int cur = it & 1;
         const int next = tile + a.nsplit;
-        bool spread = false;
-        if (next < ntiles) spread = issue(next, cur ^ 1, BMC_PG_SPREAD && TAPS == 1 && wave_active);
+        if (next < ntiles) issue(next, cur ^ 1);
         if (do_bias) {
             const float* const bp = lds + cur * BUF + (tid >> 7) * 16 * 128 + (tid & 127);
 #pragma unroll
@@ -233,7 +213,6 @@ __global__ __launch_bounds__(512, 2) void pgemm_dma_kernel(const PgemmK a) {
 #pragma unroll
                 for (int qb = 0; qb < NBAT; ++qb) {
                     if (qb + 1 < NBAT) rd((qb + 1) & 1, (qb + 1) * QB);
-                    if (spread && qb < 4) { issue_piece(2 * qb); issue_piece(2 * qb + 1); }      // (the first half of the tile: the pieces land under the second)
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < QB; ++j)
