@@ -1,7 +1,7 @@
-cd $GRAFT_REPO_ROOT; L=$PWD/bmcnet-esr_amd/csrc; O=$PWD/gpurun_out; mkdir -p $O
+cd $GRAFT_REPO_ROOT; O=$PWD/gpurun_out; mkdir -p $O
+export BMC_PMC_COMMIT=fa91bc8
 {
-for r in 1 2; do for s in hip hip_pgspread0; do echo "== $r $s: $(BMC_HIP_LIB=$L/libbmc_$s.so timeout 200 python tools/time_pgemm1.py 2>&1 | tail -1)"; BMC_HIP_LIB=$L/libbmc_$s.so timeout 300 python tools/kbench.py wgrad1 gram 2>&1 | grep -v amdgpu.ids; done; done
-timeout 1200 python -m pytest tests/test_gpu_r2.py tests/test_gpu_parity.py tests/test_gpu_r3.py tests/test_gpu_r5.py -x -q -m gpu -k "bie or pgemm or golden or attn or chain or fuzz or gram or wgrad or merge" 2>&1 | tail -3
-for s in hip hip_pgspread0 hip hip_pgspread0; do BMC_HIP_LIB=$L/libbmc_$s.so timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-bf16x6 --also none > $O/r06r_$s.json 2> $O/r06r_$s.err; echo "$s: $(grep -o '"ms_per_step": [0-9.]*' $O/r06r_$s.json | head -1)"; done
-} > $O/r06r.log 2>&1
-tail -40 $O/r06r.log
+timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3
+bash tools/gpu_run.sh r06 stats stats1 pmc
+} > $O/r06s.log 2>&1
+tail -30 $O/r06s.log | cut -c1-300
