@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT; O=$PWD/gpurun_out; mkdir -p $O
-export BMC_PMC_COMMIT=fa91bc8
 {
-timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3
-bash tools/gpu_run.sh r06 stats stats1 pmc
-} > $O/r06s.log 2>&1
-tail -30 $O/r06s.log | cut -c1-300
+bash tools/gpu_run.sh r06 bench
+python3 -c "import json;d=json.load(open('$O/r06_bench.json'));print(d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['cpu_baseline']['all_host_cores']['value'])"
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/r06t_bench20.json 2> $O/r06t_bench20.err; python3 -c "import json;d=json.load(open('$O/r06t_bench20.json'));print('steps20', d['ms_per_step'], d['value'])"
+} > $O/r06t.log 2>&1
+tail -4 $O/r06t.log | cut -c1-300
