@@ -82,3 +82,37 @@ def test_wino_rows_rule_matches_the_host_side_tile_count():
         assert lib._wino_rows(B, H, W, 128, 0) == th, (B, H, W)
         assert ops.wino_tiles(B, H, W, 128) == (B * ((H + th - 1) // th) * ((W + 15) // 16), th)
     assert lib._wino_rows(8, 31, 56, 256, 0) == 8              # two channel tiles double the count: one round of 8-row tiles
+
+
+def test_bench_ranks_pin_to_disjoint_runs_of_physical_cores():
+    """bench.pin_rank_to_cores (round 6): every rank of `bench.py --gpus N` binds its host threads to its own run of physical cores
+    (SMT siblings included) BEFORE its first GPU call; the runs of different ranks are disjoint, a single rank is left alone, and
+    BMC_BENCH_PIN=0 switches it off.  Run in child processes: the call changes the caller's affinity."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib.util, json, os, sys\n"
+            "spec = importlib.util.spec_from_file_location('bench', os.path.join(%r, 'bench.py')); b = importlib.util.module_from_spec(spec)\n"
+            "sys.argv = ['bench.py']; spec.loader.exec_module(b)\n"
+            "before = sorted(os.sched_getaffinity(0))\n"
+            "info = b.pin_rank_to_cores(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(os.environ['W']))\n"
+            "print(json.dumps({'info': info, 'before': before, 'after': sorted(os.sched_getaffinity(0))}))\n") % root
+
+    def run(rank, world, pin="1"):
+        env = dict(os.environ, W=str(world), BMC_BENCH_PIN=pin)
+        r = subprocess.run([sys.executable, "-c", code.replace("sys.argv[1]) if len(sys.argv) > 1 else 0", "%d) if True else 0" % rank)],
+                           env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-1000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    one = run(0, 1)
+    assert one["info"] is None and one["after"] == one["before"]
+    if len(one["before"]) < 2:
+        pytest.skip("one CPU: nothing to share out")
+    a, b = run(0, 2), run(1, 2)
+    assert a["info"] and b["info"] and a["info"]["physical_cores"] == b["info"]["physical_cores"] >= 1
+    assert set(a["after"]).isdisjoint(b["after"]) and set(a["after"]) | set(b["after"]) <= set(one["before"])
+    assert a["after"] == list(range(a["info"]["first"], a["info"]["last"] + 1)) or len(a["after"]) == a["info"]["logical_cpus"]
+    off = run(1, 2, pin="0")
+    assert off["info"] is None and off["after"] == off["before"]
