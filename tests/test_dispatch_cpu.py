@@ -4,6 +4,8 @@ import gc
 import os
 import sys
 
+import pytest
+
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
