@@ -219,3 +219,59 @@ def test_bench_launcher_two_ranks_on_one_gpu():
     assert rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["higher_is_better"] is True
     assert rec["config"]["ranks_in_lock_step"] is True and rec["config"]["rccl_ranks"] == 2, rec["config"]
     assert rec["config"]["collective_backend"].startswith("gloo") and rec["config"]["rank_cpu_pinning"] is not None
+
+
+# ------------------------------------------------------------------ every epilogue form of the two kernels whose operand requests moved
+@pytest.mark.parametrize("kind", ["wino4", "conv1p"])
+@pytest.mark.parametrize("res,relu,mask,acc", [
+    (True, False, False, False), (False, True, True, False), (False, False, False, True), (True, True, False, True),
+    (False, False, True, True), (True, True, True, False), (True, True, True, True), (False, True, False, False)])
+def test_epilogue_forms_with_operands_requested_ahead(kind, res, relu, mask, acc):
+    """Round 6 moved the epilogue's operand requests in front of arithmetic: `wino4_conv_kernel` asks for the first tile row of the FIRST
+    operand the launch has (residual, else mask, else previous output) between the passes of its output transform,
+    `conv1p_kernel<16>` for all of them in front of the tile's MFMAs.  Every combination -- residual only, mask only, accumulate only,
+    mixed, none -- at RAGGED sizes (tiles / pixel runs that hang over the image: those lanes read a stand-in address) against float64:
+    out = [mask > 0] relu(conv + bias + residual) + previous output  (/root/reference/models/submodules.py:31-35 and its autograd)."""
+    dev = _gpu()
+    from bmc_hip import ops
+    from bmc_hip.ops import ConvSpec, _packed_weight, _src, conv_raw, coutpad
+    ops.set_math("fp32")
+    g = torch.Generator().manual_seed(641 + 8 * res + 4 * relu + 2 * mask + acc)
+    if kind == "wino4":
+        B, H, W, cin, taps, wino = 2, 19, 37, 128, 9, 4            # 10 x 5 tiles: the last workgroup tile of an image is partial
+    else:
+        B, H, W, cin, taps, wino = 3, 13, 21, 256, 1, 0            # 273 pixels: the last 64-pixel run of an image holds 17
+    Cn = 128
+    x = torch.randn(B, H, W, cin, generator=g)
+    w = torch.randn(Cn, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1, generator=g) / (cin * taps) ** 0.5
+    b = torch.randn(Cn, generator=g)
+    r = torch.randn(B, H, W, Cn, generator=g)
+    m = torch.randn(B, H, W, Cn, generator=g)
+    prev = torch.randn(B, H, W, Cn, generator=g)
+    y = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=taps // 9).permute(0, 2, 3, 1)
+    if res:
+        y = y + r.double()
+    if relu:
+        y = torch.relu(y)
+    if mask:
+        y = torch.where(m.double() > 0, y, torch.zeros_like(y))
+    if acc:
+        y = y + prev.double()
+    spec = ConvSpec.dense(cin)
+    xg, rg, mg = x.to(dev), r.to(dev), m.to(dev)
+    out = prev.to(dev).clone()
+    wp = _packed_weight(w.reshape(1, Cn, cin, taps).to(dev), spec, None, wino=wino) if wino else \
+        _packed_weight(w.reshape(1, Cn, cin, taps).to(dev), spec, None)
+    ops.PROFILE = []
+    try:
+        conv_raw([_src(xg, 0, cin, 0, None, 0, B)], wp, spec.kpad * taps * coutpad(Cn), b.reshape(1, Cn).to(dev), Cn, out.data_ptr(), H * W * Cn, Cn,
+                 B, H, W, Cn, taps, relu=relu, residual=_src(rg, 0, Cn, 0, None, 0, B) if res else None, bpg=B, accumulate=acc,
+                 mask=_src(mg, 0, Cn, 0, None, 0, B) if mask else None, wino=wino)
+        torch.cuda.synchronize()
+        kinds = [p[0] for p in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert kinds == (["wino4_conv<9,128>"] if kind == "wino4" else ["conv_kernel<1,128>"]), kinds
+    err = rel_l2(out, y)
+    print("%s res=%d relu=%d mask=%d acc=%d: %.2e" % (kind, res, relu, mask, acc, err))
+    assert err < (1e-5 if kind == "wino4" else 2e-6)
